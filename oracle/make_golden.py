@@ -1,0 +1,169 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in the build container, and
+check oracle/naf_oracle.py against it on the way.  TEST INFRASTRUCTURE; container-only.
+
+    python oracle/make_golden.py            # needs /root/reference (read-only) on disk
+
+The reference (valeoai/NAF, /root/reference) is imported unmodified; the only foreign piece is the
+``natten.functional`` stand-in of oracle/natten_shim.py (NATTEN is not installable here ->
+"parity unpinned" at that boundary, see naf_oracle.py's header).  Inputs and weights are NOT
+stored: they are regenerated anywhere from ``naf_oracle.hash_normal`` seeds recorded in each file.
+Only reference OUTPUTS (or strided samples of them) are stored, as float32 arrays.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("NAF_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from oracle import natten_shim            # noqa: E402
+from oracle import naf_oracle as O        # noqa: E402
+
+natten_shim.install()
+sys.path.insert(0, REF)
+import importlib.util                      # noqa: E402
+
+import src.layers as ref_layers           # noqa: E402  (reference: src/layers/__init__.py)
+
+try:                                       # reference: src/model/naf.py (the package __init__ drags in
+    from src.model.naf import NAF as RefNAF   # unrelated baselines that may need absent deps)
+except Exception:                          # pragma: no cover
+    spec = importlib.util.spec_from_file_location("ref_naf", os.path.join(REF, "src/model/naf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    RefNAF = mod.NAF
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def ref_model(params, **kw):
+    m = RefNAF(**kw).eval()
+    missing = m.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+report = {}
+
+# ---- F1: RoPE ---------------------------------------------------------------------------------
+x = O.hash_normal((1, 256, 6, 10), seed=101)
+rr = ref_layers.RoPE(embed_dim=256, num_heads=4, base=100.0, rescale_coords=2.0).eval()
+y_ref = rr(x)
+y_orc = O.rope(x, O.rope_periods(256, 4, 100.0), 4)
+report["F1 rope"] = maxdiff(y_ref, y_orc)
+assert maxdiff(rr.periods, O.rope_periods(256, 4, 100.0)) == 0.0
+save("F1_rope", seed=101, shape=[1, 256, 6, 10], heads=4, out=y_ref, periods=rr.periods)
+
+# ---- F2: conv stem (tiny dims; reflect pad, GN, SiLU, no residual) ------------------------------
+p2 = O.make_params(dim=32, heads_rope=2, seed=2)
+m2 = ref_model(p2, dim=32, heads_attn=2, heads_rope=2, kernel_size=3)
+img2 = O.hash_normal((1, 3, 20, 24), seed=202)
+e_ref = m2.image_encoder.forward_encoder(img2, (20, 24))
+e_orc = O.conv_stem(img2, p2)
+report["F2 conv stem"] = maxdiff(e_ref, e_orc)
+save("F2_conv_stem", param_seed=2, dim=32, heads_rope=2, image_seed=202, image_shape=[1, 3, 20, 24], out=e_ref)
+
+# ---- F3: attention only, integer ratio d=4, k=7, all border cells, with logits -------------------
+q3 = O.hash_normal((1, 256, 32, 48), seed=301)
+k3 = O.hash_normal((1, 256, 8, 12), seed=302)
+v3 = O.hash_normal((1, 24, 8, 12), seed=303)
+ca = ref_layers.CrossAttention(dim=256, num_heads=4, kernel_size=(7, 7))
+o_ref, l_ref = ca(q3, k3, v3, return_weights=True)
+o_orc, l_orc = O.xna(q3, k3, v3, 7, 4, return_logits=True)
+report["F3 xna out"] = maxdiff(o_ref, o_orc)
+report["F3 xna logits"] = maxdiff(l_ref, l_orc)
+report["F3 lowres form"] = maxdiff(o_ref, O.xna_lowres(q3, k3, v3, 7, 4))
+save("F3_xna_d4_k7", q_seed=301, k_seed=302, v_seed=303, q_shape=[1, 256, 32, 48], lr=[8, 12], C=24,
+     heads=4, k=7, out=o_ref, logits=l_ref)
+
+# ---- F4: non-multiple sizes 5x7 -> 23x30 (dilation 4,4 with remainders), k=3 and k=5 --------------
+q4 = O.hash_normal((1, 128, 23, 30), seed=401)
+k4 = O.hash_normal((1, 128, 5, 7), seed=402)
+v4 = O.hash_normal((1, 16, 5, 7), seed=403)
+f4 = {}
+for kk in (3, 5):
+    ca = ref_layers.CrossAttention(dim=128, num_heads=2, kernel_size=(kk, kk))
+    o_ref, l_ref = ca(q4, k4, v4, return_weights=True)
+    o_orc, l_orc = O.xna(q4, k4, v4, kk, 2, return_logits=True)
+    report[f"F4 k={kk} out"] = maxdiff(o_ref, o_orc)
+    report[f"F4 k={kk} logits"] = maxdiff(l_ref, l_orc)
+    f4[f"out_k{kk}"] = o_ref
+    f4[f"logits_k{kk}"] = l_ref
+save("F4_xna_nonmultiple", q_seed=401, k_seed=402, v_seed=403, q_shape=[1, 128, 23, 30], lr=[5, 7], C=16,
+     heads=2, **f4)
+
+# ---- F5: full P1 config (BASELINE configs[0]) -- 224^2, C=384, 14^2 -> 224^2, k=7 ------------------
+p5 = O.make_params(dim=256, heads_rope=4, seed=5)
+m5 = ref_model(p5, kernel_size=7)
+img5 = O.hash_normal((1, 3, 224, 224), seed=501)
+ft5 = O.hash_normal((1, 384, 14, 14), seed=502)
+o_ref = m5(img5, ft5, (224, 224))
+o_orc = O.naf_forward(p5, img5, ft5, (224, 224), kernel_size=7)
+o_fast = O.naf_forward_fast(p5, img5, ft5, (224, 224), kernel_size=7)
+report["F5 full P1"] = maxdiff(o_ref, o_orc)
+report["F5 full P1 (fast form)"] = maxdiff(o_ref, o_fast)
+save("F5_full_P1", param_seed=5, image_seed=501, feat_seed=502, k=7, stride=16, offset=[3, 5],
+     sample=o_ref[:, :, 3::16, 5::16].contiguous(), ch_mean=o_ref.mean(dim=(0, 2, 3)),
+     ch_absmax=o_ref.abs().amax(dim=(0, 2, 3)), top_rows=o_ref[:, ::48, :2, :].contiguous(),
+     left_cols=o_ref[:, ::48, :, -2:].contiguous())
+
+# ---- F6: denoising-like call (ratio 1, C=3, one head; denoising.py:213) ---------------------------
+p6 = O.make_params(dim=64, heads_rope=1, seed=6)
+m6 = ref_model(p6, dim=64, heads_attn=1, heads_rope=1, kernel_size=5)
+img6 = O.hash_normal((2, 3, 24, 20), seed=601)
+ft6 = O.hash_normal((2, 3, 24, 20), seed=602)
+o_ref, l_ref = m6(img6, ft6, (24, 20), return_weights=True)
+o_orc, l_orc = O.naf_forward(p6, img6, ft6, (24, 20), kernel_size=5, heads_attn=1, heads_rope=1,
+                             return_weights=True)
+report["F6 denoise out"] = maxdiff(o_ref, o_orc)
+report["F6 denoise logits"] = maxdiff(l_ref, l_orc)
+save("F6_denoise_d1", param_seed=6, dim=64, image_seed=601, feat_seed=602, shape=[2, 3, 24, 20], k=5,
+     out=o_ref, logits=l_ref)
+
+# ---- F7: image > 4x output (bilinear pre-shrink, naf.py:39-48) and image != output pooling (:34) ----
+p7 = O.make_params(dim=32, heads_rope=2, seed=7)
+m7 = ref_model(p7, dim=32, heads_attn=2, heads_rope=2, kernel_size=3)
+img7 = O.hash_normal((1, 3, 64, 80), seed=701)
+ft7 = O.hash_normal((1, 10, 6, 7), seed=702)
+o_ref_a = m7(img7, ft7, (12, 14))                                     # pre-shrink to 48x48, pool 48->12x14
+o_orc_a = O.naf_forward(p7, img7, ft7, (12, 14), kernel_size=3, heads_attn=2, heads_rope=2)
+img7b = O.hash_normal((1, 3, 36, 42), seed=703)
+o_ref_b = m7(img7b, ft7, (18, 21))                                    # 2x pooling, no pre-shrink
+o_orc_b = O.naf_forward(p7, img7b, ft7, (18, 21), kernel_size=3, heads_attn=2, heads_rope=2)
+report["F7a preshrink"] = maxdiff(o_ref_a, o_orc_a)
+report["F7b pooled"] = maxdiff(o_ref_b, o_orc_b)
+save("F7_preshrink_pool", param_seed=7, dim=32, image_seed_a=701, image_shape_a=[1, 3, 64, 80], out_size_a=[12, 14],
+     image_seed_b=703, image_shape_b=[1, 3, 36, 42], out_size_b=[18, 21], feat_seed=702,
+     feat_shape=[1, 10, 6, 7], k=3, out_a=o_ref_a, out_b=o_ref_b)
+
+print("\noracle vs imported reference (max abs diff, fp32):")
+worst = 0.0
+for k_, v_ in report.items():
+    print(f"  {k_:28s} {v_:.3e}")
+    worst = max(worst, v_)
+assert worst <= 1e-5, f"oracle deviates from the reference by {worst}"
+with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
+    f.write("oracle/naf_oracle.py vs imported reference + natten shim (max abs diff, fp32)\n")
+    for k_, v_ in report.items():
+        f.write(f"{k_:28s} {v_:.3e}\n")
+print("OK: oracle pinned to the imported reference (<= 1e-5) on F1-F7")
