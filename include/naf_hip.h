@@ -1,0 +1,141 @@
+/*
+ * naf_hip.h -- C ABI of libnaf_hip.so: MI355X (gfx950 / CDNA4) kernels for the NAF forward hot path.
+ *
+ * This is the drop-in boundary.  The reference (valeoai/NAF) is pure Python; the arithmetic of its
+ * cross-scale neighbourhood attention lives behind these foreign calls:
+ *
+ *     natten.functional.na2d_qk / na2d_av      src/layers/attentions.py:20,24   (NATTEN <= 0.17)
+ *     natten.na2d(..., backend="cutlass-fna")  src/layers/attentions.py:72      (NATTEN >= 0.20)
+ *
+ * plus torch-eager glue around them (nearest-exact K/V upsampling attentions.py:48-61, scale and
+ * softmax :21-23, RoPE rope.py:137-174, key pooling naf.py:63-69).  Each entry point below names the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is a HIP device pointer owned by the caller.
+ *   - the library allocates, retains and frees NO device memory; outputs and workspaces are the
+ *     caller's.  Launches are asynchronous on the caller's hipStream_t (passed as void*), on the
+ *     caller's current device.  Functions are re-entrant.
+ *   - return value 0 = success; non-zero = error, text via naf_last_error() (thread-local).
+ *     Nothing throws or aborts across the ABI.  Argument checks mirror the reference's failure modes
+ *     (NATTEN: odd kernel, kernel*dilation <= extent; einops: channels divisible by heads).
+ *   - strides are in ELEMENTS of the tensor's dtype.
+ */
+#ifndef NAF_HIP_H
+#define NAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAF_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef void* naf_stream_t; /* hipStream_t */
+
+enum naf_dtype { NAF_BF16 = 0, NAF_F32 = 1 };
+
+enum naf_status {
+    NAF_OK = 0,
+    NAF_ERR_INVALID = 1,     /* bad argument (shape / dtype / alignment / NULL) */
+    NAF_ERR_UNSUPPORTED = 2, /* valid request this build has no kernel for */
+    NAF_ERR_LAUNCH = 3       /* HIP runtime reported an error */
+};
+
+enum naf_xna_path {
+    NAF_XNA_AUTO = 0,    /* pick: MFMA cell kernel when eligible, else table-driven kernel */
+    NAF_XNA_MFMA = 1,    /* integer ratio Ho = dy*h, Wo = dx*w; one workgroup per (cell, head) */
+    NAF_XNA_GENERIC = 2  /* any sizes; needs idx_y / idx_x */
+};
+
+/* ---- library ------------------------------------------------------------------------------- */
+int naf_version(void);
+const char* naf_last_error(void);
+
+/* ---- host helper: which low-res rows/cols a hi-res query attends to (one axis) ------------------
+ * Replaces, for one axis, NATTEN's neighbourhood rule composed with the reference's nearest-exact
+ * upsampling of K/V (attentions.py:48-61 + NATTEN get_window_start, dilation = L_out / L_in).
+ * out_host[L_out * k] (HOST memory).  Errors like NATTEN: k even, k*dilation > L_out, L_out < L_in. */
+int naf_axis_index_table(int32_t* out_host, int32_t L_out, int32_t L_in, int32_t k);
+
+/* ---- RoPE tables --------------------------------------------------------------------------------
+ * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),
+ * eval mode.  tab_y device float [Ho][2][n_periods] (cos then sin), tab_x device float [Wo][2][..].
+ * periods: device float [n_periods] (the module's persistent buffer, rope.py:77-81). */
+int naf_rope_tables(float* tab_y, float* tab_x, const float* periods, int32_t n_periods, int32_t Ho,
+                    int32_t Wo, naf_stream_t stream);
+
+/* ---- RoPE + query write + key pooling, one pass ----------------------------------------------------
+ * Replaces RoPE.forward's rotation (rope.py:147-174), the identity QueryEncoder (naf.py:55-60) and
+ * KeyEncoder's adaptive_avg_pool2d of the ROTATED guidance (naf.py:63-69).
+ *   x      device, x_dtype, logical [B, Cq, Ho, Wo], element strides x_stride = {b, c, y, x}
+ *   q      device bf16, logical [B, heads, Ho, Wo, Dh], strides q_stride = {b, head, y, x}, Dh contiguous
+ *   k_lr   device bf16, logical [B, heads, h, w, Dh],   strides k_stride = {b, head, y, x}, Dh contiguous
+ * Dh = Cq / heads, Dh % 4 == 0.  Pool window of low-res row i: [floor(i*Ho/h), ceil((i+1)*Ho/h)). */
+typedef struct naf_rope_pool_args {
+    const void* x;
+    void* q;
+    void* k_lr;
+    const float* tab_y; /* [Ho][2][Dh/4] */
+    const float* tab_x; /* [Wo][2][Dh/4] */
+    int32_t x_dtype;    /* naf_dtype */
+    int32_t B, Cq, heads, Ho, Wo, h, w;
+    int64_t x_stride[4];
+    int64_t q_stride[4];
+    int64_t k_stride[4];
+} naf_rope_pool_args;
+int naf_rope_pool_fwd(const naf_rope_pool_args* a, naf_stream_t stream);
+
+/* ---- value packing --------------------------------------------------------------------------------
+ * Replaces the rearrange + dtype cast of the value tensor in CrossAttention._resize
+ * (attentions.py:50-51) WITHOUT the nearest-exact upsampling (values stay low-res).
+ *   v  device, v_dtype, logical [B, C, h, w], strides {b, c, y, x};   vp device bf16 [B, h, w, C] dense. */
+int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t C, int32_t h, int32_t w,
+                    const int64_t v_stride[4], naf_stream_t stream);
+
+/* ---- cross-scale neighbourhood attention forward -------------------------------------------------
+ * Replaces legacy_attention (attentions.py:16-29: na2d_qk -> *scale -> softmax -> na2d_av), the fused
+ * na2d call (attentions.py:72) and the K/V nearest-exact upsampling feeding them (attentions.py:60-61),
+ * evaluated directly on the low-res grid.
+ *   q      device bf16 [B, heads, Ho, Wo, Dq]   strides {b, head, y, x}, Dq contiguous
+ *   k_lr   device bf16 [B, heads, h, w, Dq]     strides {b, head, y, x}, Dq contiguous
+ *   v_lr   device bf16 [B, heads, h, w, Dv]     strides {b, head, y, x}, Dv contiguous
+ *   out    device out_dtype [B, heads, Ho, Wo, Dv] strides {b, head, y, x}, Dv contiguous
+ *          (a channels-last [B, Ho, Wo, heads*Dv] buffer is {Ho*Wo*C, Dv, Wo*C, C})
+ *   logits optional device float [B, heads, Ho, Wo, ky*kx] dense: scaled pre-softmax scores, i.e. what
+ *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.
+ *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the
+ *          generic path, ignored by the MFMA path (closed form, integer ratio).
+ * scale <= 0 selects the reference default Dq^-0.5 (attentions.py:46). */
+typedef struct naf_xna_args {
+    const void* q;
+    const void* k_lr;
+    const void* v_lr;
+    void* out;
+    float* logits;
+    const int32_t* idx_y;
+    const int32_t* idx_x;
+    int32_t B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx;
+    int32_t out_dtype; /* naf_dtype */
+    int32_t path;      /* naf_xna_path */
+    float scale;
+    int32_t reserved;
+    int64_t q_stride[4];
+    int64_t k_stride[4];
+    int64_t v_stride[4];
+    int64_t o_stride[4];
+} naf_xna_args;
+
+/* Which kernel naf_xna_fwd would run for these arguments (NAF_XNA_MFMA or NAF_XNA_GENERIC), or a
+ * negative naf_status on invalid arguments.  Lets the caller skip building index tables. */
+int naf_xna_select(const naf_xna_args* a);
+/* Scratch bytes the call needs (currently always 0; kept so callers need not change later). */
+size_t naf_workspace_bytes(const naf_xna_args* a);
+int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAF_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libnaf_hip.so (the C ABI declared in include/naf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or does not export every symbol,
+``load()`` raises and every op built on it raises with it.  ``import torch`` happens first on purpose:
+the library's DT_NEEDED libamdhip64.so.7 then resolves to the HIP runtime torch already mapped.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported before the HIP library is dlopen'ed)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
+
+NAF_BF16, NAF_F32 = 0, 1
+XNA_AUTO, XNA_MFMA, XNA_GENERIC = 0, 1, 2
+
+I64x4 = C.c_int64 * 4
+
+
+class RopePoolArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("q", C.c_void_p), ("k_lr", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p),
+        ("x_dtype", C.c_int32), ("B", C.c_int32), ("Cq", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32),
+        ("Wo", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("x_stride", I64x4), ("q_stride", I64x4), ("k_stride", I64x4),
+    ]
+
+
+class XnaArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k_lr", C.c_void_p), ("v_lr", C.c_void_p), ("out", C.c_void_p), ("logits", C.c_void_p),
+        ("idx_y", C.c_void_p), ("idx_x", C.c_void_p),
+        ("B", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
+        ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
+        ("out_dtype", C.c_int32), ("path", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32),
+        ("q_stride", I64x4), ("k_stride", I64x4), ("v_stride", I64x4), ("o_stride", I64x4),
+    ]
+
+
+# symbol -> (restype, argtypes); must list every function include/naf_hip.h declares
+SIGNATURES = {
+    "naf_version": (C.c_int, []),
+    "naf_last_error": (C.c_char_p, []),
+    "naf_axis_index_table": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
+    "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "naf_rope_pool_fwd": (C.c_int, [C.POINTER(RopePoolArgs), C.c_void_p]),
+    "naf_pack_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(C.c_int64), C.c_void_p]),
+    "naf_xna_select": (C.c_int, [C.POINTER(XnaArgs)]),
+    "naf_workspace_bytes": (C.c_size_t, [C.POINTER(XnaArgs)]),
+    "naf_xna_fwd": (C.c_int, [C.POINTER(XnaArgs), C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NafHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libnaf_hip.so and bind every declared symbol; raises NafHipError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NafHipError(
+                f"{LIB_PATH} not found: build it with `python -m naf_amd.build` (hipcc, gfx950). "
+                "naf_amd has no CPU or PyTorch fallback for its kernels.")
+        try:
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover
+            raise NafHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise NafHipError(f"{LIB_PATH} does not export {name}; rebuild with `python -m naf_amd.build --force`") from e
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().naf_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = last_error()
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise NafHipError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,49 @@
+// Shared device/host helpers for libnaf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "naf_hip.h"
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+#define NAF_LDS __attribute__((address_space(3)))
+
+// ---- error plumbing (naf_api.cpp owns the storage) ----
+void naf_set_error(const char* fmt, ...);
+int naf_check_launch(const char* what);
+
+#define NAF_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            naf_set_error(__VA_ARGS__); \
+            return NAF_ERR_INVALID;   \
+        }                             \
+    } while (0)
+
+// ---- kernel launchers implemented in the .hip files ----
+int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s);      // xna_mfma.hip
+int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out);  // xna_mfma.hip
+int naf_launch_xna_generic(const naf_xna_args* a, float scale, hipStream_t s);   // xna_generic.hip
+int naf_launch_rope_tables(float* ty, float* tx, const float* periods, int np, int Ho, int Wo, hipStream_t s);
+int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);             // rope_pool.hip
+int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, int h, int w,
+                           const int64_t* vs, hipStream_t s);                    // pack.hip
+
+// ---- device helpers ----
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// Bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD one contiguous
+// range of logical ids so neighbouring cells (which share K/V windows) meet in the same L2.
+__device__ __forceinline__ uint32_t naf_xcd_remap(uint32_t bid, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u, xcd = bid & 7u, idx = bid >> 3;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,218 @@
+// RoPE tables + (RoPE -> bf16 query write -> key pooling) in one pass over the guidance features.
+//
+// Replaces rope.py:84-105,137-174 (eval-mode coordinates), the identity QueryEncoder (naf.py:55-60)
+// and KeyEncoder's adaptive_avg_pool2d of the ROTATED guidance (naf.py:63-69; pooled AFTER RoPE).
+//
+// RoPE (rope.py:15-34,139-153): inside each head of Dh channels, channel t < Dh/2 is paired with
+// t + Dh/2; angle index a = t: a < Dh/4 uses the row coordinate and periods[a], a >= Dh/4 uses the
+// column coordinate and periods[a - Dh/4]:
+//      out[t]        = x[t] * cos - x[t + Dh/2] * sin
+//      out[t + Dh/2] = x[t + Dh/2] * cos + x[t] * sin
+// coordinates c = 2 * (i + 0.5) / L - 1, angle = 2*pi*c / period, all fp32 like the reference.
+//
+// One workgroup per low-res cell.  It walks the cell's adaptive-pool window
+// [floor(i*Ho/h), ceil((i+1)*Ho/h)) x [...], rotates every pixel once in fp32, accumulates the key
+// mean in fp32 and writes the bf16 query for the pixels it OWNS ([floor(i*Ho/h), floor((i+1)*Ho/h)):
+// the owned ranges partition the image, pool windows may overlap by one row/column when Ho % h != 0).
+#include "naf_common.h"
+
+__global__ void rope_tables_kernel(float* tab, const float* periods, int np, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * np) return;
+    const int pos = i / np, a = i - pos * np;
+    // rope.py:102-105: coords = arange(0.5, L) / L ; coords = 2*coords - 1
+    const float c = 2.0f * (((float)pos + 0.5f) / (float)L) - 1.0f;
+    // rope.py:139: angles = 2*pi*coords / periods
+    const float ang = (6.283185307179586f * c) / periods[a];
+    tab[(pos * 2 + 0) * np + a] = cosf(ang);
+    tab[(pos * 2 + 1) * np + a] = sinf(ang);
+}
+
+int naf_launch_rope_tables(float* ty, float* tx, const float* periods, int np, int Ho, int Wo, hipStream_t s) {
+    hipLaunchKernelGGL(rope_tables_kernel, dim3((Ho * np + 255) / 256), dim3(256), 0, s, ty, periods, np, Ho);
+    hipLaunchKernelGGL(rope_tables_kernel, dim3((Wo * np + 255) / 256), dim3(256), 0, s, tx, periods, np, Wo);
+    return naf_check_launch("rope_tables_kernel");
+}
+
+struct RopePoolParams {
+    const void* x;
+    bf16_t* q;
+    bf16_t* k;
+    const float* tab_y;
+    const float* tab_x;
+    int32_t B, Cq, heads, Dh, Ho, Wo, h, w;
+    int32_t tpp;     // threads per pixel (power of two dividing 256)
+    int32_t nchunk;  // pair-chunks per pixel = Cq / (2 * VEC)
+    int64_t xs[4], qs[4], ks[4];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* p, int64_t cstride, float (&o)[VEC]) {
+    if constexpr (VEC == 8 && sizeof(T) == 2) {
+        if (cstride == 1) {
+            const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+            return;
+        }
+    }
+    if constexpr (VEC == 8 && sizeof(T) == 4) {
+        if (cstride == 1) {
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = a[i];
+                o[4 + i] = b[i];
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = (float)p[i * cstride];
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_bf16(bf16_t* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 8) {
+        bf16x8_t o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x8_t*>(p) = o;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p[i] = (bf16_t)v[i];
+    }
+}
+
+// T = input element type, VEC = channels per thread per half (8: vector path, 1: any Dh % 4 == 0)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [256 / tpp][Cq]
+    const int tid = threadIdx.x;
+    int L = blockIdx.x;
+    const int cx = L % p.w;
+    L /= p.w;
+    const int cy = L % p.h;
+    const int b = L / p.h;
+
+    // adaptive_avg_pool2d window (naf.py:68) and the owned (query-writing) range
+    const int ys = (int)(((int64_t)cy * p.Ho) / p.h), ye = (int)((((int64_t)cy + 1) * p.Ho + p.h - 1) / p.h);
+    const int xs = (int)(((int64_t)cx * p.Wo) / p.w), xe = (int)((((int64_t)cx + 1) * p.Wo + p.w - 1) / p.w);
+    const int yo = (int)((((int64_t)cy + 1) * p.Ho) / p.h), xo = (int)((((int64_t)cx + 1) * p.Wo) / p.w);
+    const int wy = ye - ys, wx = xe - xs;
+    const int npix = wy * wx;
+
+    const int chunk = tid & (p.tpp - 1);
+    const int plane = tid / p.tpp;
+    const int nplanes = 256 / p.tpp;
+    const bool active = chunk < p.nchunk;
+
+    const int half = p.Dh >> 1, quarter = p.Dh >> 2;
+    // pair-chunk -> (head, t0): chunks enumerate t in [0, Dh/2) per head
+    const int cph = half / VEC;  // chunks per head
+    const int head = active ? chunk / cph : 0;
+    const int t0 = active ? (chunk - head * cph) * VEC : 0;
+    const int c1 = head * p.Dh + t0;  // first-half channel; partner is c1 + half
+
+    float acc1[VEC], acc2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc1[i] = acc2[i] = 0.f;
+
+    const T* xb = reinterpret_cast<const T*>(p.x) + b * p.xs[0];
+    if (active) {
+        for (int pi = plane; pi < npix; pi += nplanes) {
+            const int py = pi / wx, px = pi - py * wx;
+            const int y = ys + py, x = xs + px;
+            const T* xp = xb + (int64_t)y * p.xs[2] + (int64_t)x * p.xs[3];
+            float v1[VEC], v2[VEC], cs[VEC], sn[VEC];
+            load_vec<T, VEC>(xp + (int64_t)c1 * p.xs[1], p.xs[1], v1);
+            load_vec<T, VEC>(xp + (int64_t)(c1 + half) * p.xs[1], p.xs[1], v2);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const int a = t0 + i;
+                const float* tb = (a < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + a)
+                                                : (p.tab_x + (int64_t)x * 2 * quarter + (a - quarter));
+                cs[i] = tb[0];
+                sn[i] = tb[quarter];
+            }
+            float o1[VEC], o2[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                o1[i] = v1[i] * cs[i] - v2[i] * sn[i];
+                o2[i] = v2[i] * cs[i] + v1[i] * sn[i];
+                acc1[i] += o1[i];
+                acc2[i] += o2[i];
+            }
+            if (y < yo && x < xo) {
+                bf16_t* qp = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)y * p.qs[2] + (int64_t)x * p.qs[3] + t0;
+                store_bf16<VEC>(qp, o1);
+                store_bf16<VEC>(qp + half, o2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            red[plane * p.Cq + c1 + i] = acc1[i];
+            red[plane * p.Cq + c1 + half + i] = acc2[i];
+        }
+    }
+    __syncthreads();
+    const float invn = 1.0f / (float)npix;
+    for (int c = tid; c < p.Cq; c += 256) {
+        float s = 0.f;
+        for (int pl = 0; pl < nplanes; ++pl) s += red[pl * p.Cq + c];
+        const int hd = c / p.Dh, d = c - hd * p.Dh;
+        p.k[b * p.ks[0] + hd * p.ks[1] + (int64_t)cy * p.ks[2] + (int64_t)cx * p.ks[3] + d] = (bf16_t)(s * invn);
+    }
+}
+
+int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
+    RopePoolParams p;
+    p.x = a->x;
+    p.q = static_cast<bf16_t*>(a->q);
+    p.k = static_cast<bf16_t*>(a->k_lr);
+    p.tab_y = a->tab_y;
+    p.tab_x = a->tab_x;
+    p.B = a->B; p.Cq = a->Cq; p.heads = a->heads; p.Dh = a->Cq / a->heads;
+    p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
+    for (int i = 0; i < 4; ++i) {
+        p.xs[i] = a->x_stride[i]; p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i];
+    }
+    // vector path: 8 channels per half per thread, needs Dh % 32 == 0 (a chunk never straddles the
+    // row/column angle split) and 16-byte alignment of every access
+    const size_t esz = a->x_dtype == NAF_BF16 ? 2 : 4;
+    bool vec = (p.Dh % 32 == 0);
+    vec = vec && (reinterpret_cast<uintptr_t>(a->q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a->x) % 16 == 0);
+    for (int i = 0; i < 4; ++i) vec = vec && (a->q_stride[i] % 8 == 0);
+    if (a->x_stride[1] == 1) {
+        vec = vec && (a->x_stride[0] * esz % 16 == 0) && (a->x_stride[2] * esz % 16 == 0) && (a->x_stride[3] * esz % 16 == 0);
+    }
+    const int VECN = vec ? 8 : 1;
+    p.nchunk = a->Cq / (2 * VECN);
+    int tpp = 1;
+    while (tpp < p.nchunk) tpp <<= 1;
+    if (tpp > 256) {
+        naf_set_error("naf_rope_pool_fwd: guidance dim %d too large for this kernel (%d pair-chunks per pixel > 256)", a->Cq, p.nchunk);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    p.tpp = tpp;
+    const size_t lds = (size_t)(256 / tpp) * a->Cq * sizeof(float);
+    if (lds > 64 * 1024) {
+        naf_set_error("naf_rope_pool_fwd: reduction scratch %zu B exceeds 64 KiB (Cq=%d)", lds, a->Cq);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    const int64_t nb = (int64_t)a->B * a->h * a->w;
+    if (nb <= 0 || nb > 0x7fffffffLL) {
+        naf_set_error("naf_rope_pool_fwd: grid out of range");
+        return NAF_ERR_INVALID;
+    }
+    const dim3 g((uint32_t)nb), blk(256);
+    if (a->x_dtype == NAF_BF16) {
+        if (vec) hipLaunchKernelGGL((rope_pool_kernel<bf16_t, 8>), g, blk, lds, s, p);
+        else hipLaunchKernelGGL((rope_pool_kernel<bf16_t, 1>), g, blk, lds, s, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((rope_pool_kernel<float, 8>), g, blk, lds, s, p);
+        else hipLaunchKernelGGL((rope_pool_kernel<float, 1>), g, blk, lds, s, p);
+    }
+    return naf_check_launch("rope_pool_kernel");
+}

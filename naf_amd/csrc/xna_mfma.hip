@@ -1,0 +1,80 @@
+// Eligibility test + dispatcher for the MFMA cell kernel (see xna_mfma_kernel.h).
+#include "xna_mfma_kernel.h"
+
+#define NAF_DECL(K) int naf_xna_mfma_launch_k##K(const XnaMfmaParams& p, int dvt, int out_dtype, hipStream_t s);
+NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13) NAF_DECL(15)
+#undef NAF_DECL
+
+static size_t lds_for(int ks, int dvt) {
+    const int kpad = ((ks * ks + 31) / 32) * 32;
+    return (size_t)kpad * (72 + dvt + 16) * 2;
+}
+
+static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Returns 1 when the MFMA cell kernel can serve the request (and the Dv tile / LDS bytes it would
+// use), 0 otherwise.  Never sets the error string: ineligibility is not an error.
+int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) {
+    if (a->ky != a->kx) return 0;
+    const int ks = a->ky;
+    if (ks < 3 || ks > 15 || (ks & 1) == 0) return 0;
+    if (a->Dq != 64) return 0;
+    if (a->logits != nullptr) return 0;
+    if (a->h < ks || a->w < ks) return 0;
+    if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
+    if (a->Dv % 16 != 0) return 0;
+    if (!aligned_to(a->q, 16) || !aligned_to(a->k_lr, 16) || !aligned_to(a->v_lr, 16) || !aligned_to(a->out, 16)) return 0;
+    for (int i = 0; i < 4; ++i) {
+        if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->o_stride[i] % 4) return 0;
+    }
+    static const int cand[] = {256, 192, 128, 96, 64, 32};
+    for (int c : cand) {
+        if (a->Dv % c == 0 && lds_for(ks, c) <= 160 * 1024) {
+            if (dvt_out) *dvt_out = c;
+            if (lds_out) *lds_out = lds_for(ks, c);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
+    int dvt = 0;
+    size_t lds = 0;
+    if (!naf_xna_mfma_eligible(a, &dvt, &lds)) {
+        naf_set_error(
+            "naf_xna_fwd: MFMA path needs square odd kernel 3..15, Dq=64, integer ratio, h,w >= kernel, Dv %% 16 == 0, "
+            "16-byte aligned tensors and no logits output (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
+            a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    XnaMfmaParams p;
+    p.q = static_cast<const bf16_t*>(a->q);
+    p.k = static_cast<const bf16_t*>(a->k_lr);
+    p.v = static_cast<const bf16_t*>(a->v_lr);
+    p.out = a->out;
+    p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
+    p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
+    p.nchunk = a->Dv / dvt;
+    const int64_t nb = (int64_t)a->B * a->h * a->w * a->heads * p.nchunk;
+    if (nb <= 0 || nb > 0x7fffffffLL) {
+        naf_set_error("naf_xna_fwd: grid of %lld workgroups out of range", (long long)nb);
+        return NAF_ERR_INVALID;
+    }
+    p.nblocks = (uint32_t)nb;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    for (int i = 0; i < 4; ++i) {
+        p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i]; p.os[i] = a->o_stride[i];
+    }
+    switch (a->ky) {
+        case 3: return naf_xna_mfma_launch_k3(p, dvt, a->out_dtype, s);
+        case 5: return naf_xna_mfma_launch_k5(p, dvt, a->out_dtype, s);
+        case 7: return naf_xna_mfma_launch_k7(p, dvt, a->out_dtype, s);
+        case 9: return naf_xna_mfma_launch_k9(p, dvt, a->out_dtype, s);
+        case 11: return naf_xna_mfma_launch_k11(p, dvt, a->out_dtype, s);
+        case 13: return naf_xna_mfma_launch_k13(p, dvt, a->out_dtype, s);
+        case 15: return naf_xna_mfma_launch_k15(p, dvt, a->out_dtype, s);
+    }
+    naf_set_error("naf_xna_fwd: kernel size %d has no MFMA instantiation", a->ky);
+    return NAF_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,98 @@
+"""Batch sharding of the NAF forward across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The path is embarrassingly parallel over the batch: GroupNorm is per-sample (convolutions.py:83-84)
+and RoPE / pooling / attention are per-image, so activations never cross GPUs.  Collectives are used
+only off the data path:
+  * one broadcast of the flattened parameters (662 528 fp32 = 2.65 MB) at start-up;
+  * optional scatter of rank-0-owned inputs;
+  * all-gather of small per-rank results (timings, checksums) -- or, on request, of the outputs.
+The reference has no distributed code at all; this is new functionality asked
+for by BASELINE.json, written directly against torch.distributed ("nccl" == RCCL on ROCm, "gloo" on CPU
+for the tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition of ``n_items`` images: first ``n % world`` ranks get one extra."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """One flat broadcast of every parameter and persistent buffer (so all ranks run rank-``src``'s
+    weights).  2.65 MB for the default NAF: latency-bound, done once."""
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+        off += n
+
+
+def scatter_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, device, src: int = 0) -> torch.Tensor:
+    """Rank ``src`` owns ``full`` [N, ...]; every rank receives its ``shard_range`` slice."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(shape[0], rank, world)
+    out = torch.empty((hi - lo, *shape[1:]), dtype=dtype, device=device)
+    if rank == src:
+        chunks = []
+        for r in range(world):
+            a, b = shard_range(shape[0], r, world)
+            chunks.append(full[a:b].contiguous())
+        for r in range(world):
+            if r == src:
+                out.copy_(chunks[r])
+            elif chunks[r].numel():
+                dist.send(chunks[r], dst=r)
+    elif out.numel():
+        dist.recv(out, src=src)
+    return out
+
+
+def gather_scalars(values: Sequence[float], device) -> List[List[float]]:
+    """All-gather a short list of floats from every rank (timings, checksums)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [o.tolist() for o in outs]
+
+
+def gather_outputs(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """Optional mode: all-gather the per-rank outputs into the full batch (137 GB at G3 -- far more
+    expensive than the compute; off by default)."""
+    world = dist.get_world_size()
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    mx = max(b - a for a, b in sizes)
+    pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: b - a] for o, (a, b) in zip(outs, sizes)], dim=0)
+
+
+class ShardedNAF:
+    """Runs ``model`` on this rank's slice of a batch, in micro-batches to bound the encoder's
+    activations (fp32/bf16 guidance at full resolution)."""
+
+    def __init__(self, model: torch.nn.Module, micro_batch: int = 2):
+        self.model = model
+        self.micro_batch = max(1, int(micro_batch))
+
+    def __call__(self, image: torch.Tensor, features: torch.Tensor, output_size) -> torch.Tensor:
+        outs = []
+        for i in range(0, image.shape[0], self.micro_batch):
+            outs.append(self.model(image[i:i + self.micro_batch], features[i:i + self.micro_batch], output_size))
+        return torch.cat(outs, dim=0) if len(outs) != 1 else outs[0]

@@ -1,0 +1,218 @@
+"""NAF upsampler module: the reference's public operator (``naf(image, lr_features, target_size)``)
+on MI355X-native kernels.
+
+Mirrors the reference's module tree so that ``state_dict`` keys, constructor arguments and the
+attributes callers read are identical (src/model/naf.py:72-116, src/layers/convolutions.py:6-92,
+src/layers/rope.py:39-83, src/layers/attentions.py:32-47):
+
+    NAF.image_encoder.encoder / .sem_encoder    nn.Sequential(Conv2d, EncBlock, ...)  (1x1 / 3x3-reflect)
+    NAF.image_encoder.rope.periods              persistent buffer [D_head / 4]
+    NAF.query_encoder, NAF.key_encoder          parameter-free
+    NAF.upsampler.kernel_size / .num_heads / .scale / .dilation
+
+The forward pass differs in HOW, not WHAT:
+  * K/V are never upsampled to the output grid and the score tensor is never materialised
+    (attentions.py:60-61,20-23 do both);
+  * RoPE, the identity query encoder and the key pooling are one HIP pass (naf_rope_pool_fwd);
+  * attention runs in the fused HIP kernel (naf_xna_fwd): MFMA cell kernel for integer ratios,
+    table-driven kernel otherwise and for ``return_weights``.
+Contract: bf16 queries/keys/values, fp32 softmax and accumulation; the output dtype follows
+``features`` (bf16 -> bf16, anything else -> fp32) and is returned as a logical [B, C, Ho, Wo]
+view of a channels-last buffer -- the same view the reference returns on its fused NATTEN path
+(attentions.py:75).  Inputs must live on a ROCm device; there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+class EncBlock(nn.Module):
+    """GroupNorm(8) -> SiLU -> Conv -> GroupNorm(8) -> SiLU -> Conv, reflect padding, no skip
+    (convolutions.py:6-64 with residual=False, in == out channels so no shortcut conv exists)."""
+
+    def __init__(self, channels: int, kernel_size: int, num_groups: int = 8, bias: bool = True):
+        super().__init__()
+        pad = kernel_size // 2
+        self.norm1 = nn.GroupNorm(num_groups, channels)
+        self.conv1 = nn.Conv2d(channels, channels, kernel_size, padding=pad, padding_mode="reflect", bias=bias)
+        self.norm2 = nn.GroupNorm(num_groups, channels)
+        self.conv2 = nn.Conv2d(channels, channels, kernel_size, padding=pad, padding_mode="reflect", bias=bias)
+
+
+def make_branch(in_dim: int, hidden: int, kernel_size: int, ks_res: int, num_layers: int) -> nn.Sequential:
+    """Same parameter layout as the reference's ``encoder(...)`` (convolutions.py:67-92)."""
+    return nn.Sequential(
+        nn.Conv2d(in_dim, hidden, kernel_size, padding=kernel_size // 2, padding_mode="reflect", bias=True),
+        *[EncBlock(hidden, ks_res) for _ in range(num_layers)],
+    )
+
+
+class RoPE(nn.Module):
+    """Holds the `periods` buffer (rope.py:77-81,128-135) and caches the device sin/cos tables per
+    output size, like the reference caches coordinates per (H, W) (rope.py:159-161).  Only the
+    deterministic eval-mode coordinates exist here (train-time shift/jitter/rescale: rope.py:107-124)."""
+
+    def __init__(self, embed_dim: int, num_heads: int, base: float = 100.0, rescale_coords: Optional[float] = None):
+        super().__init__()
+        if embed_dim % (4 * num_heads):
+            raise AssertionError("embed_dim must be divisible by 4 * num_heads")
+        self.num_heads = num_heads
+        self.base = base
+        self.D_head = embed_dim // num_heads
+        self.rescale_coords = rescale_coords
+        d = self.D_head
+        periods = base ** (2 * torch.arange(d // 4, dtype=torch.float32) / (d // 2))
+        self.register_buffer("periods", periods, persistent=True)
+        self._tables = None
+        self._tables_key = None
+
+    def tables(self, Ho: int, Wo: int):
+        p = self.periods
+        key = (Ho, Wo, str(p.device), p.data_ptr(), p._version)
+        if key != self._tables_key:
+            self._tables = ops.rope_tables(p, Ho, Wo)
+            self._tables_key = key
+        return self._tables
+
+
+class ImageEncoder(nn.Module):
+    """Guidance encoder (naf.py:11-52).  The two conv branches currently run through
+    torch/MIOpen in ``stem_dtype`` (bf16, channels-last); RoPE is applied by the caller's fused
+    rope+pool kernel, not here."""
+
+    def __init__(self, in_channels=3, out_channels=256, heads_rope=1, use_encoder=True, rope_base=None,
+                 rope_rescale=None, img_layers=2):
+        super().__init__()
+        self.use_encoder = use_encoder
+        self.out_channels = out_channels
+        self.encoder = make_branch(in_channels, out_channels // 2, 1, 1, img_layers)
+        self.sem_encoder = make_branch(in_channels, out_channels // 2, 3, 3, img_layers)
+        self.rope = RoPE(out_channels, num_heads=heads_rope, base=rope_base, rescale_coords=rope_rescale)
+        self.stem_dtype = torch.bfloat16
+
+    @staticmethod
+    def _conv(x, conv: nn.Conv2d, dt):
+        pad = conv.kernel_size[0] // 2
+        if pad:
+            x = F.pad(x, (pad, pad, pad, pad), mode="reflect")
+        return F.conv2d(x, conv.weight.to(dt), None if conv.bias is None else conv.bias.to(dt))
+
+    def _branch(self, x, seq: nn.Sequential, dt):
+        x = self._conv(x, seq[0], dt)
+        for blk in list(seq)[1:]:
+            x = F.silu(F.group_norm(x, blk.norm1.num_groups, blk.norm1.weight.to(dt), blk.norm1.bias.to(dt), blk.norm1.eps))
+            x = self._conv(x, blk.conv1, dt)
+            x = F.silu(F.group_norm(x, blk.norm2.num_groups, blk.norm2.weight.to(dt), blk.norm2.bias.to(dt), blk.norm2.eps))
+            x = self._conv(x, blk.conv2, dt)
+        return x
+
+    def guidance(self, image: torch.Tensor, output_size: Tuple[int, int]) -> torch.Tensor:
+        """Pre-RoPE guidance features, logical [B, dim, Ho, Wo] (naf.py:37-49 + :31-35)."""
+        ho, wo = output_size
+        x = image
+        if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
+            x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
+                              mode="bilinear", align_corners=False)
+        if self.use_encoder:
+            dt = self.stem_dtype
+            x = x.to(dt).contiguous(memory_format=torch.channels_last)
+            x = torch.cat([self._branch(x, self.encoder, dt), self._branch(x, self.sem_encoder, dt)], dim=1)
+        if x.shape[-2:] != (ho, wo):
+            x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
+        return x.contiguous(memory_format=torch.channels_last)
+
+
+class QueryEncoder(nn.Module):
+    """Identity (naf.py:55-60)."""
+
+    def forward(self, x):
+        return x
+
+
+class KeyEncoder(nn.Module):
+    """Parameter-free; the pooling itself happens inside the fused rope+pool kernel (naf.py:63-69)."""
+
+    def forward(self, x, features):  # pragma: no cover - kept for API shape only
+        raise RuntimeError("naf_amd: KeyEncoder pooling is fused into naf_rope_pool_fwd; call NAF.forward")
+
+
+class CrossAttention(nn.Module):
+    """Cross-scale neighbourhood attention (attentions.py:32-75) on naf_xna_fwd."""
+
+    def __init__(self, dim, num_heads, kernel_size=(9, 9), **kwargs):
+        super().__init__()
+        assert dim % num_heads == 0, "dim must be divisible by num_heads"
+        self.num_heads = num_heads
+        self.kernel_size = tuple(kernel_size)
+        self.scale = (dim // num_heads) ** -0.5
+        self.dilation = None
+
+    def forward(self, q5, k5, values, return_weights=False, path="auto"):
+        """q5/k5: 5-D bf16 views from ops.rope_pool; values: [B, C, h, w] features."""
+        B, C = values.shape[:2]
+        if C % self.num_heads:
+            raise ValueError(f"feature channels {C} not divisible by {self.num_heads} heads")   # einops error in the reference
+        Ho, Wo = q5.shape[2:4]
+        h, w = values.shape[-2:]
+        self.dilation = (Ho // h, Wo // w)                                     # attentions.py:56-57
+        vp = ops.pack_values(values)
+        v5 = vp.view(B, h, w, self.num_heads, C // self.num_heads).permute(0, 3, 1, 2, 4)
+        out_dtype = torch.bfloat16 if values.dtype == torch.bfloat16 else torch.float32
+        res = ops.xna_forward(q5, k5, v5, self.kernel_size, out_dtype=out_dtype, return_logits=return_weights,
+                              path="generic" if return_weights else path, scale=self.scale)
+        out5, logits = res if return_weights else (res, None)
+        # [B, heads, Ho, Wo, Dv] view of a channels-last buffer -> logical [B, C, Ho, Wo]
+        out = out5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, C).permute(0, 3, 1, 2)
+        if values.dtype not in (torch.bfloat16, torch.float32):
+            out = out.to(values.dtype)
+        return (out, logits) if return_weights else out
+
+
+class NAF(nn.Module):
+    """Drop-in for the reference's ``NAF`` (naf.py:72-116): same constructor, same ``state_dict``."""
+
+    def __init__(self, dim=256, heads_attn=4, heads_rope=4, kernel_size=9, use_encoder=True, rope_base=100.0,
+                 rope_rescale=2.0, img_layers=2, **kwargs):
+        super().__init__()
+        self.image_encoder = ImageEncoder(in_channels=3, out_channels=dim, heads_rope=heads_rope,
+                                          use_encoder=use_encoder, rope_base=rope_base, img_layers=img_layers,
+                                          rope_rescale=rope_rescale)
+        self.query_encoder = QueryEncoder()
+        self.key_encoder = KeyEncoder()
+        self.upsampler = CrossAttention(dim=dim, num_heads=heads_attn, kernel_size=(kernel_size, kernel_size))
+        self.xna_path = "auto"
+
+    def guidance_qk(self, image, lr_size, output_size):
+        """RoPE'd bf16 queries and pooled keys (5-D views) for ``image``."""
+        ho, wo = int(output_size[0]), int(output_size[1])
+        enc = self.image_encoder
+        with ops._Timed("stem"):
+            x = enc.guidance(image, (ho, wo))
+        tab_y, tab_x = enc.rope.tables(ho, wo)
+        heads_rope, heads_attn = enc.rope.num_heads, self.upsampler.num_heads
+        same = heads_attn == heads_rope
+        q5, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, q_layout="head_major" if same else "channels_last")
+        if not same:        # re-split the channel axis for attention: pure views of channels-last buffers
+            B, _, Ho, Wo, _ = q5.shape
+            dim = enc.out_channels
+            q5 = q5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, heads_attn, dim // heads_attn).permute(0, 3, 1, 2, 4)
+            h, w = k5.shape[2:4]
+            k5 = k5.permute(0, 2, 3, 1, 4).reshape(B, h, w, heads_attn, dim // heads_attn).permute(0, 3, 1, 2, 4)
+        return q5, k5
+
+    @torch.no_grad()
+    def forward(self, image, features, output_size, return_weights=False, *args, **kwargs):
+        if not (image.is_cuda and features.is_cuda):
+            raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback); got "
+                               f"image on {image.device}, features on {features.device}")
+        if image.dim() != 4 or features.dim() != 4 or image.shape[0] != features.shape[0]:
+            raise ValueError(f"expected image [B,3,H,W] and features [B,C,h,w], got {tuple(image.shape)} / {tuple(features.shape)}")
+        q5, k5 = self.guidance_qk(image, features.shape[-2:], output_size)
+        with ops._Timed("attention"):
+            return self.upsampler(q5, k5, features, return_weights=return_weights, path=self.xna_path)

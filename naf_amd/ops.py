@@ -1,0 +1,226 @@
+"""Host-side operators over libnaf_hip.so: thin, typed wrappers that hand raw device pointers, element
+strides and torch's current HIP stream to the C ABI.  torch is plumbing here (device memory, streams);
+every kernel is the library's.  There is no CPU / eager fallback: CPU tensors raise.
+
+Reference counterparts (paths relative to the reference repo):
+  axis_index_table   NATTEN neighbourhood rule + nearest-exact map      src/layers/attentions.py:48-61
+  rope_tables        RoPE.create_coordinate / angle, sin, cos           src/layers/rope.py:84-105,137-146
+  rope_pool          RoPE.forward rotation + KeyEncoder pooling         src/layers/rope.py:147-174, src/model/naf.py:63-69
+  pack_values        CrossAttention._resize layout/dtype part           src/layers/attentions.py:50-51
+  xna_forward        legacy_attention / na2d                            src/layers/attentions.py:16-29,72
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import XnaArgs, RopePoolArgs, I64x4
+
+_DT = {torch.bfloat16: _lib.NAF_BF16, torch.float32: _lib.NAF_F32}
+
+# Optional kernel timer (bench.py): an object with start(name) / stop(name) that records HIP events on
+# the CURRENT stream tightly around one C-ABI launch.  None in normal operation.
+KERNEL_TIMER = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_TIMER is not None:
+            KERNEL_TIMER.start(self.name)
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMER is not None:
+            KERNEL_TIMER.stop(self.name)
+        return False
+_PATH = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "generic": _lib.XNA_GENERIC}
+
+
+def _gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"naf_amd: `{name}` is on {t.device}; the NAF hot path only exists as HIP kernels for a "
+                           "ROCm device (no CPU fallback). Move the module and its inputs to 'cuda'.")
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _strides4(t: torch.Tensor, dims) -> I64x4:
+    return I64x4(*[int(t.stride(d)) for d in dims])
+
+
+# ------------------------------------------------------------------------------------------------
+def axis_index_table(L_out: int, L_in: int, k: int) -> torch.Tensor:
+    """[L_out, k] int32 CPU tensor of low-res indices (host function of the library, no GPU needed)."""
+    lib = _lib.load()
+    if L_out <= 0 or k <= 0:
+        raise ValueError(f"axis_index_table: bad sizes L_out={L_out} k={k}")
+    out = torch.empty((int(L_out), int(k)), dtype=torch.int32)
+    rc = lib.naf_axis_index_table(C.cast(out.data_ptr(), C.POINTER(C.c_int32)), int(L_out), int(L_in), int(k))
+    _lib.check(rc, "naf_axis_index_table")
+    return out
+
+
+_table_cache = {}
+
+
+def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
+    key = (int(L_out), int(L_in), int(k), str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        if len(_table_cache) > 64:
+            _table_cache.clear()
+        t = axis_index_table(L_out, L_in, k).to(device)
+        _table_cache[key] = t
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+def rope_tables(periods: torch.Tensor, Ho: int, Wo: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin tables [Ho, 2, P] and [Wo, 2, P] (fp32) for the module's `periods` buffer [P]."""
+    _gpu(periods, "periods")
+    lib = _lib.load()
+    per = periods.detach().to(torch.float32).contiguous()
+    P = per.numel()
+    ty = torch.empty((Ho, 2, P), dtype=torch.float32, device=per.device)
+    tx = torch.empty((Wo, 2, P), dtype=torch.float32, device=per.device)
+    with torch.cuda.device(per.device):
+        rc = lib.naf_rope_tables(ty.data_ptr(), tx.data_ptr(), per.data_ptr(), P, int(Ho), int(Wo), _stream(per))
+    _lib.check(rc, "naf_rope_tables")
+    return ty, tx
+
+
+def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: int, lr_size,
+              q_layout: str = "head_major") -> Tuple[torch.Tensor, torch.Tensor]:
+    """x: logical [B, Cq, Ho, Wo] (bf16/fp32, any strides; channels-last is the fast layout).
+    Returns q [B, heads, Ho, Wo, Dh] bf16 (RoPE'd queries) and k_lr [B, heads, h, w, Dh] bf16
+    (adaptive-avg-pooled RoPE'd keys), both as 5-D strided views with Dh contiguous."""
+    _gpu(x, "guidance features")
+    lib = _lib.load()
+    if x.dtype not in _DT:
+        x = x.float()
+    B, Cq, Ho, Wo = x.shape
+    h, w = int(lr_size[0]), int(lr_size[1])
+    if Cq % heads:
+        raise ValueError(f"rope_pool: {Cq} channels not divisible by {heads} heads")
+    Dh = Cq // heads
+    dev = x.device
+    if q_layout == "head_major":
+        q = torch.empty((B, heads, Ho, Wo, Dh), dtype=torch.bfloat16, device=dev)
+    elif q_layout == "channels_last":
+        q = torch.empty((B, Ho, Wo, heads, Dh), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
+    else:
+        raise ValueError(f"unknown q_layout {q_layout!r}")
+    k = torch.empty((B, h, w, heads, Dh), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
+    a = RopePoolArgs()
+    a.x, a.q, a.k_lr = x.data_ptr(), q.data_ptr(), k.data_ptr()
+    a.tab_y, a.tab_x = tab_y.data_ptr(), tab_x.data_ptr()
+    a.x_dtype = _DT[x.dtype]
+    a.B, a.Cq, a.heads, a.Ho, a.Wo, a.h, a.w = B, Cq, heads, Ho, Wo, h, w
+    a.x_stride = _strides4(x, (0, 1, 2, 3))
+    a.q_stride = _strides4(q, (0, 1, 2, 3))
+    a.k_stride = _strides4(k, (0, 1, 2, 3))
+    if tab_y.shape != (Ho, 2, Dh // 4) or tab_x.shape != (Wo, 2, Dh // 4):
+        raise ValueError(f"rope_pool: tables {tuple(tab_y.shape)}/{tuple(tab_x.shape)} do not match Ho={Ho} Wo={Wo} Dh/4={Dh // 4}")
+    with torch.cuda.device(dev), _Timed("rope_pool"):
+        rc = lib.naf_rope_pool_fwd(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_rope_pool_fwd")
+    return q, k
+
+
+def pack_values(v: torch.Tensor) -> torch.Tensor:
+    """[B, C, h, w] (bf16/fp32, any strides) -> dense channels-last bf16 [B, h, w, C]."""
+    _gpu(v, "lr_features")
+    lib = _lib.load()
+    if v.dtype not in _DT:
+        v = v.float()
+    B, Cc, h, w = v.shape
+    vp = torch.empty((B, h, w, Cc), dtype=torch.bfloat16, device=v.device)
+    st = _strides4(v, (0, 1, 2, 3))
+    with torch.cuda.device(v.device):
+        rc = lib.naf_pack_values(vp.data_ptr(), v.data_ptr(), _DT[v.dtype], B, Cc, h, w, st, _stream(v))
+    _lib.check(rc, "naf_pack_values")
+    return vp
+
+
+def _fill_xna(q, k, v, out, logits, idx_y, idx_x, ky, kx, path, scale) -> XnaArgs:
+    B, heads, Ho, Wo, Dq = q.shape
+    _, _, h, w, Dv = v.shape
+    a = XnaArgs()
+    a.q, a.k_lr, a.v_lr, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.logits = logits.data_ptr() if logits is not None else None
+    a.idx_y = idx_y.data_ptr() if idx_y is not None else None
+    a.idx_x = idx_x.data_ptr() if idx_x is not None else None
+    a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx
+    a.out_dtype = _DT[out.dtype]
+    a.path = _PATH[path]
+    a.scale = float(scale) if scale else 0.0
+    a.q_stride = _strides4(q, (0, 1, 2, 3))
+    a.k_stride = _strides4(k, (0, 1, 2, 3))
+    a.v_stride = _strides4(v, (0, 1, 2, 3))
+    a.o_stride = _strides4(out, (0, 1, 2, 3))
+    return a
+
+
+def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size, *,
+                out_dtype: torch.dtype = torch.bfloat16, return_logits: bool = False, path: str = "auto",
+                scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+    """Cross-scale neighbourhood attention forward.
+
+    q [B, heads, Ho, Wo, Dq] bf16, k_lr [B, heads, h, w, Dq] bf16, v_lr [B, heads, h, w, Dv] bf16 --
+    5-D strided views with the last dim contiguous.  Returns ``out`` as a [B, heads, Ho, Wo, Dv] view
+    of a dense channels-last [B, Ho, Wo, heads*Dv] buffer (and, with ``return_logits``, the scaled
+    pre-softmax scores [B, heads, Ho, Wo, ky*kx] fp32 -- what the reference's return_weights gives).
+    """
+    for t, n in ((q, "q"), (k_lr, "k_lr"), (v_lr, "v_lr")):
+        _gpu(t, n)
+        if t.dtype != torch.bfloat16:
+            raise TypeError(f"xna_forward: {n} must be bfloat16, got {t.dtype}")
+        if t.dim() != 5 or t.stride(4) != 1:
+            raise ValueError(f"xna_forward: {n} must be 5-D [B, heads, H, W, D] with D contiguous")
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    B, heads, Ho, Wo, Dq = q.shape
+    _, _, h, w, Dv = v_lr.shape
+    if k_lr.shape != (B, heads, h, w, Dq):
+        raise ValueError(f"xna_forward: k_lr shape {tuple(k_lr.shape)} does not match q/v")
+    if out_dtype not in _DT:
+        raise TypeError(f"xna_forward: out_dtype {out_dtype} not supported (bfloat16 / float32)")
+    dev = q.device
+    if out is None:
+        out = torch.empty((B, Ho, Wo, heads, Dv), dtype=out_dtype, device=dev).permute(0, 3, 1, 2, 4)
+    logits = torch.empty((B, heads, Ho, Wo, ky * kx), dtype=torch.float32, device=dev) if return_logits else None
+    a = _fill_xna(q, k_lr, v_lr, out, logits, None, None, ky, kx, path, scale)
+    sel = lib.naf_xna_select(C.byref(a))
+    if sel < 0:
+        _lib.check(-sel, "naf_xna_select")
+    if sel == _lib.XNA_GENERIC:
+        iy = device_index_table(Ho, h, ky, dev)
+        ix = device_index_table(Wo, w, kx, dev)
+        a.idx_y, a.idx_x = iy.data_ptr(), ix.data_ptr()
+    with torch.cuda.device(dev), _Timed("xna_mfma" if sel == _lib.XNA_MFMA else "xna_generic"):
+        rc = lib.naf_xna_fwd(C.byref(a), _stream(q))
+    _lib.check(rc, "naf_xna_fwd")
+    return (out, logits) if return_logits else out
+
+
+def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logits=False, path="auto") -> str:
+    """Name of the kernel ``xna_forward`` would dispatch to ('mfma' / 'generic') -- for tests / bench."""
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else tuple(kernel_size)
+    B, heads, Ho, Wo, Dq = q.shape
+    Dv = v_lr.shape[-1]
+    out = torch.empty((1,), dtype=out_dtype, device=q.device)
+    fake = torch.empty((1,), dtype=torch.float32, device=q.device) if return_logits else None
+    a = _fill_xna(q, k_lr, v_lr, out, fake, None, None, ky, kx, path, None)
+    a.o_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    sel = lib.naf_xna_select(C.byref(a))
+    if sel < 0:
+        _lib.check(-sel, "naf_xna_select")
+    return {1: "mfma", 2: "generic"}[sel]

@@ -208,8 +208,13 @@ def natten_window_start(i: int, L: int, k: int, dil: int) -> int:
 def nearest_exact_src(L_out: int, L_in: int) -> np.ndarray:
     """F.interpolate(mode='nearest-exact') source index: floor((i + 0.5) * L_in / L_out), clamped
     (attentions.py:48-49)."""
-    i = np.arange(L_out, dtype=np.float64)
-    return np.minimum(np.floor((i + 0.5) * (L_in / L_out)).astype(np.int64), L_in - 1)
+    # ATen device arithmetic (UpSample.cuh nearest_neighbor_exact_compute_source_index): all fp32.
+    # torch's CPU build agrees except at exact ties (i + 0.5) * L_in / L_out == integer for a few
+    # non-integer ratios, where its FMA-contracted code rounds the other way.
+    i = np.arange(L_out, dtype=np.float32)
+    scale = np.float32(L_in) / np.float32(L_out)
+    prod = (i + np.float32(0.5)) * scale
+    return np.minimum(np.floor(prod).astype(np.int64), L_in - 1)
 
 
 def axis_index_table(L_out: int, L_in: int, k: int) -> np.ndarray:

@@ -1,0 +1,122 @@
+"""CPU tests of the drop-in boundary: libnaf_hip.so builds for gfx950, loads, exports every symbol that
+include/naf_hip.h declares; the host-side functions and the Python mirror of the reference interface
+behave like the reference (names, arguments, errors).  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "naf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(naf_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(built_lib):
+    lib = C.CDLL(built_lib)
+    declared = _declared_symbols()
+    assert {"naf_version", "naf_last_error", "naf_axis_index_table", "naf_rope_tables", "naf_rope_pool_fwd",
+            "naf_pack_values", "naf_xna_select", "naf_workspace_bytes", "naf_xna_fwd"} <= set(declared)
+    for name in declared:
+        assert hasattr(lib, name), f"libnaf_hip.so does not export {name}"
+    from naf_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes binding and header disagree"
+    lib.naf_version.restype = C.c_int
+    assert lib.naf_version() >= 100
+
+
+def test_struct_layout_matches_header(built_lib):
+    """sizeof of the ctypes mirrors == the C structs (checked through a tiny C probe compiled with gcc)."""
+    import subprocess, tempfile
+    from naf_amd import _lib
+    src = '#include "naf_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", sizeof(naf_rope_pool_args), sizeof(naf_xna_args));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        a, b = map(int, subprocess.check_output([os.path.join(d, "p")]).split())
+    assert a == C.sizeof(_lib.RopePoolArgs) and b == C.sizeof(_lib.XnaArgs)
+
+
+@pytest.mark.parametrize("L_in", [1, 2, 3, 5, 7, 14, 28, 32, 64])
+def test_axis_index_table_matches_oracle(built_lib, L_in):
+    from naf_amd import ops
+    n = 0
+    for L_out in list(range(L_in, 4 * L_in + 3)) + [16 * L_in, 16 * L_in + 5, 32 * L_in]:
+        for k in (1, 3, 5, 7, 9, 15):
+            if k * (L_out // L_in) > L_out:
+                with pytest.raises(ValueError):
+                    ops.axis_index_table(L_out, L_in, k)
+                continue
+            t = ops.axis_index_table(L_out, L_in, k).numpy()
+            assert np.array_equal(t, O.axis_index_table(L_out, L_in, k)), (L_out, L_in, k)
+            assert t.min() >= 0 and t.max() < L_in
+            n += 1
+    assert n > 0
+
+
+def test_axis_index_table_errors_mirror_natten(built_lib):
+    from naf_amd import ops
+    with pytest.raises(ValueError, match="odd"):
+        ops.axis_index_table(16, 4, 4)
+    with pytest.raises(ValueError, match="exceeds"):
+        ops.axis_index_table(20, 5, 7)
+    with pytest.raises(ValueError, match="smaller"):
+        ops.axis_index_table(4, 8, 3)
+
+
+def test_module_mirrors_reference_interface():
+    from naf_amd import NAF
+    m = NAF()
+    sd = m.state_dict()
+    ref_keys = set(O.make_params().keys())
+    assert set(sd.keys()) == ref_keys                       # 36 conv/GN tensors + rope periods
+    assert sum(p.numel() for p in m.parameters()) == 662528   # test/test_results.json:255 "# Params"
+    assert m.upsampler.kernel_size == (9, 9) and m.upsampler.num_heads == 4
+    assert abs(m.upsampler.scale - 0.125) < 1e-12
+    assert torch.equal(m.image_encoder.rope.periods, O.rope_periods(256, 4, 100.0))
+    m.load_state_dict(O.make_params(seed=3), strict=True)
+    m2 = NAF(dim=96, heads_attn=1, heads_rope=1, kernel_size=15, img_layers=2, use_semencoder=True)   # denoising.py notes
+    assert m2.upsampler.kernel_size == (15, 15)
+    with pytest.raises(AssertionError):
+        NAF(dim=128, heads_attn=3)          # attentions.py:41 "dim must be divisible by num_heads"
+
+
+def test_forward_has_no_cpu_fallback():
+    from naf_amd import NAF
+    m = NAF()
+    with pytest.raises(RuntimeError, match="ROCm"):
+        m(torch.zeros(1, 3, 16, 16), torch.zeros(1, 8, 4, 4), (16, 16))
+
+
+def test_product_never_imports_oracle():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import naf_amd, naf_amd.ops, naf_amd.dist, hubconf; "
+            "bad=[m for m in sys.modules if m.split('.')[0]=='oracle']; assert not bad, bad") % ROOT
+    subprocess.check_call([sys.executable, "-c", code])
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "naf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("no oracle", ""), f
+
+
+def test_hubconf_entry_point():
+    import hubconf
+    m = hubconf.naf(pretrained=False, device="cpu")
+    assert not m.training and type(m).__name__ == "NAF"
+    assert "naf" in dir(hubconf) and hubconf.dependencies == ["torch"]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from naf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NafHipError, match="no CPU or PyTorch fallback"):
+        _lib.load()

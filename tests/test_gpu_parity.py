@@ -1,0 +1,361 @@
+"""GPU parity tests (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the golden vectors produced by the imported reference.
+
+Tolerances (fp, stated here as the prompt asks):
+  * kernels fed bf16-rounded inputs vs the fp32 oracle on the SAME rounded inputs:
+      fp32 output  : |err| <= 6e-3 + 6e-3*|ref|   (P is rounded to bf16 before the PV MFMA: rel 2^-9 per weight)
+      bf16 output  : |err| <= 1.2e-2 + 1.2e-2*|ref|  (+ one bf16 rounding of the result)
+  * whole forward (bf16 conv stem through MIOpen, bf16 Q/K/V) vs the fp32 reference golden vectors:
+      |err| <= 6e-2 + 3e-2*|ref| elementwise and mean |err| <= 6e-3 (outputs are O(1)).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from naf_amd import _lib
+    _lib.load()                      # fail loudly if the HIP library is missing on a GPU box
+    return torch.device("cuda:0")
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def to5(x, heads):
+    """[B, C, H, W] fp32 -> bf16 5-D [B, heads, H, W, D] (head-major, D contiguous)."""
+    B, C, H, W = x.shape
+    return x.view(B, heads, C // heads, H, W).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16)
+
+
+def run_xna(dev, q, k, v, ksz, heads, out_dtype=torch.float32, path="auto", return_logits=False):
+    from naf_amd import ops
+    B, C = v.shape[:2]
+    h, w = v.shape[-2:]
+    q5, k5 = to5(q, heads).to(dev), to5(k, heads).to(dev)
+    vp = ops.pack_values(v.to(dev))
+    v5 = vp.view(B, h, w, heads, C // heads).permute(0, 3, 1, 2, 4)
+    res = ops.xna_forward(q5, k5, v5, ksz, out_dtype=out_dtype, path=path, return_logits=return_logits)
+    out5, lg = res if return_logits else (res, None)
+    Ho, Wo = q.shape[-2:]
+    out = out5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, C).permute(0, 3, 1, 2).float().cpu()
+    torch.cuda.synchronize()
+    return (out, lg.cpu()) if return_logits else out
+
+
+def assert_close(got, ref, atol, rtol, what=""):
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err "
+                                 f"{float(err.max()):.4e} at {np.unravel_index(int(err.argmax()), err.shape)}; "
+                                 f"ref absmax {float(ref.abs().max()):.3f}")
+
+
+# ---- rope tables / rope+pool / pack -----------------------------------------------------------------
+def test_rope_tables(dev):
+    from naf_amd import ops
+    per = O.rope_periods(256, 4, 100.0)
+    ty, tx = ops.rope_tables(per.to(dev), 37, 50)
+    ang = O.rope_angles(37, 50, per).view(37, 50, 64)
+    assert (ty[:, 0].cpu() - torch.cos(ang[:, 0, :16])).abs().max() < 2e-6
+    assert (ty[:, 1].cpu() - torch.sin(ang[:, 0, :16])).abs().max() < 2e-6
+    assert (tx[:, 0].cpu() - torch.cos(ang[0, :, 16:32])).abs().max() < 2e-6
+    assert (tx[:, 1].cpu() - torch.sin(ang[0, :, 16:32])).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("shape,heads,lr,fmt", [
+    ((1, 256, 32, 48), 4, (8, 12), "nhwc_f32"),       # integer ratio, vector path
+    ((2, 256, 23, 30), 4, (5, 7), "nhwc_bf16"),       # overlapping pool windows (Ho % h != 0)
+    ((1, 64, 12, 10), 1, (12, 10), "nchw_f32"),       # ratio 1, one head of 64, strided (NCHW) input
+    ((1, 24, 9, 8), 2, (3, 4), "nchw_f32"),           # Dh = 12: scalar path
+    ((1, 96, 16, 16), 1, (4, 4), "nhwc_f32"),         # Dh = 96 (denoising dims)
+])
+def test_rope_pool(dev, shape, heads, lr, fmt):
+    from naf_amd import ops
+    B, C, H, W = shape
+    x = O.hash_normal(shape, 77)
+    if "bf16" in fmt:
+        x = bf16r(x)
+    per = O.rope_periods(C, heads, 100.0)
+    ref_q = O.rope(x, per, heads)
+    ref_k = O.key_pool(ref_q, lr)
+    xd = x.to(dev)
+    if "bf16" in fmt:
+        xd = xd.to(torch.bfloat16)
+    if "nhwc" in fmt:
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    ty, tx = ops.rope_tables(per.to(dev), H, W)
+    for layout in ("head_major", "channels_last"):
+        q5, k5 = ops.rope_pool(xd, ty, tx, heads, lr, q_layout=layout)
+        q = q5.permute(0, 1, 4, 2, 3).reshape(B, C, H, W).float().cpu()
+        k = k5.permute(0, 1, 4, 2, 3).reshape(B, C, *lr).float().cpu()
+        assert_close(q, ref_q, 1e-5, 2 ** -8, f"q {fmt} {layout}")       # one bf16 rounding
+        assert_close(k, ref_k, 1e-5, 2 ** -8, f"k {fmt} {layout}")
+
+
+def test_pack_values(dev):
+    from naf_amd import ops
+    v = O.hash_normal((2, 50, 7, 9), 5)
+    for src in (v.to(dev), v.to(dev).to(torch.bfloat16), v.to(dev).permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)):
+        vp = ops.pack_values(src)
+        assert vp.shape == (2, 7, 9, 50) and vp.dtype == torch.bfloat16
+        assert torch.equal(vp.cpu(), src.permute(0, 2, 3, 1).to(torch.bfloat16).cpu())
+
+
+# ---- attention: staged checks that localise a layout error -------------------------------------------
+def test_xna_mfma_uniform_attention_is_window_mean(dev):
+    """q = 0 -> uniform weights: out = mean of the clamped window of V (checks gather, masks, V^T reads,
+    store layout without any QK dependence)."""
+    h, w, d, ksz, C, heads = 9, 11, 4, 7, 128, 4
+    q = torch.zeros(1, 256, h * d, w * d)
+    k = O.hash_normal((1, 256, h, w), 1)
+    v = bf16r(O.hash_normal((1, C, h, w), 2))
+    ref = O.xna_lowres(q, k, v, ksz, heads)
+    out = run_xna(dev, q, k, v, ksz, heads, path="mfma")
+    assert_close(out, ref, 6e-3, 6e-3, "uniform attention")
+
+
+def test_xna_mfma_constant_values(dev):
+    h, w, d, ksz, heads = 8, 8, 4, 5, 4
+    q = O.hash_normal((1, 256, h * d, w * d), 3)
+    k = O.hash_normal((1, 256, h, w), 4)
+    v = torch.arange(64, dtype=torch.float32).view(1, 64, 1, 1).expand(1, 64, h, w).contiguous() / 16.0
+    out = run_xna(dev, q, k, v, ksz, heads, path="mfma")
+    assert_close(out, v[:, :, :1, :1].expand_as(out), 2e-3, 4e-3, "constant values")
+
+
+MFMA_CASES = [
+    # (B, h, w, dy, dx, ksz, C, heads)
+    (1, 8, 12, 4, 4, 7, 128, 4),          # F3-like geometry, every border cell
+    (2, 7, 7, 4, 4, 7, 64, 4),            # h == w == k: window is the whole grid
+    (1, 9, 10, 16, 16, 7, 768, 4),        # G1's cell shape and channel count (Dv = 192)
+    (1, 8, 8, 16, 16, 7, 1024, 4),        # G3 channel count (Dv = 256)
+    (1, 10, 9, 16, 16, 7, 384, 4),        # P1 channel count (Dv = 96)
+    (1, 6, 5, 3, 5, 3, 128, 4),           # 15-query cells: ragged last tile, k = 3
+    (1, 6, 7, 2, 4, 5, 256, 4),           # 8-query cells
+    (1, 11, 12, 8, 8, 9, 256, 4),         # default kernel 9
+    (1, 12, 13, 4, 4, 11, 128, 4),        # kernel 11
+    (1, 16, 17, 4, 4, 15, 1024, 4),       # kernel 15 with Dv = 256 (Dv tiles of 128)
+    (1, 14, 13, 2, 8, 13, 192, 4),        # kernel 13
+    (3, 5, 6, 5, 7, 3, 512, 4),           # odd cell shape 5x7, batch 3
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES)
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_xna_mfma_matches_oracle(dev, case, out_dtype):
+    B, h, w, dy, dx, ksz, C, heads = case
+    seed = sum(case)
+    q = bf16r(O.hash_normal((B, 256, h * dy, w * dx), seed + 1))
+    k = bf16r(O.hash_normal((B, 256, h, w), seed + 2))
+    v = bf16r(O.hash_normal((B, C, h, w), seed + 3))
+    ref = O.xna_lowres(q, k, v, ksz, heads)
+    out = run_xna(dev, q, k, v, ksz, heads, out_dtype=out_dtype, path="mfma")
+    tol = 6e-3 if out_dtype == torch.float32 else 1.2e-2
+    assert_close(out, ref, tol, tol, f"mfma {case} {out_dtype}")
+
+
+def test_xna_mfma_peaked_softmax(dev):
+    """Large logits (|s| ~ 40): exercises the max-subtraction path; one key dominates."""
+    h, w, d, ksz, heads = 8, 8, 4, 7, 4
+    q = bf16r(O.hash_normal((1, 256, h * d, w * d), 9) * 4.0)
+    k = bf16r(O.hash_normal((1, 256, h, w), 10) * 4.0)
+    v = bf16r(O.hash_normal((1, 128, h, w), 11))
+    ref = O.xna_lowres(q, k, v, ksz, heads)
+    out = run_xna(dev, q, k, v, ksz, heads, path="mfma")
+    assert_close(out, ref, 1e-2, 1e-2, "peaked softmax")
+    assert torch.isfinite(out).all()
+
+
+GENERIC_CASES = [
+    # (B, Cq, heads, (Ho, Wo), (h, w), ksz, C)
+    (1, 128, 2, (23, 30), (5, 7), 3, 16),      # F4: non-multiple sizes
+    (1, 128, 2, (23, 30), (5, 7), 5, 16),
+    (2, 64, 1, (24, 20), (24, 20), 5, 3),      # denoising-like: ratio 1, C = 3, one head
+    (1, 96, 1, (16, 16), (16, 16), 15, 3),     # kernel 15 at ratio 1, Dq = 96
+    (1, 256, 4, (64, 64), (28, 28), 9, 40),    # notebook case 28 -> 64
+    (1, 256, 4, (8, 8), (4, 4), 3, 24),        # tiny cells (dy*dx = 4): AUTO picks the table kernel
+]
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES)
+def test_xna_generic_matches_oracle(dev, case):
+    B, Cq, heads, (Ho, Wo), (h, w), ksz, C = case
+    q = bf16r(O.hash_normal((B, Cq, Ho, Wo), 41))
+    k = bf16r(O.hash_normal((B, Cq, h, w), 42))
+    v = bf16r(O.hash_normal((B, C, h, w), 43))
+    ref, ref_lg = O.xna(q, k, v, ksz, heads, return_logits=True)
+    out, lg = run_xna(dev, q, k, v, ksz, heads, path="auto", return_logits=True)
+    assert_close(out, ref, 2e-5, 2e-5, f"generic out {case}")
+    assert_close(lg, ref_lg, 2e-5, 2e-5, f"generic logits {case}")
+
+
+def test_generic_and_mfma_agree(dev):
+    """Two independent kernels on an integer-ratio problem."""
+    h, w, d, ksz, heads, C = 10, 9, 8, 7, 4, 192
+    q = bf16r(O.hash_normal((1, 256, h * d, w * d), 51))
+    k = bf16r(O.hash_normal((1, 256, h, w), 52))
+    v = bf16r(O.hash_normal((1, C, h, w), 53))
+    a = run_xna(dev, q, k, v, ksz, heads, path="mfma")
+    b = run_xna(dev, q, k, v, ksz, heads, path="generic")
+    assert_close(a, b, 6e-3, 6e-3, "mfma vs generic")
+
+
+def test_xna_errors_mirror_reference(dev):
+    from naf_amd import ops
+    q = torch.zeros(1, 4, 20, 20, 64, dtype=torch.bfloat16, device=dev)
+    k = torch.zeros(1, 4, 5, 5, 64, dtype=torch.bfloat16, device=dev)
+    v = torch.zeros(1, 4, 5, 5, 16, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError, match="exceeds"):       # NATTEN: kernel*dilation > extent
+        ops.xna_forward(q, k, v, 7)
+    with pytest.raises(ValueError, match="odd"):
+        ops.xna_forward(q, k, v, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.xna_forward(q.cpu(), k.cpu(), v.cpu(), 3)
+
+
+# ---- golden vectors from the imported reference: attention-only and whole forward -----------------------
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_golden_F3_attention(dev, golden_dir):
+    g = _g(golden_dir, "F3_xna_d4_k7")
+    q = O.hash_normal(tuple(g["q_shape"]), int(g["q_seed"]))
+    k = O.hash_normal((1, 256, *g["lr"]), int(g["k_seed"]))
+    v = O.hash_normal((1, int(g["C"]), *g["lr"]), int(g["v_seed"]))
+    out, lg = run_xna(dev, q, k, v, 7, 4, path="auto", return_logits=True)       # table kernel (logits)
+    # inputs are rounded to bf16 inside: logits of O(3) with 64-term dots -> abs 4e-2
+    assert_close(lg, torch.from_numpy(g["logits"]), 5e-2, 1e-2, "F3 logits vs reference")
+    assert_close(out, torch.from_numpy(g["out"]), 4e-2, 2e-2, "F3 out vs reference")
+    # Dv = 6 is not MFMA-eligible; an MFMA-eligible variant of the same geometry is covered above
+
+
+def _load_model(dev, params, **kw):
+    from naf_amd import NAF
+    m = NAF(**kw).eval()
+    m.load_state_dict(params, strict=True)
+    return m.to(dev)
+
+
+def _forward_stats(got, ref):
+    err = (got - ref).abs()
+    return float(err.max()), float(err.mean())
+
+
+def test_golden_F5_full_forward_P1(dev, golden_dir):
+    """BASELINE configs[0] end to end against the reference's output (fp32 features -> fp32 output)."""
+    g = _g(golden_dir, "F5_full_P1")
+    p = O.make_params(seed=int(g["param_seed"]))
+    m = _load_model(dev, p, kernel_size=int(g["k"]))
+    img = O.hash_normal((1, 3, 224, 224), int(g["image_seed"]))
+    ft = O.hash_normal((1, 384, 14, 14), int(g["feat_seed"]))
+    out = m(img.to(dev), ft.to(dev), (224, 224))
+    assert out.shape == (1, 384, 224, 224) and out.dtype == torch.float32
+    out = out.float().cpu()
+    oy, ox = g["offset"]
+    st = int(g["stride"])
+    ref = torch.from_numpy(g["sample"])
+    got = out[:, :, oy::st, ox::st]
+    assert_close(got, ref, 6e-2, 3e-2, "F5 strided sample")
+    assert _forward_stats(got, ref)[1] <= 6e-3
+    assert_close(out[:, ::48, :2, :], torch.from_numpy(g["top_rows"]), 6e-2, 3e-2, "F5 top rows")
+    assert_close(out[:, ::48, :, -2:], torch.from_numpy(g["left_cols"]), 6e-2, 3e-2, "F5 right cols")
+    assert (out.mean(dim=(0, 2, 3)) - torch.from_numpy(g["ch_mean"])).abs().max() <= 5e-3
+    # bf16 features -> bf16 output, same values within one more rounding
+    out_b = m(img.to(dev), ft.to(dev).to(torch.bfloat16), [224, 224])
+    assert out_b.dtype == torch.bfloat16
+    assert_close(out_b.float().cpu()[:, :, oy::st, ox::st], ref, 8e-2, 4e-2, "F5 bf16 I/O")
+
+
+def test_golden_F6_denoise_like(dev, golden_dir):
+    g = _g(golden_dir, "F6_denoise_d1")
+    p = O.make_params(dim=int(g["dim"]), heads_rope=1, seed=int(g["param_seed"]))
+    m = _load_model(dev, p, dim=int(g["dim"]), heads_attn=1, heads_rope=1, kernel_size=int(g["k"]))
+    shp = tuple(g["shape"])
+    img, ft = O.hash_normal(shp, int(g["image_seed"])), O.hash_normal(shp, int(g["feat_seed"]))
+    out, lg = m(img.to(dev), ft.to(dev), torch.Size(shp[-2:]), return_weights=True)
+    assert lg.shape == tuple(g["logits"].shape)
+    assert_close(out.float().cpu(), torch.from_numpy(g["out"]), 6e-2, 3e-2, "F6 out")
+    assert_close(lg.cpu(), torch.from_numpy(g["logits"]), 1e-1, 3e-2, "F6 logits (pre-softmax, scaled)")
+
+
+def test_golden_F7_preshrink_and_pool(dev, golden_dir):
+    g = _g(golden_dir, "F7_preshrink_pool")
+    p = O.make_params(dim=int(g["dim"]), heads_rope=2, seed=int(g["param_seed"]))
+    m = _load_model(dev, p, dim=int(g["dim"]), heads_attn=2, heads_rope=2, kernel_size=int(g["k"]))
+    ft = O.hash_normal(tuple(g["feat_shape"]), int(g["feat_seed"]))
+    for tag in ("a", "b"):
+        img = O.hash_normal(tuple(g[f"image_shape_{tag}"]), int(g[f"image_seed_{tag}"]))
+        out = m(img.to(dev), ft.to(dev), tuple(int(s) for s in g[f"out_size_{tag}"]))
+        assert_close(out.float().cpu(), torch.from_numpy(g[f"out_{tag}"]), 6e-2, 3e-2, f"F7{tag}")
+
+
+def test_heads_rope_differs_from_heads_attn(dev):
+    p = O.make_params(dim=64, heads_rope=1, seed=8)
+    m = _load_model(dev, p, dim=64, heads_attn=4, heads_rope=1, kernel_size=3)
+    img = O.hash_normal((1, 3, 16, 16), 81)
+    ft = O.hash_normal((1, 8, 4, 4), 82)
+    ref = O.naf_forward(p, img, ft, (16, 16), kernel_size=3, heads_attn=4, heads_rope=1)
+    assert_close(m(img.to(dev), ft.to(dev), (16, 16)).float().cpu(), ref, 6e-2, 3e-2, "heads 1/4")
+
+
+# ---- BASELINE full sizes: size-independent properties + sampled rows vs the oracle ----------------------
+FULL = [
+    ("G1", 1, 768, 64, 1024, 7),
+    ("G2-k7", 1, 1024, 32, 512, 7),
+    ("G2-k11", 1, 1024, 32, 512, 11),
+    ("G2-k15", 1, 1024, 32, 512, 15),
+    ("G4", 1, 768, 128, 2048, 7),
+]
+
+
+@pytest.mark.parametrize("name,B,C,lr,out_sz,ksz", FULL)
+def test_full_size_properties(dev, name, B, C, lr, out_sz, ksz):
+    from naf_amd import ops
+    heads = 4
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    k = torch.randn(B, 256, lr, lr, generator=gen)
+    v1 = torch.randn(B, C, lr, lr, generator=gen)
+    v2 = torch.randn(B, C, lr, lr, generator=gen)
+    q5 = torch.randn(B, heads, out_sz, out_sz, 64, generator=torch.Generator(device=dev).manual_seed(5), device=dev,
+                     dtype=torch.float32).to(torch.bfloat16)
+    k5 = to5(k, heads).to(dev)
+
+    def run(v, dtype=torch.float32):
+        vp = ops.pack_values(v.to(dev))
+        v5 = vp.view(B, lr, lr, heads, C // heads).permute(0, 3, 1, 2, 4)
+        assert ops.xna_select(q5, k5, v5, ksz, out_dtype=dtype) == "mfma"
+        return ops.xna_forward(q5, k5, v5, ksz, out_dtype=dtype, path="mfma")
+
+    # (1) partition of unity: constant values pass through
+    ones = run(torch.full((B, C, lr, lr), 0.5))
+    assert float((ones - 0.5).abs().max()) <= 2e-3
+    del ones
+    # (2) linearity in V: f(v1) + f(v2) == f(v1 + v2) up to bf16 rounding of the packed values
+    o1, o2 = run(bf16r(v1)), run(bf16r(v2))
+    o12 = run(bf16r(bf16r(v1) + bf16r(v2)))
+    lin = (o1 + o2 - o12).abs()
+    assert float(lin.max()) <= 6e-2 and float(lin.mean()) <= 4e-3
+    # (3) convexity: outputs stay inside [min, max] of the values
+    assert float(o1.max()) <= float(bf16r(v1).max()) + 1e-3 and float(o1.min()) >= float(bf16r(v1).min()) - 1e-3
+    del o2, o12, lin
+    # (4) sampled rows against the oracle at full size (interior, top border, bottom border)
+    rows = sorted({0, 1, out_sz // 2 - 1, out_sz // 2, out_sz - 17, out_sz - 1})
+    iy = O.axis_index_table(out_sz, lr, ksz)[rows]
+    ix = O.axis_index_table(out_sz, lr, ksz)
+    q_rows = q5[:, :, rows].float().cpu().permute(0, 1, 4, 2, 3).reshape(B, 256, len(rows), out_sz)
+    ref = O.xna_tables(q_rows, bf16r(k), bf16r(v1), iy, ix, heads)
+    got = o1[:, :, rows].permute(0, 1, 4, 2, 3).reshape(B, C, len(rows), out_sz).float().cpu()
+    assert_close(got, ref, 6e-3, 6e-3, f"{name} sampled rows")
