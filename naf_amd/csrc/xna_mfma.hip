@@ -27,7 +27,7 @@ int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) 
     for (int i = 0; i < 4; ++i) {
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->o_stride[i] % 4) return 0;
     }
-    static const int cand[] = {256, 192, 128, 96, 64, 32};
+    static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
     for (int c : cand) {
         if (a->Dv % c == 0 && lds_for(ks, c) <= 160 * 1024) {
             if (dvt_out) *dvt_out = c;

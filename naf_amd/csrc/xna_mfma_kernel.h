@@ -17,7 +17,8 @@
 //     O^T[ch][px]  = V^T[ch][key] . P^T[key][px] A = V^T via ds_read_b64_tr_b16 (hardware transpose
 //                                                 of the row-major V window), B = P packed to bf16
 //   lane (px = l&15, g = l>>4) ends with 4 consecutive channels of its own pixel per 16-channel
-//   tile -> 8-byte (bf16) / 16-byte (f32) stores, 1/sum applied in registers.
+//   tile; bf16 tiles are paired and re-dealt with v_permlane16_swap so every lane stores 16 bytes
+//   (64 contiguous bytes per pixel per instruction); 1/sum is applied in registers.
 //   The MFMA contraction order over keys is a free permutation; the same (g, j) -> key slot map
 //   is used for P and V^T so no cross-lane movement of P is needed.
 #pragma once
@@ -62,7 +63,10 @@ __device__ __forceinline__ void xna_store4(bf16_t* dst, f32x4_t v) {
 }
 __device__ __forceinline__ void xna_store4(float* dst, f32x4_t v) { *reinterpret_cast<f32x4_t*>(dst) = v; }
 
-template <int KS, int DVT, typename OutT>
+// ABL: ablation bits for tools/xna_probe.hip only (the library instantiates ABL = 0):
+//   1 no output stores, 2 no PV MFMAs / V reads, 4 no Q loads, 8 no K/V staging loads, 16 no QK MFMAs,
+//   32 non-temporal output stores, 64 narrow (8 B / lane) bf16 stores
+template <int KS, int DVT, typename OutT, int ABL = 0>
 __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
     using G = XnaGeom<KS>;
     constexpr int KK = G::KK, KPAD = G::KPAD, MT = G::MT, KST = G::KST, KROW = G::KROW;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
             const int i = it * 256 + tid;
             const int key = i >> 3, c = i & 7;
             u32x4_t val = {0u, 0u, 0u, 0u};
-            if (key < KK) {
+            if (key < KK && !(ABL & 8)) {
                 const int wy = key / KS, wx = key - wy * KS;
                 val = *reinterpret_cast<const u32x4_t*>(kb + wy * p.ks[2] + wx * p.ks[3] + c * 8);
             }
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
             if ((VTOT % 256 == 0) || i < VTOT) {
                 const int key = i / VCH, c = i - key * VCH;
                 u32x4_t val = {0u, 0u, 0u, 0u};
-                if (key < KK) {
+                if (key < KK && !(ABL & 8)) {
                     const int wy = key / KS, wx = key - wy * KS;
                     val = *reinterpret_cast<const u32x4_t*>(vb + wy * p.vs[2] + wx * p.vs[3] + c * 8);
                 }
@@ -141,8 +145,12 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
         const int ps = min(wave * 16 + col, npix - 1);
         const int py = ps / p.dx, px = ps - py * p.dx;
         const bf16_t* qp = qb + py * p.qs[2] + px * p.qs[3] + grp * 8;
-        qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-        qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+        if (!(ABL & 4)) {
+            qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+            qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+        } else {
+            qf[0] = qf[1] = bf16x8_t{};
+        }
     }
 
     for (int t = wave; t < ntile; t += 4) {
@@ -152,8 +160,12 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
             const int ps = min((t + 4) * 16 + col, npix - 1);
             const int py = ps / p.dx, px = ps - py * p.dx;
             const bf16_t* qp = qb + py * p.qs[2] + px * p.qs[3] + grp * 8;
-            qn[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-            qn[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+            if (!(ABL & 4)) {
+                qn[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                qn[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+            } else {
+                qn[0] = qn[1] = bf16x8_t{};
+            }
         }
 
         // ---- S^T = K . Q^T ----
@@ -163,8 +175,12 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka + mt * 16 * KROW + ks * 32);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+                if (!(ABL & 16)) {
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka + mt * 16 * KROW + ks * 32);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+                } else {
+                    acc[ks] += (float)qf[ks][mt & 7];
+                }
             }
             s[mt] = acc;
         }
@@ -209,12 +225,15 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
         const bool pvalid = ps < npix;
         const int psc = min(ps, npix - 1);
         const int py = psc / p.dx, px = psc - py * p.dx;
-        OutT* op = ob + py * p.os[2] + px * p.os[3] + grp * 4;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        OutT* op = ob + py * p.os[2] + px * p.os[3];
+        auto pv_tile = [&](int ct) -> f32x4_t {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
+                if (ABL & 2) {
+                    acc[ks & 3] += (float)pf[ks][ct & 7];
+                    continue;
+                }
                 const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                     (NAF_LDS bf16x4_t*)(va + (ks * 32) * VROW + ct * 16));
                 const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -224,8 +243,46 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
                 a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[ks], acc, 0, 0, 0);
             }
-            acc *= inv;
-            if (pvalid) xna_store4(op + ct * 16, acc);
+            return acc * inv;
+        };
+        constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
+        constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
+        if constexpr (kWide) {
+            // bf16: lane (px, g) holds channels g*4..g*4+3 of a 16-channel tile (8 B).  Exchange halves
+            // between the lane pairs (g, g^1) of two adjacent tiles with v_permlane16_swap so that every
+            // lane owns 8 consecutive channels -> one 16-byte store, 64 contiguous bytes per pixel.
+            OutT* opw = op + (grp & 1) * 16 + (grp >> 1) * 8;
+#pragma unroll
+            for (int ct = 0; ct < CTP; ct += 2) {
+                const f32x4_t a = pv_tile(ct), bq = pv_tile(ct + 1);
+                bf16x4_t ab, bb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ab[i] = (bf16_t)a[i];
+                    bb[i] = (bf16_t)bq[i];
+                }
+                const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
+                if (ABL & 1) {
+                    asm volatile("" ::"v"(wv));
+                } else if (pvalid) {
+                    if (ABL & 32)
+                        __builtin_nontemporal_store(wv, reinterpret_cast<u32x4_t*>(opw + ct * 16));
+                    else
+                        *reinterpret_cast<u32x4_t*>(opw + ct * 16) = wv;
+                }
+            }
+        }
+#pragma unroll
+        for (int ct = CTP; ct < CT; ++ct) {
+            const f32x4_t acc = pv_tile(ct);
+            if (ABL & 1) {
+                asm volatile("" ::"v"(acc));
+            } else if (pvalid) {
+                xna_store4(op + grp * 4 + ct * 16, acc);
+            }
         }
         qf[0] = qn[0];
         qf[1] = qn[1];
@@ -266,6 +323,8 @@ static int xna_mfma_launch_ks(const XnaMfmaParams& p, int dvt, int out_dtype, hi
             break;                                                                       \
         }
     switch (dvt) {
+        NAF_CASE(16)
+        NAF_CASE(48)
         NAF_CASE(32)
         NAF_CASE(64)
         NAF_CASE(96)

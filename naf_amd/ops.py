@@ -216,7 +216,7 @@ def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logi
     ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else tuple(kernel_size)
     B, heads, Ho, Wo, Dq = q.shape
     Dv = v_lr.shape[-1]
-    out = torch.empty((1,), dtype=out_dtype, device=q.device)
+    out = torch.empty((1, 1, 1, heads, Dv), dtype=out_dtype, device=q.device).permute(0, 3, 1, 2, 4)
     fake = torch.empty((1,), dtype=torch.float32, device=q.device) if return_logits else None
     a = _fill_xna(q, k_lr, v_lr, out, fake, None, None, ky, kx, path, None)
     a.o_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)

@@ -1,0 +1,132 @@
+// Stand-alone ablation / timing probe for the MFMA cell kernel (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inaf_amd/csrc tools/xna_probe.hip -o tools/bin/xna_probe
+//   tools/bin/xna_probe [C=768] [lr=64] [d=16] [reps=20]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "xna_mfma_kernel.h"
+
+void naf_set_error(const char* fmt, ...) { (void)fmt; }
+int naf_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return 3; }
+    return 0;
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+#ifndef PROBE_KS
+#define PROBE_KS 7
+#endif
+#ifndef PROBE_DVT
+#define PROBE_DVT 192
+#endif
+
+// streaming ceilings with ideal coalescing: pure write, and the kernel's 1:3 read:write mix
+__global__ __launch_bounds__(256) void stream_write(u32x4_t* __restrict__ out, size_t n) {
+    const u32x4_t v = {1u, 2u, 3u, (uint32_t)blockIdx.x};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v;
+}
+__global__ __launch_bounds__(256) void stream_mix13(u32x4_t* __restrict__ out, const u32x4_t* __restrict__ in, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const u32x4_t v = in[i];
+        out[i] = v;
+        out[n + i] = v;
+        out[2 * n + i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void stream_copy(u32x4_t* __restrict__ out, const u32x4_t* __restrict__ in, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
+}
+
+template <int ABL>
+float run(const XnaMfmaParams& p, int reps, const char* name, double bytes) {
+    constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, PROBE_DVT>();
+    auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, 0, p);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    printf("%-44s %8.4f ms  %8.1f GB/s (algorithmic)\n", name, ms, bytes / ms / 1e6);
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    const int C = argc > 1 ? atoi(argv[1]) : 768, lr = argc > 2 ? atoi(argv[2]) : 64, d = argc > 3 ? atoi(argv[3]) : 16;
+    const int reps = argc > 4 ? atoi(argv[4]) : 20;
+    const int heads = 4, Dq = 64, Dv = C / heads, Ho = lr * d, Wo = lr * d, B = 1;
+    if (Dv % PROBE_DVT) { printf("Dv %d not a multiple of DVT %d\n", Dv, PROBE_DVT); return 1; }
+    const size_t nq = (size_t)B * heads * Ho * Wo * Dq, nk = (size_t)B * lr * lr * heads * Dq, nv = (size_t)B * lr * lr * C;
+    const size_t no = (size_t)B * Ho * Wo * C;
+    std::vector<uint16_t> hq(nq), hk(nk), hv(nv);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; float f = ((st >> 8) & 0xffff) / 65536.0f * 2.f - 1.f; union { float f; uint32_t u; } cv; cv.f = f; return (uint16_t)(cv.u >> 16); };
+    for (auto& x : hq) x = rnd();
+    for (auto& x : hk) x = rnd();
+    for (auto& x : hv) x = rnd();
+    bf16_t *q, *k, *v, *o;
+    CK(hipMalloc(&q, nq * 2)); CK(hipMalloc(&k, nk * 2)); CK(hipMalloc(&v, nv * 2)); CK(hipMalloc(&o, no * 2));
+    CK(hipMemcpy(q, hq.data(), nq * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(k, hk.data(), nk * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(v, hv.data(), nv * 2, hipMemcpyHostToDevice));
+    XnaMfmaParams p;
+    p.q = q; p.k = k; p.v = v; p.out = o;
+    p.B = B; p.heads = heads; p.Ho = Ho; p.Wo = Wo; p.h = lr; p.w = lr; p.dy = d; p.dx = d; p.nchunk = Dv / PROBE_DVT;
+    p.nblocks = (uint32_t)(B * lr * lr * heads * p.nchunk);
+    p.scale_log2e = 0.125f * 1.4426950408889634f;
+    // q head-major [B, heads, Ho, Wo, 64]; k [B, h, w, heads*64]; v [B, h, w, C]; out [B, Ho, Wo, C]
+    p.qs[0] = (int64_t)heads * Ho * Wo * Dq; p.qs[1] = (int64_t)Ho * Wo * Dq; p.qs[2] = (int64_t)Wo * Dq; p.qs[3] = Dq;
+    p.ks[0] = (int64_t)lr * lr * heads * Dq; p.ks[1] = Dq; p.ks[2] = (int64_t)lr * heads * Dq; p.ks[3] = heads * Dq;
+    p.vs[0] = (int64_t)lr * lr * C; p.vs[1] = Dv; p.vs[2] = (int64_t)lr * C; p.vs[3] = C;
+    p.os[0] = (int64_t)Ho * Wo * C; p.os[1] = Dv; p.os[2] = (int64_t)Wo * C; p.os[3] = C;
+    const double bytes = 2.0 * B * (256.0 * Ho * Wo + (256.0 + C) * lr * lr + (double)C * Ho * Wo);
+    printf("workload: C=%d lr=%d d=%d -> %dx%d, k=%d, DVT=%d, %u workgroups, algorithmic %.3f GB\n", C, lr, d, Ho, Wo, PROBE_KS,
+           PROBE_DVT, p.nblocks, bytes / 1e9);
+    {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        const size_t nout = no * 2 / 16, nin = nq * 2 / 16;
+        for (int grid : {2048, 8192}) {
+            float ms;
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(stream_write, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, nout);
+            CK(hipEventRecord(a));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(stream_write, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, nout);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+            printf("stream_write  grid %5d: %.4f ms  %.1f GB/s\n", grid, ms, no * 2.0 / ms / 1e6);
+            const size_t n3 = nout / 3 < nin ? nout / 3 : nin;
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(stream_mix13, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, (const u32x4_t*)q, n3);
+            CK(hipEventRecord(a));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(stream_mix13, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, (const u32x4_t*)q, n3);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+            printf("stream_mix13  grid %5d: %.4f ms  %.1f GB/s (1 read : 3 write)\n", grid, ms, n3 * 64.0 / ms / 1e6);
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(stream_copy, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, (const u32x4_t*)q, nin);
+            CK(hipEventRecord(a));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(stream_copy, dim3(grid), dim3(256), 0, 0, (u32x4_t*)o, (const u32x4_t*)q, nin);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+            printf("stream_copy   grid %5d: %.4f ms  %.1f GB/s (1 read : 1 write)\n", grid, ms, nin * 32.0 / ms / 1e6);
+        }
+    }
+    run<0>(p, reps, "full kernel", bytes);
+    run<1>(p, reps, "no output stores", bytes);
+    run<2>(p, reps, "no PV mfma / V reads", bytes);
+    run<4>(p, reps, "no Q loads", bytes);
+    run<8>(p, reps, "no K/V staging loads", bytes);
+    run<16>(p, reps, "no QK mfma", bytes);
+    run<2 | 16>(p, reps, "no mfma at all (loads+softmax+stores)", bytes);
+    run<1 | 2 | 16>(p, reps, "no mfma, no stores", bytes);
+    run<1 | 4>(p, reps, "no Q loads, no stores (compute only)", bytes);
+    run<1 | 4 | 8>(p, reps, "compute only, no staging", bytes);
+    run<64>(p, reps, "narrow 8 B stores (old)", bytes);
+    run<32>(p, reps, "non-temporal stores", bytes);
+    run<0>(p, reps, "full kernel (again)", bytes);
+    return 0;
+}
