@@ -209,7 +209,8 @@ def main():
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
             "roofline": roof,
             "phases_ms": {k: (round(timer.mean_ms(k), 4) if timer.mean_ms(k) else None)
-                          for k in ("stem", "rope_pool", "attention", "xna_mfma")},
+                          for k in ("stem", "stem_conv0", "stem_conv1", "stem_conv3", "rope_pool", "attention", "xna_mfma")},
+            "launches_per_step": {k: timer.count(k) // max(1, args.steps) for k in ("stem_conv0", "stem_conv1", "stem_conv3")},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(C, ksz)

@@ -60,6 +60,54 @@ const char* naf_last_error(void);
  * out_host[L_out * k] (HOST memory).  Errors like NATTEN: k even, k*dilation > L_out, L_out < L_in. */
 int naf_axis_index_table(int32_t* out_host, int32_t L_out, int32_t L_in, int32_t k);
 
+/* ---- guidance conv stem ----------------------------------------------------------------------------
+ * Replaces the reference's encoder() branches (convolutions.py:6-92, built at naf.py:26-27 with
+ * hidden = dim/2 = 128 channels, GroupNorm(8), SiLU, reflect padding, no residual) for the default
+ * width.  Activations are channels-last bf16 [B, H, W, 128]; GroupNorm statistics travel as fp64
+ * {sum, sum of squares} per (batch, group) in `stats` buffers [B][8][2] that the CALLER zeroes
+ * before the producing launch (hipMemsetAsync on the same stream).
+ *
+ * naf_stem_conv0_fwd : Conv2d(3 -> 128, ksize 1 or 3, reflect) + bias         (convolutions.py:68-75)
+ *   image device [B, 3, H, W] f32/bf16, element strides {b, c, y, x}; weight device f32 [128][3][k][k]
+ *   (the module's own parameter), bias f32 [128]; y device bf16, strides {b, y, x}, 128 ch contiguous;
+ *   stats_out accumulates sum / sum^2 of y per GroupNorm group.
+ * naf_stem_conv_fwd  : GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, ksize 1 or 3, reflect) + bias
+ *   (one norm/act/conv triple of EncBlock.forward, convolutions.py:52-61).  x device bf16 with its
+ *   stats_in; gn_weight/gn_bias f32 [128]; w_packed device bf16 [k*k][128 oc][128 ic]
+ *   (= weight.permute(2,3,0,1)); y / stats_out as above (stats_out may be NULL). */
+typedef struct naf_stem_conv0_args {
+    const void* image;
+    void* y;
+    const float* weight;
+    const float* bias;
+    double* stats_out;
+    int32_t image_dtype; /* naf_dtype */
+    int32_t ksize;       /* 1 or 3 */
+    int32_t B, H, W;
+    int32_t reserved;
+    int64_t image_stride[4];
+    int64_t y_stride[3];
+} naf_stem_conv0_args;
+int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream);
+
+typedef struct naf_stem_conv_args {
+    const void* x;
+    void* y;
+    const void* w_packed;
+    const float* bias;
+    const float* gn_weight;
+    const float* gn_bias;
+    const double* stats_in;
+    double* stats_out;
+    int32_t ksize; /* 1 or 3 */
+    int32_t B, H, W;
+    float eps;
+    int32_t reserved;
+    int64_t x_stride[3];
+    int64_t y_stride[3];
+} naf_stem_conv_args;
+int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream);
+
 /* ---- RoPE tables --------------------------------------------------------------------------------
  * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),
  * eval mode.  tab_y device float [Ho][2][n_periods] (cos then sin), tab_x device float [Wo][2][..].

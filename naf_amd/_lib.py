@@ -40,11 +40,33 @@ class XnaArgs(C.Structure):
     ]
 
 
+I64x3 = C.c_int64 * 3
+
+
+class StemConv0Args(C.Structure):
+    _fields_ = [
+        ("image", C.c_void_p), ("y", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_out", C.c_void_p),
+        ("image_dtype", C.c_int32), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("reserved", C.c_int32), ("image_stride", I64x4), ("y_stride", I64x3),
+    ]
+
+
+class StemConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("gn_weight", C.c_void_p),
+        ("gn_bias", C.c_void_p), ("stats_in", C.c_void_p), ("stats_out", C.c_void_p),
+        ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("eps", C.c_float),
+        ("reserved", C.c_int32), ("x_stride", I64x3), ("y_stride", I64x3),
+    ]
+
+
 # symbol -> (restype, argtypes); must list every function include/naf_hip.h declares
 SIGNATURES = {
     "naf_version": (C.c_int, []),
     "naf_last_error": (C.c_char_p, []),
     "naf_axis_index_table": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
+    "naf_stem_conv0_fwd": (C.c_int, [C.POINTER(StemConv0Args), C.c_void_p]),
+    "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_rope_pool_fwd": (C.c_int, [C.POINTER(RopePoolArgs), C.c_void_p]),
     "naf_pack_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

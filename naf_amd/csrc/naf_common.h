@@ -37,6 +37,9 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);           
 int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, int h, int w,
                            const int64_t* vs, hipStream_t s);                    // pack.hip
 
+int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);            // stem_conv0.hip
+int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s);              // stem_conv.hip
+
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 

@@ -82,9 +82,10 @@ class RoPE(nn.Module):
 
 
 class ImageEncoder(nn.Module):
-    """Guidance encoder (naf.py:11-52).  The two conv branches currently run through
-    torch/MIOpen in ``stem_dtype`` (bf16, channels-last); RoPE is applied by the caller's fused
-    rope+pool kernel, not here."""
+    """Guidance encoder (naf.py:11-52).  At the default width (dim 256 -> 128 hidden channels) both
+    conv branches run through the library's fused HIP stem (naf_stem_conv0_fwd / naf_stem_conv_fwd:
+    GroupNorm+SiLU+conv in one weight-stationary MFMA pass per layer).  Other widths use torch/MIOpen ops in
+    ``stem_dtype`` (bf16, channels-last).  RoPE is applied by the caller's fused rope+pool kernel."""
 
     def __init__(self, in_channels=3, out_channels=256, heads_rope=1, use_encoder=True, rope_base=None,
                  rope_rescale=None, img_layers=2):
@@ -95,6 +96,7 @@ class ImageEncoder(nn.Module):
         self.sem_encoder = make_branch(in_channels, out_channels // 2, 3, 3, img_layers)
         self.rope = RoPE(out_channels, num_heads=heads_rope, base=rope_base, rescale_coords=rope_rescale)
         self.stem_dtype = torch.bfloat16
+        self.stem_impl = "hip"      # "hip": fused HIP stem (hidden width 128); "torch": MIOpen ops (any width)
 
     @staticmethod
     def _conv(x, conv: nn.Conv2d, dt):
@@ -112,6 +114,50 @@ class ImageEncoder(nn.Module):
             x = self._conv(x, blk.conv2, dt)
         return x
 
+    # ---- fused HIP stem (default width: 128 hidden channels, GroupNorm(8)) -------------------------
+    def _hip_stem_ok(self) -> bool:
+        c0 = self.encoder[0]
+        return (self.use_encoder and c0.out_channels == 128 and c0.in_channels == 3
+                and all(b.norm1.num_groups == 8 for b in list(self.encoder)[1:]))
+
+    def _packed(self, conv: nn.Conv2d) -> torch.Tensor:
+        """bf16 [k*k, oc, ic] copy of a conv weight, cached until the parameter changes."""
+        cache = self.__dict__.setdefault("_wcache", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            k = w.shape[-1]
+            hit = (key, w.detach().permute(2, 3, 0, 1).reshape(k * k, w.shape[0], w.shape[1]).contiguous().to(torch.bfloat16))
+            cache[id(conv)] = hit
+        return hit[1]
+
+    def _stem_hip(self, image: torch.Tensor) -> torch.Tensor:
+        """Both conv branches through naf_stem_conv0_fwd / naf_stem_conv_fwd; returns the concatenated
+        guidance as a logical [B, 256, H, W] view of a channels-last bf16 buffer (naf.py:31-33)."""
+        B, _, H, W = image.shape
+        dev = image.device
+        branches = (self.encoder, self.sem_encoder)
+        nstage = 1 + 2 * (len(self.encoder) - 1)
+        stats = torch.zeros((2, nstage, B, 8, 2), dtype=torch.float64, device=dev)      # one memset for all sums
+        cat = torch.empty((B, H, W, 256), dtype=torch.bfloat16, device=dev)
+        bufs = [torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+        for br, seq in enumerate(branches):
+            conv0 = seq[0]
+            last = nstage == 1
+            dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[0]
+            ops.stem_conv0(image, conv0.weight.detach().float().contiguous(), conv0.bias.detach().float(), dst, stats[br, 0])
+            cur, st = dst, 0
+            for blk in list(seq)[1:]:
+                for norm, conv in ((blk.norm1, blk.conv1), (blk.norm2, blk.conv2)):
+                    st += 1
+                    last = st == nstage - 1
+                    dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[st % 2]
+                    ops.stem_conv(cur, stats[br, st - 1], norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
+                                  self._packed(conv), conv.bias.detach().float(), dst, None if last else stats[br, st])
+                    cur = dst
+        return cat.permute(0, 3, 1, 2)
+
     def guidance(self, image: torch.Tensor, output_size: Tuple[int, int]) -> torch.Tensor:
         """Pre-RoPE guidance features, logical [B, dim, Ho, Wo] (naf.py:37-49 + :31-35)."""
         ho, wo = output_size
@@ -119,7 +165,9 @@ class ImageEncoder(nn.Module):
         if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
             x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
                               mode="bilinear", align_corners=False)
-        if self.use_encoder:
+        if self.use_encoder and self.stem_impl == "hip" and self._hip_stem_ok():
+            x = self._stem_hip(x)
+        elif self.use_encoder:
             dt = self.stem_dtype
             x = x.to(dt).contiguous(memory_format=torch.channels_last)
             x = torch.cat([self._branch(x, self.encoder, dt), self._branch(x, self.sem_encoder, dt)], dim=1)

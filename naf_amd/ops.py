@@ -4,6 +4,7 @@ every kernel is the library's.  There is no CPU / eager fallback: CPU tensors ra
 
 Reference counterparts (paths relative to the reference repo):
   axis_index_table   NATTEN neighbourhood rule + nearest-exact map      src/layers/attentions.py:48-61
+  stem_conv0/stem_conv  encoder() conv + GroupNorm + SiLU chain         src/layers/convolutions.py:6-92
   rope_tables        RoPE.create_coordinate / angle, sin, cos           src/layers/rope.py:84-105,137-146
   rope_pool          RoPE.forward rotation + KeyEncoder pooling         src/layers/rope.py:147-174, src/model/naf.py:63-69
   pack_values        CrossAttention._resize layout/dtype part           src/layers/attentions.py:50-51
@@ -17,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import XnaArgs, RopePoolArgs, I64x4
+from ._lib import XnaArgs, RopePoolArgs, StemConv0Args, StemConvArgs, I64x3, I64x4
 
 _DT = {torch.bfloat16: _lib.NAF_BF16, torch.float32: _lib.NAF_F32}
 
@@ -79,6 +80,51 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
         t = axis_index_table(L_out, L_in, k).to(device)
         _table_cache[key] = t
     return t
+
+
+# ------------------------------------------------------------------------------------------------
+def stem_conv0(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, y: torch.Tensor,
+               stats_out: torch.Tensor) -> None:
+    """Conv2d(3 -> 128, k in {1, 3}, reflect) + bias.  image [B,3,H,W] f32/bf16 (any strides); weight f32
+    [128,3,k,k]; y: bf16 [B,H,W,128] view (128 channels contiguous); stats_out f64 [B,8,2], pre-zeroed."""
+    _gpu(image, "image")
+    lib = _lib.load()
+    if image.dtype not in _DT:
+        image = image.float()
+    B, Cin, H, W = image.shape
+    if Cin != 3 or tuple(weight.shape[:2]) != (128, 3) or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise ValueError(f"stem_conv0: expected a 3-channel image and an f32 [128,3,k,k] weight, got {tuple(image.shape)} / {tuple(weight.shape)}")
+    a = StemConv0Args()
+    a.image, a.y, a.weight, a.bias, a.stats_out = image.data_ptr(), y.data_ptr(), weight.data_ptr(), bias.data_ptr(), stats_out.data_ptr()
+    a.image_dtype, a.ksize, a.B, a.H, a.W = _DT[image.dtype], int(weight.shape[-1]), B, H, W
+    a.image_stride = _strides4(image, (0, 1, 2, 3))
+    a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
+    with torch.cuda.device(image.device), _Timed("stem_conv0"):
+        rc = lib.naf_stem_conv0_fwd(C.byref(a), _stream(image))
+    _lib.check(rc, "naf_stem_conv0_fwd")
+
+
+def stem_conv(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor, eps: float,
+              w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor]) -> None:
+    """GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, k in {1,3}, reflect) + bias on bf16 [B,H,W,128] views.
+    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats f64 [B,8,2] (stats_out pre-zeroed or None)."""
+    _gpu(x, "x")
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    if Cc != 128 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
+        raise ValueError("stem_conv: activations must be bf16 [B,H,W,128] with channels contiguous")
+    taps = w_packed.shape[0]
+    a = StemConvArgs()
+    a.x, a.y, a.w_packed, a.bias = x.data_ptr(), y.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
+    a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    a.stats_out = stats_out.data_ptr() if stats_out is not None else None
+    a.ksize = {1: 1, 9: 3}[int(taps)]
+    a.B, a.H, a.W, a.eps = B, H, W, float(eps)
+    a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
+    a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
+    with torch.cuda.device(x.device), _Timed("stem_conv%d" % a.ksize):
+        rc = lib.naf_stem_conv_fwd(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_stem_conv_fwd")
 
 
 # ------------------------------------------------------------------------------------------------

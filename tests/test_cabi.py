@@ -24,6 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol(built_lib):
     lib = C.CDLL(built_lib)
     declared = _declared_symbols()
     assert {"naf_version", "naf_last_error", "naf_axis_index_table", "naf_rope_tables", "naf_rope_pool_fwd",
+            "naf_stem_conv0_fwd", "naf_stem_conv_fwd",
             "naf_pack_values", "naf_xna_select", "naf_workspace_bytes", "naf_xna_fwd"} <= set(declared)
     for name in declared:
         assert hasattr(lib, name), f"libnaf_hip.so does not export {name}"
@@ -37,12 +38,14 @@ def test_struct_layout_matches_header(built_lib):
     """sizeof of the ctypes mirrors == the C structs (checked through a tiny C probe compiled with gcc)."""
     import subprocess, tempfile
     from naf_amd import _lib
-    src = '#include "naf_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", sizeof(naf_rope_pool_args), sizeof(naf_xna_args));return 0;}\n'
+    src = ('#include "naf_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(naf_rope_pool_args), '
+           'sizeof(naf_xna_args), sizeof(naf_stem_conv0_args), sizeof(naf_stem_conv_args));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
-        a, b = map(int, subprocess.check_output([os.path.join(d, "p")]).split())
+        a, b, c, e = map(int, subprocess.check_output([os.path.join(d, "p")]).split())
     assert a == C.sizeof(_lib.RopePoolArgs) and b == C.sizeof(_lib.XnaArgs)
+    assert c == C.sizeof(_lib.StemConv0Args) and e == C.sizeof(_lib.StemConvArgs)
 
 
 @pytest.mark.parametrize("L_in", [1, 2, 3, 5, 7, 14, 28, 32, 64])

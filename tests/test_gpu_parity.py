@@ -54,6 +54,13 @@ def run_xna(dev, q, k, v, ksz, heads, out_dtype=torch.float32, path="auto", retu
     return (out, lg.cpu()) if return_logits else out
 
 
+def _load_model(dev, params, **kw):
+    from naf_amd import NAF
+    m = NAF(**kw).eval()
+    m.load_state_dict(params, strict=True)
+    return m.to(dev)
+
+
 def assert_close(got, ref, atol, rtol, what=""):
     err = (got - ref).abs()
     bound = atol + rtol * ref.abs()
@@ -112,6 +119,75 @@ def test_pack_values(dev):
         vp = ops.pack_values(src)
         assert vp.shape == (2, 7, 9, 50) and vp.dtype == torch.bfloat16
         assert torch.equal(vp.cpu(), src.permute(0, 2, 3, 1).to(torch.bfloat16).cpu())
+
+
+# ---- fused conv stem ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("ks", [1, 3])
+@pytest.mark.parametrize("shape", [(1, 20, 24), (2, 37, 70), (1, 64, 32)])
+def test_stem_conv0(dev, ks, shape):
+    """Conv2d(3 -> 128, reflect) + GroupNorm sums against torch fp32 (output rounded to bf16 once)."""
+    import torch.nn.functional as F
+    from naf_amd import ops
+    B, H, W = shape
+    img = O.hash_normal((B, 3, H, W), 61)
+    w = O.hash_normal((128, 3, ks, ks), 62, 0.3)
+    bias = O.hash_normal((128,), 63, 0.1)
+    ref = F.conv2d(F.pad(img, (ks // 2,) * 4, mode="reflect") if ks == 3 else img, w, bias)
+    y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+    st = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+    ops.stem_conv0(img.to(dev), w.to(dev), bias.to(dev), y, st)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert_close(got, ref, 1e-5, 2 ** -8, f"conv0 k={ks}")
+    g = ref.double().view(B, 8, 16, H, W)
+    assert torch.allclose(st[..., 0].cpu(), g.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[..., 1].cpu(), (g * g).sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("ks", [1, 3])
+@pytest.mark.parametrize("shape", [(1, 20, 24), (2, 37, 70), (1, 130, 96)])
+def test_stem_conv_layer(dev, ks, shape):
+    """One GroupNorm -> SiLU -> Conv layer against torch fp32 on the same bf16 input."""
+    import torch.nn.functional as F
+    from naf_amd import ops
+    B, H, W = shape
+    x = bf16r(O.hash_normal((B, 128, H, W), 71) * 1.5 + 0.3)
+    w = bf16r(O.hash_normal((128, 128, ks, ks), 72, 1.0 / (11.3 * ks)))
+    bias = O.hash_normal((128,), 73, 0.1)
+    gw, gb = 1.0 + O.hash_normal((128,), 74, 0.1), O.hash_normal((128,), 75, 0.1)
+    a = F.silu(F.group_norm(x, 8, gw, gb, 1e-5))
+    a = bf16r(a)                                               # the kernel feeds the MFMA with bf16 activations
+    ref = F.conv2d(F.pad(a, (ks // 2,) * 4, mode="reflect") if ks == 3 else a, w, bias)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    g = x.double().view(B, 8, 16, H, W)
+    st_in = torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev)
+    st_out = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+    y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+    wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
+    ops.stem_conv(xd, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert_close(got, ref, 2e-2, 1e-2, f"stem conv k={ks} {shape}")     # bf16 rounding of SiLU(GN(x)) at |x| ~ boundary
+    assert float((got - ref).abs().mean()) <= 2e-3
+    gr = ref.double().view(B, 8, 16, H, W)
+    assert torch.allclose(st_out[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+    assert torch.allclose(st_out[..., 1].cpu(), (gr * gr).sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 24), (2, 45, 67), (1, 160, 64)])
+def test_stem_whole_matches_oracle(dev, shape):
+    """Both branches, all 5 layers each, against the fp32 oracle conv stem (convolutions.py:67-92)."""
+    B, H, W = shape
+    p = O.make_params(seed=9)
+    m = _load_model(dev, p)
+    img = O.hash_normal((B, 3, H, W), 91)
+    ref = O.conv_stem(img, p)
+    assert m.image_encoder._hip_stem_ok()
+    got = m.image_encoder._stem_hip(img.to(dev)).float().cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    assert float(err.mean()) <= 8e-3 and float(err.max()) <= 1.5e-1, (float(err.mean()), float(err.max()))
+    m.image_encoder.stem_impl = "torch"
+    alt = m.image_encoder.guidance(img.to(dev), (H, W)).float().cpu()     # MIOpen bf16 path: same ballpark
+    assert float((alt - ref).abs().mean()) <= 2e-2
 
 
 # ---- attention: staged checks that localise a layout error -------------------------------------------
@@ -241,13 +317,6 @@ def test_golden_F3_attention(dev, golden_dir):
     assert_close(lg, torch.from_numpy(g["logits"]), 5e-2, 1e-2, "F3 logits vs reference")
     assert_close(out, torch.from_numpy(g["out"]), 4e-2, 2e-2, "F3 out vs reference")
     # Dv = 6 is not MFMA-eligible; an MFMA-eligible variant of the same geometry is covered above
-
-
-def _load_model(dev, params, **kw):
-    from naf_amd import NAF
-    m = NAF(**kw).eval()
-    m.load_state_dict(params, strict=True)
-    return m.to(dev)
 
 
 def _forward_stats(got, ref):
