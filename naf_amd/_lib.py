@@ -12,7 +12,8 @@ import threading
 
 import torch  # noqa: F401  (must be imported before the HIP library is dlopen'ed)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
+# NAF_HIP_LIB lets an experiment point at an alternative build of the SAME library (A/B kernel variants)
+LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
 NAF_BF16, NAF_F32 = 0, 1
 XNA_AUTO, XNA_MFMA, XNA_GENERIC = 0, 1, 2

@@ -1,0 +1,354 @@
+// Kernel of naf_stem_conv_fwd (see stem_conv.hip for the design notes); a header so that
+// tools/stem_probe.hip can instantiate ablation variants.
+#pragma once
+#include <type_traits>
+
+#ifndef NAF_STEM_SLOT_PINS
+#define NAF_STEM_SLOT_PINS 1
+#endif
+
+#include "naf_common.h"
+
+struct StemConvParams {
+    const bf16_t* x;       // [B, H, W, 128] channels contiguous, strides below
+    bf16_t* y;             // [B, H, W, >=128] (may be a 128-channel slice of a wider tensor)
+    const bf16_t* w;       // packed [KS*KS][128 oc][128 ic]
+    const float* bias;     // [128]
+    const float* gamma;    // [128] GroupNorm weight applied to x
+    const float* beta;     // [128]
+    const double* stats_in;  // [B][8][2] sum, sum^2 of x over (H, W, 16 ch)
+    double* stats_out;       // [B][8][2] of y, or nullptr
+    int32_t B, H, W, tiles_x, segs_y, seg_h;
+    float eps;
+    int64_t xs[3], ys[3];  // element strides {b, y, x}
+};
+
+namespace {
+constexpr int C = 128;        // channels in == out
+constexpr int RS = 2;         // output rows per step
+constexpr int TW = 32;        // strip width (pixels)
+constexpr int PXE = C + 8;    // LDS elements per pixel (272 B)
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+}  // namespace
+
+template <int KS>
+struct StemGeom {
+    static constexpr int HALO = KS / 2;
+    static constexpr int PXS = TW + 2 * HALO;                 // pixels a step's MFMAs read per ring row
+    static constexpr int PXR = ((RS * PXS + 15) / 16) * 16 / RS;  // pixels stored per ring row (padded so that
+                                                              // RS rows are a whole number of 16-pixel load waves)
+    static constexpr int NROW = RS + 2 * HALO;                // input rows a step reads
+    static constexpr int RING = NROW + RS;                    // ring slots
+    static constexpr int ROWE = PXR * PXE;                    // elements per ring row
+    static constexpr int NLD = RS * PXR / 16;                 // 16-byte loads per thread per batch of RS rows
+    static constexpr int NST = RS * TW / 16;                  // 16-byte stores per thread per output tile
+    static constexpr int TAPS = KS * KS;
+    static constexpr int KH = 4;                              // k-steps per B-fragment set
+    static constexpr int NSETS = NROW * KS * (8 / KH);        // sets per step: (input row, tap column, k half)
+    static constexpr int PRE = (NROW + RS - 1) / RS;          // load batches step 0 needs
+};
+
+// ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue
+// (bias, sums, LDS tile), 4 no LDS B-fragment reads (MFMA on stale registers), 8 no row stores, 16 no global loads,
+// 32 no per-step barrier, 64 no per-slot scheduling pins
+template <int KS, int ABL = 0>
+__global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const StemConvParams p) {
+    using G = StemGeom<KS>;
+    constexpr int HALO = G::HALO, PXR = G::PXR, NROW = G::NROW, RING = G::RING, ROWE = G::ROWE;
+    constexpr int NLD = G::NLD, NST = G::NST, TAPS = G::TAPS, KH = G::KH, NSETS = G::NSETS, PRE = G::PRE;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);                     // [RING][PXR][PXE]
+    bf16_t* otile = ring + RING * ROWE;                                 // [2][RS*TW][PXE]
+    float* cvec = reinterpret_cast<float*>(otile + 2 * RS * TW * PXE);  // [3][128]: bias, GN scale, GN shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n32 = lane & 31, half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int seg = bid % p.segs_y;
+    const int b = bid / p.segs_y;
+    const int sx = tx * TW;
+    const int sy = seg * p.seg_h;
+    const int sy_end = min(p.H, sy + p.seg_h);
+    const int nstep = (sy_end - sy + RS - 1) / RS;
+
+    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
+    bf16x8_t wreg[TAPS * 8];
+    {
+        const bf16_t* wp = p.w + (size_t)(wave * 32 + n32) * C + half * 8;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
+    }
+    // per-channel vectors in LDS (kept out of the register file, which the weights fill):
+    //   cvec[0][c] conv bias, cvec[1][c] / cvec[2][c] GroupNorm scale / shift of the INPUT channel c
+    const int chunk = tid & 15, pl = tid >> 4;
+    if (tid < C) {
+        const int g = tid >> 4;  // 16 channels per group
+        const double n = (double)p.H * (double)p.W * 16.0;
+        const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float gmm = p.gamma[tid];
+        cvec[tid] = p.bias[tid];
+        cvec[C + tid] = gmm * rstd;
+        cvec[2 * C + tid] = p.beta[tid] - (float)mean * gmm * rstd;
+    }
+    __syncthreads();
+
+    // GroupNorm scale / shift of this thread's 8 input channels (3x3 schedule keeps them in registers)
+    float ga[8], gb[8], ga2[8], gb2[8];  // y = x*ga + gb ; -log2(e)*y = x*ga2 + gb2
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ga[e] = cvec[C + chunk * 8 + e];
+        gb[e] = cvec[2 * C + chunk * 8 + e];
+        ga2[e] = ga[e] * -1.4426950408889634f;
+        gb2[e] = gb[e] * -1.4426950408889634f;
+    }
+    const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
+    bf16_t* yb = p.y + (int64_t)b * p.ys[0] + chunk * 8;
+
+    // Loads.  Piece n of a batch is ring pixel (rr, px) = divmod(pl + 16 n, PXR); its image column is
+    // fixed for the whole kernel (reflect padding = coordinate map), only the row advances.  Pieces past
+    // the pixels the MFMAs read are padding: they load a clamped pixel and are never consumed, which
+    // keeps every piece unconditional (no per-lane branch in the step body).
+    int64_t col_off[NLD];
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int px = (pl + 16 * n) % PXR;
+        col_off[n] = (int64_t)reflect(sx - HALO + px, p.W) * p.xs[2];
+    }
+    // per-piece constants of the 3x3 schedule: ring row (0/1) and in-row LDS offset of load piece n;
+    // LDS offset and global offset (relative to the tile's first row) of store piece n
+    int c_rr[NLD], c_pxoff[NLD], st_lds[NST];
+    int64_t st_goff[NST];
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int i = pl + 16 * n;
+        c_rr[n] = i / PXR;
+        c_pxoff[n] = (i - c_rr[n] * PXR) * PXE + chunk * 8;
+    }
+#pragma unroll
+    for (int n = 0; n < NST; ++n) {
+        const int opx = pl + 16 * n;
+        const int g = opx / TW, px = opx - g * TW;
+        st_lds[n] = opx * PXE + chunk * 8;
+        st_goff[n] = (int64_t)g * p.ys[1] + (int64_t)(sx + px) * p.ys[2];
+    }
+    u32x4_t ld[NLD];
+    auto issue_one = [&](int batch, int n) __attribute__((always_inline)) {
+        const int rr = (pl + 16 * n) / PXR;
+        const int row = reflect(sy - HALO + batch * RS + rr, p.H);
+        ld[n] = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)row * p.xs[1] + col_off[n]);
+    };
+    // GroupNorm affine + SiLU + bf16, into ring slot (input row index % RING)
+    auto commit_one = [&](int batch, int n) __attribute__((always_inline)) {
+        const int i = pl + 16 * n;
+        const int rr = i / PXR, px = i - rr * PXR;
+        const int slot = (batch * RS + rr) % RING;
+        const bf16x8_t v = __builtin_bit_cast(bf16x8_t, ld[n]);
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(cvec + C + chunk * 8);
+        const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(cvec + C + chunk * 8 + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(cvec + 2 * C + chunk * 8);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(cvec + 2 * C + chunk * 8 + 4);
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (bf16_t)silu(fmaf((float)v[e], a0[e], b0[e]));
+            o[4 + e] = (bf16_t)silu(fmaf((float)v[4 + e], a1[e], b1[e]));
+        }
+        *reinterpret_cast<bf16x8_t*>(ring + slot * ROWE + px * PXE + chunk * 8) = o;
+    };
+    // whole-row stores of output tile `st`: thread -> (pixel, 16-byte chunk); a wave instruction covers
+    // 4 px x 256 contiguous bytes.  EDGE: tile may stick out of the image / segment.
+    auto store_one = [&](int st, int n, auto edge) __attribute__((always_inline)) {
+        const bf16_t* ot = otile + (st & 1) * (RS * TW * PXE);
+        const int opx = pl + 16 * n;  // 0 .. RS*TW-1
+        const int g = opx / TW, px = opx - g * TW;
+        const int orow = sy + st * RS + g;
+        if (!decltype(edge)::value || (orow < sy_end && sx + px < p.W)) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ot + opx * PXE + chunk * 8);
+            *reinterpret_cast<u32x4_t*>(yb + (int64_t)orow * p.ys[1] + (int64_t)(sx + px) * p.ys[2]) = v;
+        }
+    };
+
+    // prologue: batches 0 .. PRE-1 (the NROW rows of step 0) into the ring, batch PRE in flight
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) issue_one(k, n);
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) commit_one(k, n);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) issue_one(PRE, n);
+
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before tap shift)
+
+    // One step = RS output rows.  FIRST: no previous tile to store.  EDGE: per-lane validity checks.
+    // Rows past the segment are loaded (clamped by reflect) and committed but never used, so the body
+    // has no "is there a next step" branches: with FIRST = EDGE = false it is ONE basic block and the
+    // scheduler is free to sink the side work into the MFMA shadow.
+    auto step_body = [&](int step, auto first, auto edge) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value, EDGE = decltype(edge)::value;
+        f32x16_t acc[RS];
+#pragma unroll
+        for (int g = 0; g < RS; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        }
+        int slot_off[NROW];
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) slot_off[i] = ((step * RS + i) % RING) * ROWE;
+
+        bf16_t* ot = otile + (step & 1) * (RS * TW * PXE);
+        // epilogue slice: accumulator rows 4j..4j+3 of output row g -> bias, GroupNorm sums, bf16, LDS tile
+        auto epi = [&](int g, int j) __attribute__((always_inline)) {
+            if (ABL & 2) {
+                asm volatile("" ::"v"(acc[g][j * 4]), "v"(acc[g][j * 4 + 1]), "v"(acc[g][j * 4 + 2]), "v"(acc[g][j * 4 + 3]));
+                return;
+            }
+            const int orow = sy + step * RS + g;
+            const bool valid = !EDGE || ((orow < sy_end) && (sx + n32 < p.W));
+            const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
+            bf16x4_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = acc[g][j * 4 + i] + bj[i];
+                o[i] = (bf16_t)v;
+                const float vm = valid ? v : 0.f;
+                s1[j >> 1] += vm;
+                s2[j >> 1] = fmaf(vm, vm, s2[j >> 1]);
+            }
+            *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
+        };
+
+        bf16x8_t bb[2][KH] = {};
+        auto load_set = [&](int sidx, bf16x8_t (&dst)[KH]) __attribute__((always_inline)) {
+            const int rt = sidx / (8 / KH), kh = sidx - rt * (8 / KH);
+            const int i = rt / KS, dx = rt - i * KS;
+            const bf16_t* bp = ring + slot_off[i] + dx * PXE + lane_b + kh * KH * 16;
+            if (ABL & 4) return;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) dst[ks] = *reinterpret_cast<const bf16x8_t*>(bp + ks * 16);
+        };
+        load_set(0, bb[0]);
+        if constexpr (KS == 3) {
+            // Hand-placed schedule, generated by tools/gen_stem_sched.py: 144 MFMA slots; GroupNorm+SiLU of
+            // the next rows, row stores of the previous tile, loads two steps ahead and the epilogue of
+            // output row 0 are cut into micro-ops of a few independent instructions and pinned behind
+            // individual MFMAs (one wave per SIMD issues in order: nothing else hides them).
+            static_assert(NLD == 5 && NST == 4 && NSETS == 24 && KH == 4 && RS == 2 && RING == 6, "schedule geometry");
+            const int commit_slot = ((step + PRE) * RS) % RING;
+            const bf16_t* prev_tile = otile + ((step - 1) & 1) * (RS * TW * PXE);
+            bf16_t* prev_rows = yb + (int64_t)(sy + (step - 1) * RS) * p.ys[1];
+            auto st_ok = [&](int st, int n) __attribute__((always_inline)) {
+                const int opx = pl + 16 * n;
+                const int g = opx / TW, px = opx - g * TW;
+                return (sy + st * RS + g < sy_end) && (sx + px < p.W);
+            };
+            const bf16_t* next_row0 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS, p.H) * p.xs[1];
+            const bf16_t* next_row1 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS + 1, p.H) * p.xs[1];
+            float cy0[8], cu0[8], cy1[8], cu1[8];
+            uint32_t co0[4], co1[4];
+            u32x4_t stv = {0u, 0u, 0u, 0u};
+#define NAF_PIN1(a) asm volatile("" : "+v"(a))
+#define NAF_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define NAF_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define NAF_SLOT_PIN                                                 \
+    do {                                                             \
+        if constexpr (!(ABL & 64) && NAF_STEM_SLOT_PINS) __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+#include "stem_conv_sched3.inc"
+#undef NAF_SLOT_PIN
+#undef NAF_PIN1
+#undef NAF_PIN2
+#undef NAF_PIN4
+#pragma unroll
+            for (int j = 0; j < 4; ++j) epi(1, j);
+        } else {
+#pragma unroll
+            for (int sidx = 0; sidx < NSETS; ++sidx) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (sidx + 1 < NSETS) load_set(sidx + 1, bb[(sidx + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int rt = sidx / (8 / KH), kh = sidx - rt * (8 / KH);
+                const int i = rt / KS, dx = rt - i * KS;
+#pragma unroll
+                for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+                    for (int g = 0; g < RS; ++g) {
+                        const int dy = i - g;
+                        if (dy >= 0 && dy < KS)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(dy * KS + dx) * 8 + kh * KH + ks],
+                                                                             bb[sidx & 1][ks], acc[g], 0, 0, 0);
+                    }
+                }
+            }
+            // 1x1 (HBM-bound): too few MFMAs to hide anything behind; plain order
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) commit_one(step + PRE, n);
+            if constexpr (!FIRST) {
+#pragma unroll
+                for (int n = 0; n < NST; ++n) store_one(step - 1, n, edge);
+            }
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) issue_one(step + 1 + PRE, n);
+#pragma unroll
+            for (int g = 0; g < RS; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) epi(g, j);
+        }
+        if (!(ABL & 32)) __syncthreads();
+    };
+
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool edge = (sx + TW > p.W) || ((sy_end - sy) % RS != 0);
+    if (!edge) {
+        step_body(0, T{}, F{});
+        for (int step = 1; step < nstep; ++step) step_body(step, F{}, F{});
+#pragma unroll
+        for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, F{});
+    } else {
+        step_body(0, T{}, T{});
+        for (int step = 1; step < nstep; ++step) step_body(step, F{}, T{});
+#pragma unroll
+        for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, T{});
+    }
+
+    if (p.stats_out) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float a = s1[g], q = s2[g];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o);
+                q += __shfl_xor(q, o);
+            }
+            if (lane == 0) {
+                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 0], (double)a);
+                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 1], (double)q);
+            }
+        }
+    }
+}
+

@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Generate naf_amd/csrc/stem_conv_sched3.inc: the hand-placed instruction schedule of one step of the
+3x3 stem layer (stem_conv_kernel<3>), as straight-line HIP.
+
+Why a generator: one wave per SIMD issues everything in order, so the ~300 VALU/LDS/global instructions
+of side work per step (GroupNorm+SiLU of the next rows, row stores of the previous tile, loads two steps
+ahead, epilogue of output row 0) only hide if they sit in the 32-cycle shadow of individual MFMAs, a few
+independent instructions per slot, never a dependent chain.  hipcc does not do that by itself (it leaves
+the side work in clumps and sinks unanchored arithmetic to its use), so the slot assignment is spelled
+out here and every micro-op is anchored (asm volatile "+v") behind the MFMA of its slot.
+
+    python tools/gen_stem_sched.py            # rewrites the .inc (committed; the build does not run this)
+
+Geometry (must match StemGeom<3>): RS = 2 output rows, KH = 4 k-steps per B-fragment set, 24 sets =
+(4 input rows x 3 tap columns x 2 k-halves); input rows 1, 2 feed both output rows (8 MFMAs / set), rows
+0 and 3 feed one (4 MFMAs / set): 144 MFMA slots per step.
+"""
+import os
+
+KS, RS, KH, NROW = 3, 2, 4, 4
+NLD, NST = 5, 4
+NSETS = NROW * KS * (8 // KH)
+
+# ---- slots --------------------------------------------------------------------------------------
+slots = []          # (sidx, ks, g, dy, dx, kh, first_of_set)
+for sidx in range(NSETS):
+    rt, kh = divmod(sidx, 8 // KH)
+    i, dx = divmod(rt, KS)
+    first = True
+    for ks in range(KH):
+        for g in range(RS):
+            dy = i - g
+            if 0 <= dy < KS:
+                slots.append((sidx, ks, g, dy, dx, kh, first))
+                first = False
+NSLOT = len(slots)
+assert NSLOT == 144
+ops = [[] for _ in range(NSLOT)]
+
+# ---- micro-ops ------------------------------------------------------------------------------------
+def commit_ops(n, v):
+    """GroupNorm affine + SiLU + bf16 of load piece n (8 channels of one ring pixel), variable set v.
+    y = x*ga + gb ; u = x*ga2 + gb2 = -log2(e)*y ; out = y * rcp(1 + exp2(u))."""
+    cy, cu, co = f"cy{v}", f"cu{v}", f"co{v}"
+    o = {}
+    for p in range(4):
+        a, b = 2 * p, 2 * p + 1
+        o[f"A{p}"] = (f"{{ const uint32_t w_ = ld[{n}][{p}]; {cy}[{a}] = __uint_as_float(w_ << 16); "
+                      f"{cy}[{b}] = __uint_as_float(w_ & 0xffff0000u); NAF_PIN2({cy}[{a}], {cy}[{b}]); }}")
+        o[f"B{p}"] = (f"{{ const float x0_ = {cy}[{a}], x1_ = {cy}[{b}]; "
+                      f"{cy}[{a}] = fmaf(x0_, ga[{a}], gb[{a}]); {cy}[{b}] = fmaf(x1_, ga[{b}], gb[{b}]); "
+                      f"{cu}[{a}] = fmaf(x0_, ga2[{a}], gb2[{a}]); {cu}[{b}] = fmaf(x1_, ga2[{b}], gb2[{b}]); "
+                      f"NAF_PIN4({cy}[{a}], {cy}[{b}], {cu}[{a}], {cu}[{b}]); }}")
+        o[f"C{p}"] = (f"{{ {cu}[{a}] = __builtin_amdgcn_exp2f({cu}[{a}]); {cu}[{b}] = __builtin_amdgcn_exp2f({cu}[{b}]); "
+                      f"NAF_PIN2({cu}[{a}], {cu}[{b}]); }}")
+        o[f"D{p}"] = f"{{ {cu}[{a}] += 1.0f; {cu}[{b}] += 1.0f; NAF_PIN2({cu}[{a}], {cu}[{b}]); }}"
+        o[f"E{p}"] = (f"{{ {cu}[{a}] = __builtin_amdgcn_rcpf({cu}[{a}]); {cu}[{b}] = __builtin_amdgcn_rcpf({cu}[{b}]); "
+                      f"NAF_PIN2({cu}[{a}], {cu}[{b}]); }}")
+        o[f"F{p}"] = (f"{{ bf16x2_t o_; o_[0] = (bf16_t)({cy}[{a}] * {cu}[{a}]); o_[1] = (bf16_t)({cy}[{b}] * {cu}[{b}]); "
+                      f"{co}[{p}] = __builtin_bit_cast(uint32_t, o_); NAF_PIN1({co}[{p}]); }}")
+    o["G"] = (f"*reinterpret_cast<u32x4_t*>(ring + (commit_slot + c_rr[{n}]) * ROWE + c_pxoff[{n}]) = "
+              f"u32x4_t{{{co}[0], {co}[1], {co}[2], {co}[3]}};")
+    return o
+
+PIECE_PLAN = [  # relative slot -> micro-op names
+    ["A0", "A1"], ["B0", "B1"], ["C0", "A2"], ["C1", "D0", "A3"], ["E0", "D1", "B2"], ["E1", "B3"],
+    ["C2", "F0"], ["C3", "F1", "D2"], ["E2", "D3"], ["E3", "F2"], ["F3"], ["G"],
+]
+COMMIT_BASE, COMMIT_STRIDE = 2, 11
+for n in range(NLD):
+    o = commit_ops(n, n & 1)
+    for r, names in enumerate(PIECE_PLAN):
+        for nm in names:
+            ops[COMMIT_BASE + COMMIT_STRIDE * n + r].append(("commit", o[nm]))
+last_commit_read = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + 3      # last A-stage of the last piece
+
+# row stores of the previous output tile
+ST_BASE = 60
+assert ST_BASE > last_commit_read
+for n in range(NST):
+    ops[ST_BASE + 3 * n].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
+    ops[ST_BASE + 3 * n + 2].append(("store", f"if (!EDGE || st_ok(step - 1, {n})) *reinterpret_cast<u32x4_t*>(prev_rows + st_goff[{n}]) = stv;"))
+
+# global loads for the step after next (ld[n] was consumed by A-stages before slot 60)
+LD_BASE = ST_BASE + 3 * NST + 2
+for n in range(NLD):
+    ops[LD_BASE + 2 * n].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>((c_rr[{n}] ? next_row1 : next_row0) + col_off[{n}]);"))
+
+# epilogue of output row 0: its accumulator is final once input row 2 is done (slot 119)
+first_row3 = next(k for k, s in enumerate(slots) if s[0] >= 18)
+assert first_row3 == 120
+for j in range(4):
+    ops[first_row3 + 2 + 5 * j].append(("epi", f"epi(0, {j});"))
+
+# ---- emit -------------------------------------------------------------------------------------------
+out = []
+out.append("// GENERATED by tools/gen_stem_sched.py -- do not edit.  One step of stem_conv_kernel<3>: 144 MFMA slots,")
+out.append("// side work pinned behind individual MFMAs.  Included inside step_body (stem_conv_kernel.h).")
+for k, (sidx, ks, g, dy, dx, kh, first) in enumerate(slots):
+    if first:
+        out.append(f"// ---- set {sidx}: input row {sidx // (KS * (8 // KH))}, tap column {dx}, k-steps {kh * KH}..{kh * KH + KH - 1}")
+        out.append("__builtin_amdgcn_sched_barrier(0);")
+        if sidx + 1 < NSETS:
+            out.append(f"load_set({sidx + 1}, bb[{(sidx + 1) & 1}]);")
+            out.append("__builtin_amdgcn_sched_barrier(0);")
+    widx = (dy * KS + dx) * 8 + kh * KH + ks
+    out.append(f"acc[{g}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[{widx}], bb[{sidx & 1}][{ks}], acc[{g}], 0, 0, 0);  // slot {k}")
+    for kind, code in ops[k]:
+        if kind == "store":
+            out.append(f"if constexpr (!(ABL & 8) && !FIRST) {{ {code} }}")
+        elif kind == "epi":
+            out.append(code)
+        elif kind == "load":
+            out.append(f"if constexpr (!(ABL & 16)) {{ {code} }}")
+        else:
+            out.append(f"if constexpr (!(ABL & 1)) {{ {code} }}")
+    out.append("NAF_SLOT_PIN;")
+
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "naf_amd", "csrc", "stem_conv_sched3.inc")
+with open(path, "w") as f:
+    f.write("\n".join(out) + "\n")
+busy = sum(1 for o in ops if o)
+print(f"wrote {path}: {NSLOT} slots, {busy} carry side work, max micro-ops per slot {max(len(o) for o in ops)}")

@@ -1,0 +1,76 @@
+// Stand-alone ablation / timing probe for the stem GroupNorm+SiLU+conv kernel (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inaf_amd/csrc tools/stem_probe.hip -o tools/bin/stem_probe
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "stem_conv_kernel.h"
+
+void naf_set_error(const char* fmt, ...) { (void)fmt; }
+int naf_check_launch(const char* what) { (void)what; return 0; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+template <int KS, int ABL>
+void run(StemConvParams p, int nblocks, int reps, const char* name, double flops, double bytes) {
+    using G = StemGeom<KS>;
+    const size_t lds = (size_t)(G::RING * G::ROWE + 2 * RS * TW * PXE) * 2 + 3 * C * sizeof(float);
+    auto kern = stem_conv_kernel<KS, ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, 0, p);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+    printf("k=%d %-46s %8.4f ms  %7.1f TFLOP/s  %7.1f GB/s\n", KS, name, ms, flops / ms / 1e9, bytes / ms / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const int H = argc > 1 ? atoi(argv[1]) : 1024, W = argc > 2 ? atoi(argv[2]) : 1024, reps = argc > 3 ? atoi(argv[3]) : 10;
+    const int segs_in = argc > 4 ? atoi(argv[4]) : 0;
+    const size_t n = (size_t)H * W * 128;
+    std::vector<uint16_t> hx(n);
+    uint32_t st = 777u;
+    for (auto& v : hx) { st = st * 1664525u + 1013904223u; union { float f; uint32_t u; } c; c.f = ((st >> 8) & 0xffff) / 32768.0f - 1.f; v = (uint16_t)(c.u >> 16); }
+    bf16_t *x, *y, *w; float *vec; double* stats;
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4)); CK(hipMalloc(&stats, 2 * 16 * 8));
+    CK(hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w, hx.data(), 9 * 128 * 128 * 2, hipMemcpyHostToDevice));
+    std::vector<float> hv(3 * 128, 0.5f);
+    CK(hipMemcpy(vec, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+    std::vector<double> hs(32);
+    for (int g = 0; g < 8; ++g) { hs[2 * g] = 0.0; hs[2 * g + 1] = (double)H * W * 16 * 0.33; }
+    CK(hipMemcpy(stats, hs.data(), 16 * 8, hipMemcpyHostToDevice));
+    StemConvParams p;
+    p.x = x; p.y = y; p.w = w; p.bias = vec; p.gamma = vec + 128; p.beta = vec + 256; p.stats_in = stats; p.stats_out = stats + 16;
+    p.B = 1; p.H = H; p.W = W; p.eps = 1e-5f;
+    p.xs[0] = (int64_t)n; p.xs[1] = (int64_t)W * 128; p.xs[2] = 128;
+    p.ys[0] = (int64_t)n; p.ys[1] = (int64_t)W * 128; p.ys[2] = 128;
+    p.tiles_x = (W + TW - 1) / TW;
+    for (int mult : {1, 2}) {
+        int segs = segs_in > 0 ? segs_in : (256 * mult + p.tiles_x - 1) / p.tiles_x;
+        int seg_h = (H + segs - 1) / segs; seg_h = ((seg_h + RS - 1) / RS) * RS;
+        p.seg_h = seg_h; p.segs_y = (H + seg_h - 1) / seg_h;
+        const int nb = p.tiles_x * p.segs_y;
+        printf("image %dx%d, %d workgroups (%d strips x %d segments of %d rows)\n", H, W, nb, p.tiles_x, p.segs_y, seg_h);
+        const double px = (double)H * W, by = px * 512.0;
+        run<3, 0>(p, nb, reps, "full", px * 2 * 1152 * 128, by);
+        run<3, 1>(p, nb, reps, "no commit (GN+SiLU, ring writes)", px * 2 * 1152 * 128, by);
+        run<3, 8>(p, nb, reps, "no row stores", px * 2 * 1152 * 128, by);
+        run<3, 16>(p, nb, reps, "no global loads", px * 2 * 1152 * 128, by);
+        run<3, 2>(p, nb, reps, "no epilogue", px * 2 * 1152 * 128, by);
+        run<3, 32>(p, nb, reps, "no barrier", px * 2 * 1152 * 128, by);
+        run<3, 25>(p, nb, reps, "no side work at all", px * 2 * 1152 * 128, by);
+        run<3, 27>(p, nb, reps, "LDS reads + MFMA + barrier", px * 2 * 1152 * 128, by);
+        run<3, 59>(p, nb, reps, "LDS reads + MFMA", px * 2 * 1152 * 128, by);
+        run<3, 63>(p, nb, reps, "MFMA only", px * 2 * 1152 * 128, by);
+        run<3, 59 + 64>(p, nb, reps, "LDS reads + MFMA, no slot pins", px * 2 * 1152 * 128, by);
+        run<3, 64>(p, nb, reps, "full, no slot pins", px * 2 * 1152 * 128, by);
+        run<1, 0>(p, nb, reps, "full", px * 2 * 128 * 128, by);
+        if (segs_in > 0) break;
+    }
+    return 0;
+}
