@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     for (int n = 0; n < NLD; ++n) issue_one(PRE, n);
 
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    long long tmacc[3] = {0, 0, 0};  // probe only (ABL & 128): cycles in MFMA block / epilogue / barrier
     const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before tap shift)
 
     // One step = RS output rows.  FIRST: no previous tile to store.  EDGE: per-lane validity checks.
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
             for (int ks = 0; ks < KH; ++ks) dst[ks] = *reinterpret_cast<const bf16x8_t*>(bp + ks * 16);
         };
         load_set(0, bb[0]);
+        long long tm0 = 0;
+        if constexpr ((ABL & 128) != 0) tm0 = __builtin_readcyclecounter();
         if constexpr (KS == 3) {
             // Hand-placed schedule, generated by tools/gen_stem_sched.py: 144 MFMA slots; GroupNorm+SiLU of
             // the next rows, row stores of the previous tile, loads two steps ahead and the epilogue of
@@ -282,8 +285,19 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
 #undef NAF_PIN1
 #undef NAF_PIN2
 #undef NAF_PIN4
+            long long tm1 = 0;
+            if constexpr ((ABL & 128) != 0) tm1 = __builtin_readcyclecounter();
 #pragma unroll
             for (int j = 0; j < 4; ++j) epi(1, j);
+            if constexpr ((ABL & 128) != 0) {
+                const long long tm2 = __builtin_readcyclecounter();
+                __syncthreads();
+                const long long tm3 = __builtin_readcyclecounter();
+                tmacc[0] += tm1 - tm0;
+                tmacc[1] += tm2 - tm1;
+                tmacc[2] += tm3 - tm2;
+                return;
+            }
         } else {
 #pragma unroll
             for (int sidx = 0; sidx < NSETS; ++sidx) {
@@ -335,6 +349,12 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
         for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, T{});
     }
 
+    if constexpr ((ABL & 128) != 0) {
+        if (lane == 0 && blockIdx.x < 8) {
+            for (int i = 0; i < 3; ++i) p.stats_out[16 + (blockIdx.x * 4 + wave) * 4 + i] = (double)tmacc[i];
+            p.stats_out[16 + (blockIdx.x * 4 + wave) * 4 + 3] = (double)nstep;
+        }
+    }
     if (p.stats_out) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {

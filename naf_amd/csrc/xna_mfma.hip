@@ -1,14 +1,9 @@
 // Eligibility test + dispatcher for the MFMA cell kernel (see xna_mfma_kernel.h).
 #include "xna_mfma_kernel.h"
 
-#define NAF_DECL(K) int naf_xna_mfma_launch_k##K(const XnaMfmaParams& p, int dvt, int out_dtype, hipStream_t s);
+#define NAF_DECL(K) int naf_xna_mfma_launch_k##K(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s);
 NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13) NAF_DECL(15)
 #undef NAF_DECL
-
-static size_t lds_for(int ks, int dvt) {
-    const int kpad = ((ks * ks + 31) / 32) * 32;
-    return (size_t)kpad * (72 + dvt + 16) * 2;
-}
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -27,15 +22,11 @@ int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) 
     for (int i = 0; i < 4; ++i) {
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->o_stride[i] % 4) return 0;
     }
-    static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
-    for (int c : cand) {
-        if (a->Dv % c == 0 && lds_for(ks, c) <= 160 * 1024) {
-            if (dvt_out) *dvt_out = c;
-            if (lds_out) *lds_out = lds_for(ks, c);
-            return 1;
-        }
-    }
-    return 0;
+    XnaMfmaPlan pl;
+    if (!xna_mfma_plan(ks, a->Dv, a->out_dtype, &pl)) return 0;
+    if (dvt_out) *dvt_out = pl.dvt;
+    if (lds_out) *lds_out = pl.lds;
+    return 1;
 }
 
 int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
@@ -55,8 +46,11 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.out = a->out;
     p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
     p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
-    p.nchunk = a->Dv / dvt;
-    const int64_t nb = (int64_t)a->B * a->h * a->w * a->heads * p.nchunk;
+    XnaMfmaPlan pl;
+    xna_mfma_plan(a->ky, a->Dv, a->out_dtype, &pl);
+    p.nchunk = a->Dv / pl.dvt;
+    const int bh = (a->h + pl.cb - 1) / pl.cb, bw = (a->w + pl.cb - 1) / pl.cb;
+    const int64_t nb = (int64_t)a->B * bh * bw * a->heads * p.nchunk;
     if (nb <= 0 || nb > 0x7fffffffLL) {
         naf_set_error("naf_xna_fwd: grid of %lld workgroups out of range", (long long)nb);
         return NAF_ERR_INVALID;
@@ -67,13 +61,13 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
         p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i]; p.os[i] = a->o_stride[i];
     }
     switch (a->ky) {
-        case 3: return naf_xna_mfma_launch_k3(p, dvt, a->out_dtype, s);
-        case 5: return naf_xna_mfma_launch_k5(p, dvt, a->out_dtype, s);
-        case 7: return naf_xna_mfma_launch_k7(p, dvt, a->out_dtype, s);
-        case 9: return naf_xna_mfma_launch_k9(p, dvt, a->out_dtype, s);
-        case 11: return naf_xna_mfma_launch_k11(p, dvt, a->out_dtype, s);
-        case 13: return naf_xna_mfma_launch_k13(p, dvt, a->out_dtype, s);
-        case 15: return naf_xna_mfma_launch_k15(p, dvt, a->out_dtype, s);
+        case 3: return naf_xna_mfma_launch_k3(p, pl, a->out_dtype, s);
+        case 5: return naf_xna_mfma_launch_k5(p, pl, a->out_dtype, s);
+        case 7: return naf_xna_mfma_launch_k7(p, pl, a->out_dtype, s);
+        case 9: return naf_xna_mfma_launch_k9(p, pl, a->out_dtype, s);
+        case 11: return naf_xna_mfma_launch_k11(p, pl, a->out_dtype, s);
+        case 13: return naf_xna_mfma_launch_k13(p, pl, a->out_dtype, s);
+        case 15: return naf_xna_mfma_launch_k15(p, pl, a->out_dtype, s);
     }
     naf_set_error("naf_xna_fwd: kernel size %d has no MFMA instantiation", a->ky);
     return NAF_ERR_UNSUPPORTED;

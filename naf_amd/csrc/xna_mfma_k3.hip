@@ -2,6 +2,6 @@
 // build can compile them in parallel).
 #include "xna_mfma_kernel.h"
 
-int naf_xna_mfma_launch_k3(const XnaMfmaParams& p, int dvt, int out_dtype, hipStream_t s) {
-    return xna_mfma_launch_ks<3>(p, dvt, out_dtype, s);
+int naf_xna_mfma_launch_k3(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s) {
+    return xna_mfma_launch_ks<3>(p, pl, out_dtype, s);
 }

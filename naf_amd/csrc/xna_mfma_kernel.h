@@ -5,22 +5,23 @@
 // keys/values.  K/V are never upsampled and the score tensor never exists.
 //
 // Work decomposition
-//   one workgroup (4 waves) = one (batch, cell, head, Dv-chunk); grid ids are remapped so each XCD
-//   (private 4 MiB L2) owns a contiguous band of cell rows and neighbouring windows meet in one L2.
-//   LDS: the head's K window [KPAD][64 (+8 pad)] bf16 and V window [KPAD][DVT (+16 pad)] bf16,
-//   KPAD = KS*KS rounded up to 32, pad rows zero.
-//   each wave walks 16-query tiles of the cell.  Everything is "swapped" so that one lane owns one
+//   one workgroup (4 waves) = one (batch, block of CB x CB cells, head, Dv-chunk); grid ids are remapped so
+//   each XCD (private 4 MiB L2) owns a contiguous band of cell rows and neighbouring windows meet in one L2.
+//   LDS: the head's K window [slots][64 (+8 pad)] bf16 and V window [slots][DVT (+16 pad)] bf16, slots =
+//   (KS+CB-1)^2 real keys (key slots up to the MFMA multiple of 32 are masked and never stored), plus
+//   (bf16 output) one [16][DVT+8] output tile per wave.
+//   each wave walks 16-query tiles of the block's cells.  Everything is "swapped" so that one lane owns one
 //   query column of the MFMA result:
 //     S^T[key][px] = K[key][:] . Q[px][:]        v_mfma_f32_16x16x32_bf16, A = K rows from LDS
 //                                                 (ds_read_b128), B = Q straight from HBM (16 B/lane)
 //     softmax over keys: 16 values in-lane + 2 cross-lane steps (lanes l^16, l^32), fp32, exp2
 //     O^T[ch][px]  = V^T[ch][key] . P^T[key][px] A = V^T via ds_read_b64_tr_b16 (hardware transpose
 //                                                 of the row-major V window), B = P packed to bf16
-//   lane (px = l&15, g = l>>4) ends with 4 consecutive channels of its own pixel per 16-channel
-//   tile; bf16 tiles are paired and re-dealt with v_permlane16_swap so every lane stores 16 bytes
-//   (64 contiguous bytes per pixel per instruction); 1/sum is applied in registers.
-//   The MFMA contraction order over keys is a free permutation; the same (g, j) -> key slot map
-//   is used for P and V^T so no cross-lane movement of P is needed.
+//   lane (px = l&15, g = l>>4) ends with 4 consecutive channels of its own pixel per 16-channel tile; bf16
+//   tiles are paired and re-dealt with v_permlane16_swap (8 channels = 16 B per lane), collected in the
+//   wave's LDS tile and stored as whole pixel rows: one store instruction = 1 KiB of DVT*2-byte runs.
+//   1/sum is applied in registers.  The MFMA contraction order over keys is a free permutation; the same
+//   (g, j) -> key slot map is used for P and V^T so no cross-lane movement of P is needed.
 #pragma once
 #include "naf_common.h"
 
@@ -35,10 +36,15 @@ struct XnaMfmaParams {
     int64_t qs[4], ks[4], vs[4], os[4];  // {b, head, y, x} element strides
 };
 
-template <int KS>
+// CB = cells per workgroup edge (1 or 2).  With CB = 2 a workgroup serves a 2x2 block of low-res cells whose
+// clamped KS x KS windows differ by at most one row / column: their union is a (KS+1) x (KS+1) window,
+// staged ONCE (64 keys for KS = 7 = exactly the padded MFMA key count, so the matrix work is unchanged) and
+// each cell masks the row / column that is not in its own window.  Window staging per cell drops 3x.
+template <int KS, int CB>
 struct XnaGeom {
-    static constexpr int KK = KS * KS;
-    static constexpr int KPAD = ((KK + 31) / 32) * 32;
+    static constexpr int WS = KS + CB - 1;         // window side held in LDS
+    static constexpr int NSLOT = WS * WS;          // key slots with real data: slot = ry * WS + rx
+    static constexpr int KPAD = ((NSLOT + 31) / 32) * 32;
     static constexpr int MT = KPAD / 16;
     static constexpr int KST = KPAD / 32;
     static constexpr int KROW = 64 + 8;  // bf16 elements per K row in LDS (144 B: 16 B-aligned, conflict-light)
@@ -48,9 +54,14 @@ struct XnaVRow {
     static constexpr int VROW = DVT + 16;  // bf16 elements per V row in LDS (row stride = 8 banks mod 64 for DVT%64==0..)
 };
 
-template <int KS, int DVT>
+// LDS bytes: K window [NSLOT][64+8] + V window [NSLOT][dvt+16] (pad key slots are NOT stored: their reads are
+// clamped to the last real row, P is exactly 0 there) + optional per-wave output staging [4][16][dvt+8].
+constexpr size_t xna_mfma_lds_for(int ks, int cb, int dvt, bool staged, int nw = 4) {
+    return (size_t)((ks + cb - 1) * (ks + cb - 1)) * (72 + dvt + 16) * 2 + (staged ? (size_t)nw * 16 * (dvt + 8) * 2 : 0);
+}
+template <int KS, int CB, int DVT, bool STG, int NW = 4>
 constexpr size_t xna_mfma_lds_bytes() {
-    return (size_t)XnaGeom<KS>::KPAD * (XnaGeom<KS>::KROW + XnaVRow<DVT>::VROW) * 2;
+    return xna_mfma_lds_for(KS, CB, DVT, STG, NW);
 }
 
 __device__ __forceinline__ void xna_store4(bf16_t* dst, f32x4_t v) {
@@ -65,18 +76,21 @@ __device__ __forceinline__ void xna_store4(float* dst, f32x4_t v) { *reinterpret
 
 // ABL: ablation bits for tools/xna_probe.hip only (the library instantiates ABL = 0):
 //   1 no output stores, 2 no PV MFMAs / V reads, 4 no Q loads, 8 no K/V staging loads, 16 no QK MFMAs,
-//   32 non-temporal output stores, 64 narrow (8 B / lane) bf16 stores
-template <int KS, int DVT, typename OutT, int ABL = 0>
-__global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
-    using G = XnaGeom<KS>;
-    constexpr int KK = G::KK, KPAD = G::KPAD, MT = G::MT, KST = G::KST, KROW = G::KROW;
+//   64 narrow (8 B / lane) bf16 stores on the unstaged path
+template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p) {
+    constexpr int NT = NW * 64;  // threads per workgroup
+    using G = XnaGeom<KS, CB>;
+    constexpr int WS = G::WS, NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW;
     constexpr int VROW = XnaVRow<DVT>::VROW;
     constexpr int CT = DVT / 16;
     constexpr int VCH = DVT / 8;  // 16-byte chunks per V row
+    constexpr int OROW = DVT + 8;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + KPAD * KROW;
+    bf16_t* Vs = Ks + NSLOT * KROW;
+    bf16_t* Os = Vs + NSLOT * VROW;  // [NW waves][16][DVT + 8] when STG
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,67 +98,43 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
     const int col = lane & 15;  // MFMA column index (query within tile) / A-row index (key or channel)
     const int grp = lane >> 4;  // MFMA k-group / result row group
 
+    const int bh = (p.h + CB - 1) / CB, bw = (p.w + CB - 1) / CB;  // blocks of CB x CB cells
     uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
     const int chunk = L % p.nchunk;
     L /= p.nchunk;
     const int head = L % p.heads;
     L /= p.heads;
-    const int cx = L % p.w;
-    L /= p.w;
-    const int cy = L % p.h;
-    const int b = L / p.h;
+    const int bx = L % bw;
+    L /= bw;
+    const int by = L % bh;
+    const int b = L / bh;
+    const int cy0 = by * CB, cx0 = bx * CB;
+    const int ncy = min(CB, p.h - cy0), ncx = min(CB, p.w - cx0);
 
-    const int y0 = min(max(cy - KS / 2, 0), p.h - KS);
-    const int x0 = min(max(cx - KS / 2, 0), p.w - KS);
-
-    // ---- stage the K and V windows (L2 -> registers -> LDS); pad rows are written as zeros ----
-    {
-        const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1] + (int64_t)y0 * p.ks[2] + (int64_t)x0 * p.ks[3];
-#pragma unroll
-        for (int it = 0; it < KST; ++it) {
-            const int i = it * 256 + tid;
-            const int key = i >> 3, c = i & 7;
-            u32x4_t val = {0u, 0u, 0u, 0u};
-            if (key < KK && !(ABL & 8)) {
-                const int wy = key / KS, wx = key - wy * KS;
-                val = *reinterpret_cast<const u32x4_t*>(kb + wy * p.ks[2] + wx * p.ks[3] + c * 8);
-            }
-            *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) = val;
-        }
-        const bf16_t* vb =
-            p.v + b * p.vs[0] + head * p.vs[1] + (int64_t)y0 * p.vs[2] + (int64_t)x0 * p.vs[3] + chunk * DVT;
-        constexpr int VTOT = KPAD * VCH;
-#pragma unroll
-        for (int it = 0; it < (VTOT + 255) / 256; ++it) {
-            const int i = it * 256 + tid;
-            if ((VTOT % 256 == 0) || i < VTOT) {
-                const int key = i / VCH, c = i - key * VCH;
-                u32x4_t val = {0u, 0u, 0u, 0u};
-                if (key < KK && !(ABL & 8)) {
-                    const int wy = key / KS, wx = key - wy * KS;
-                    val = *reinterpret_cast<const u32x4_t*>(vb + wy * p.vs[2] + wx * p.vs[3] + c * 8);
-                }
-                *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) = val;
-            }
-        }
-    }
-    __syncthreads();
+    // union window origin = window start of the block's first cell
+    const int y0 = min(max(cy0 - KS / 2, 0), p.h - KS);
+    const int x0 = min(max(cx0 - KS / 2, 0), p.w - KS);
 
     const int npix = p.dy * p.dx;
-    const int ntile = (npix + 15) >> 4;
-    const bf16_t* qb = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)(cy * p.dy) * p.qs[2] + (int64_t)(cx * p.dx) * p.qs[3];
-    OutT* ob = reinterpret_cast<OutT*>(p.out) + b * p.os[0] + head * p.os[1] + (int64_t)(cy * p.dy) * p.os[2] +
-               (int64_t)(cx * p.dx) * p.os[3] + chunk * DVT;
+    const int ntile = (npix + 15) >> 4;         // 16-query tiles per cell
+    const int ttot = ncy * ncx * ntile;         // tiles of the whole block
+    const bf16_t* qbb = p.q + b * p.qs[0] + head * p.qs[1];
+    OutT* obb = reinterpret_cast<OutT*>(p.out) + b * p.os[0] + head * p.os[1] + chunk * DVT;
 
-    // per-lane LDS addresses
-    const bf16_t* ka = Ks + col * KROW + grp * 8;                                // + mt*16*KROW + ks*32
-    const bf16_t* va = Vs + (grp * 4 + (col >> 2)) * VROW + (col & 3) * 4;       // + (ks*32 + half*16)*VROW + ct*16
+    // tile tt of the block -> its cell (cyi, cxi), tile t inside the cell, query pointer of this lane
+    auto q_ptr = [&](int tt) __attribute__((always_inline)) {
+        const int ttc = min(tt, ttot - 1);
+        const int ci = ttc / ntile, t = ttc - ci * ntile;
+        const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
+        const int ps = min(t * 16 + col, npix - 1);
+        const int py = ps / p.dx, px = ps - py * p.dx;
+        return qbb + (int64_t)((cy0 + cyi) * p.dy + py) * p.qs[2] + (int64_t)((cx0 + cxi) * p.dx + px) * p.qs[3] + grp * 8;
+    };
 
+    // first tile's queries: issued before the window staging so their HBM latency hides under it
     bf16x8_t qf[2];
     {
-        const int ps = min(wave * 16 + col, npix - 1);
-        const int py = ps / p.dx, px = ps - py * p.dx;
-        const bf16_t* qp = qb + py * p.qs[2] + px * p.qs[3] + grp * 8;
+        const bf16_t* qp = q_ptr(wave);
         if (!(ABL & 4)) {
             qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
             qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
@@ -153,13 +143,60 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
         }
     }
 
-    for (int t = wave; t < ntile; t += 4) {
+
+    // ---- stage the K and V windows (L2 -> registers -> LDS).  Slots outside the grid (only possible for the
+    // extra row / column of a CB = 2 window at the border) load a clamped cell; no query attends to them.
+    {
+        const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
+        constexpr int KTOT = NSLOT * 8;
+#pragma unroll
+        for (int it = 0; it < (KTOT + NT - 1) / NT; ++it) {
+            const int i = it * NT + tid;
+            if ((KTOT % NT == 0) || i < KTOT) {
+                const int key = i >> 3, c = i & 7;
+                u32x4_t val = {0u, 0u, 0u, 0u};
+                if (!(ABL & 8)) {
+                    const int ry = key / WS, rx = key - ry * WS;
+                    const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
+                    val = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)yy * p.ks[2] + (int64_t)xx * p.ks[3] + c * 8);
+                }
+                *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) = val;
+            }
+        }
+        const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
+        constexpr int VTOT = NSLOT * VCH;
+#pragma unroll
+        for (int it = 0; it < (VTOT + NT - 1) / NT; ++it) {
+            const int i = it * NT + tid;
+            if ((VTOT % NT == 0) || i < VTOT) {
+                const int key = i / VCH, c = i - key * VCH;
+                u32x4_t val = {0u, 0u, 0u, 0u};
+                if (!(ABL & 8)) {
+                    const int ry = key / WS, rx = key - ry * WS;
+                    const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
+                    val = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)yy * p.vs[2] + (int64_t)xx * p.vs[3] + c * 8);
+                }
+                *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) = val;
+            }
+        }
+    }
+    __syncthreads();
+
+    // key slots >= NSLOT are not stored: clamp their row to the last real key (their logits are masked, P = 0)
+    auto ka_of = [&](int mt) __attribute__((always_inline)) {   // K row mt*16 + col, 8 d's at ks*32 + grp*8
+        const int row = (mt * 16 + 15 < NSLOT) ? mt * 16 + col : min(mt * 16 + col, NSLOT - 1);
+        return Ks + row * KROW + grp * 8;
+    };
+    auto va_of = [&](int blk) __attribute__((always_inline)) {  // V rows blk*16 + grp*4 + (col>>2), 4 ch at (col&3)*4
+        const int r = blk * 16 + grp * 4 + (col >> 2);
+        const int row = (blk * 16 + 15 < NSLOT) ? r : min(r, NSLOT - 1);
+        return Vs + row * VROW + (col & 3) * 4;
+    };
+    for (int tt = wave; tt < ttot; tt += NW) {
         // prefetch the next tile's queries (clamped address when there is none)
         bf16x8_t qn[2];
         {
-            const int ps = min((t + 4) * 16 + col, npix - 1);
-            const int py = ps / p.dx, px = ps - py * p.dx;
-            const bf16_t* qp = qb + py * p.qs[2] + px * p.qs[3] + grp * 8;
+            const bf16_t* qp = q_ptr(tt + NW);
             if (!(ABL & 4)) {
                 qn[0] = *reinterpret_cast<const bf16x8_t*>(qp);
                 qn[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
@@ -167,6 +204,12 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
                 qn[0] = qn[1] = bf16x8_t{};
             }
         }
+        const int ci = tt / ntile, t = tt - ci * ntile;
+        const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
+        const int cy = cy0 + cyi, cx = cx0 + cxi;
+        // this cell's own window inside the staged (union) window
+        const int oy = (CB == 1) ? 0 : min(max(cy - KS / 2, 0), p.h - KS) - y0;
+        const int ox = (CB == 1) ? 0 : min(max(cx - KS / 2, 0), p.w - KS) - x0;
 
         // ---- S^T = K . Q^T ----
         f32x4_t s[MT];
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (!(ABL & 16)) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka + mt * 16 * KROW + ks * 32);
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
                 } else {
                     acc[ks] += (float)qf[ks][mt & 7];
@@ -191,8 +234,15 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (mt * 16 + 15 >= KK) {  // tile contains pad slots: mask them
-                    const bool valid = (mt * 16 + r + grp * 4) < KK;
+                if constexpr (CB == 1) {
+                    if (mt * 16 + 15 >= NSLOT) {  // tile contains pad slots: mask them
+                        const bool valid = (mt * 16 + r + grp * 4) < NSLOT;
+                        s[mt][r] = valid ? s[mt][r] : -INFINITY;
+                    }
+                } else {
+                    const int sl = mt * 16 + grp * 4 + r;
+                    const int ry = sl / WS, rx = sl - ry * WS;
+                    const bool valid = ((unsigned)(ry - oy) < (unsigned)KS) && ((unsigned)(rx - ox) < (unsigned)KS) && (sl < NSLOT);
                     s[mt][r] = valid ? s[mt][r] : -INFINITY;
                 }
                 m = fmaxf(m, s[mt][r]);
@@ -225,6 +275,7 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
         const bool pvalid = ps < npix;
         const int psc = min(ps, npix - 1);
         const int py = psc / p.dx, px = psc - py * p.dx;
+        OutT* ob = obb + (int64_t)(cy * p.dy) * p.os[2] + (int64_t)(cx * p.dx) * p.os[3];
         OutT* op = ob + py * p.os[2] + px * p.os[3];
         auto pv_tile = [&](int ct) -> f32x4_t {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -234,10 +285,8 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
                     acc[ks & 3] += (float)pf[ks][ct & 7];
                     continue;
                 }
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (NAF_LDS bf16x4_t*)(va + (ks * 32) * VROW + ct * 16));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (NAF_LDS bf16x4_t*)(va + (ks * 32 + 16) * VROW + ct * 16));
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
                 bf16x8_t a;
                 a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
                 a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
@@ -245,6 +294,57 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
             }
             return acc * inv;
         };
+        if constexpr (STG) {
+            // bf16, whole-row stores: the wave's 16 px x DVT result goes through its private LDS tile and
+            // leaves as 16-byte chunks in memory order, so one store instruction writes 1 KiB made of
+            // DVT*2-byte contiguous runs (full 128-byte lines) instead of 64 scattered 16-byte pieces.
+            static_assert(sizeof(OutT) == 2 && (CT % 2) == 0, "staged stores: bf16, even tile count");
+            bf16_t* ow = Os + wave * 16 * OROW;
+            bf16_t* owl = ow + col * OROW + (grp & 1) * 16 + (grp >> 1) * 8;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct += 2) {
+                const f32x4_t a = pv_tile(ct), bq = pv_tile(ct + 1);
+                bf16x4_t ab, bb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ab[i] = (bf16_t)a[i];
+                    bb[i] = (bf16_t)bq[i];
+                }
+                const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                *reinterpret_cast<u32x4_t*>(owl + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+            }
+            constexpr int NCH = 16 * VCH;  // 16-byte chunks in the tile
+            const bool rowrun = (p.dx & 15) == 0;  // a tile is 16 consecutive pixels of one row
+            const int t0 = t * 16;
+            const int ty = rowrun ? t0 / p.dx : 0, tx0 = rowrun ? t0 - ty * p.dx : 0;
+#pragma unroll
+            for (int it = 0; it < (NCH + 63) / 64; ++it) {
+                const int i = it * 64 + lane;
+                if ((NCH % 64 == 0) || i < NCH) {
+                    const int pp = i / VCH, ch = i - pp * VCH;
+                    const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + pp * OROW + ch * 8);
+                    int yy, xx;
+                    if (rowrun) {
+                        yy = ty;
+                        xx = tx0 + pp;
+                    } else {
+                        const int sp = min(t0 + pp, npix - 1);
+                        yy = sp / p.dx;
+                        xx = sp - yy * p.dx;
+                    }
+                    if (ABL & 1) {
+                        asm volatile("" ::"v"(wv));
+                    } else if (t0 + pp < npix) {
+                        *reinterpret_cast<u32x4_t*>(ob + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
+                    }
+                }
+            }
+            qf[0] = qn[0];
+            qf[1] = qn[1];
+            continue;
+        }
         constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
         constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
         if constexpr (kWide) {
@@ -289,11 +389,11 @@ __global__ __launch_bounds__(256) void xna_mfma_kernel(const XnaMfmaParams p) {
     }
 }
 
-template <int KS, int DVT, typename OutT>
+template <int KS, int DVT, typename OutT, bool STG, int CB>
 static int xna_mfma_launch_one(const XnaMfmaParams& p, hipStream_t s) {
-    constexpr size_t lds = xna_mfma_lds_bytes<KS, DVT>();
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, CB, DVT, STG>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_mfma_kernel<KS, DVT, OutT>;
+    auto kern = xna_mfma_kernel<KS, DVT, OutT, STG, CB>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -306,35 +406,70 @@ static int xna_mfma_launch_one(const XnaMfmaParams& p, hipStream_t s) {
     return naf_check_launch("xna_mfma_kernel");
 }
 
-// LDS bytes for a (KS, DVT) pair, or 0 when the pair exceeds the 160 KiB budget.
-template <int KS>
-constexpr size_t xna_mfma_lds_for(int dvt) {
-    return (size_t)XnaGeom<KS>::KPAD * (XnaGeom<KS>::KROW + dvt + 16) * 2;
+// cells per workgroup edge: 2 where the union window (KS+1)^2 needs no more MFMA key slots than KS^2 does
+// Measured on G1 (profiles/r01_xna_ablation.txt): 2x2 blocks stage 3x less K/V but the per-element window mask
+// and the halved workgroup count per CU cost more than that saves (0.52 vs 0.485 ms), so the library plans
+// CB = 1; the CB = 2 instantiation stays available to tools/xna_probe.hip.
+constexpr int xna_mfma_cb(int ks) {
+    (void)ks;
+    return 1;
+}
+
+struct XnaMfmaPlan {
+    int dvt;      // Dv tile (channels per workgroup)
+    int cb;       // cells per workgroup edge
+    bool staged;  // whole-row stores through LDS (bf16 output)
+    size_t lds;
+};
+
+// The largest Dv tile that divides Dv and fits 160 KiB; 2x2 cell blocks when free (KS = 7, 15) and they fit;
+// staged whole-row stores for bf16 output when the tile count is even and the staging tiles still fit.
+inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
+    static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
+    for (int c : cand) {
+        if (Dv % c) continue;
+        const bool can_stage = (out_dtype == NAF_BF16) && (c % 32 == 0);
+        for (int cb = xna_mfma_cb(ks); cb >= 1; --cb) {
+            for (int st = can_stage ? 1 : 0; st >= 0; --st) {
+                const size_t lds = xna_mfma_lds_for(ks, cb, c, st != 0);
+                if (lds <= 160 * 1024) {
+                    pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->lds = lds;
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
 }
 
 template <int KS>
-static int xna_mfma_launch_ks(const XnaMfmaParams& p, int dvt, int out_dtype, hipStream_t s) {
-#define NAF_CASE(D)                                                                      \
-    case D:                                                                              \
-        if constexpr (xna_mfma_lds_for<KS>(D) <= 160 * 1024) {                           \
-            return out_dtype == NAF_BF16 ? xna_mfma_launch_one<KS, D, bf16_t>(p, s)      \
-                                         : xna_mfma_launch_one<KS, D, float>(p, s);      \
-        } else {                                                                         \
-            break;                                                                       \
-        }
-    switch (dvt) {
-        NAF_CASE(16)
-        NAF_CASE(48)
-        NAF_CASE(32)
-        NAF_CASE(64)
-        NAF_CASE(96)
-        NAF_CASE(128)
-        NAF_CASE(192)
-        NAF_CASE(256)
-        default:
-            break;
+static int xna_mfma_launch_ks(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s) {
+    constexpr int CBM = xna_mfma_cb(KS);
+#define NAF_TRY(D, ST, CBV, T)                                                              \
+    if constexpr (xna_mfma_lds_for(KS, CBV, D, ST) <= 160 * 1024 && (!(ST) || (D % 32 == 0))) \
+        if (pl.dvt == D && pl.staged == ST && pl.cb == CBV) return xna_mfma_launch_one<KS, D, T, ST, CBV>(p, s);
+#define NAF_CASE(D)                                   \
+    if (out_dtype == NAF_BF16) {                      \
+        NAF_TRY(D, true, CBM, bf16_t)                 \
+        NAF_TRY(D, false, CBM, bf16_t)                \
+        if constexpr (CBM == 2) {                     \
+            NAF_TRY(D, true, 1, bf16_t)               \
+            NAF_TRY(D, false, 1, bf16_t)              \
+        }                                             \
+    } else {                                          \
+        NAF_TRY(D, false, CBM, float)                 \
+        if constexpr (CBM == 2) { NAF_TRY(D, false, 1, float) } \
     }
+    NAF_CASE(16)
+    NAF_CASE(32)
+    NAF_CASE(48)
+    NAF_CASE(64)
+    NAF_CASE(96)
+    NAF_CASE(128)
+    NAF_CASE(192)
+    NAF_CASE(256)
 #undef NAF_CASE
-    naf_set_error("xna_mfma: no kernel for kernel_size=%d Dv-tile=%d", KS, dvt);
+#undef NAF_TRY
+    naf_set_error("xna_mfma: no kernel for kernel_size=%d Dv-tile=%d cb=%d staged=%d", KS, pl.dvt, pl.cb, (int)pl.staged);
     return NAF_ERR_UNSUPPORTED;
 }

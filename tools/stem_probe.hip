@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     uint32_t st = 777u;
     for (auto& v : hx) { st = st * 1664525u + 1013904223u; union { float f; uint32_t u; } c; c.f = ((st >> 8) & 0xffff) / 32768.0f - 1.f; v = (uint16_t)(c.u >> 16); }
     bf16_t *x, *y, *w; float *vec; double* stats;
-    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4)); CK(hipMalloc(&stats, 2 * 16 * 8));
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4)); CK(hipMalloc(&stats, 4096 * 8)); CK(hipMemset(stats, 0, 4096 * 8));
     CK(hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w, hx.data(), 9 * 128 * 128 * 2, hipMemcpyHostToDevice));
     std::vector<float> hv(3 * 128, 0.5f);
@@ -67,6 +67,14 @@ int main(int argc, char** argv) {
         run<3, 27>(p, nb, reps, "LDS reads + MFMA + barrier", px * 2 * 1152 * 128, by);
         run<3, 59>(p, nb, reps, "LDS reads + MFMA", px * 2 * 1152 * 128, by);
         run<3, 63>(p, nb, reps, "MFMA only", px * 2 * 1152 * 128, by);
+        {
+            run<3, 128>(p, nb, 1, "full + cycle counters", px * 2 * 1152 * 128, by);
+            std::vector<double> t(16 + 8 * 16);
+            CK(hipMemcpy(t.data(), stats + 16, (8 * 16) * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; ++w)
+                printf("   wg %d wave %d: per step  mfma-block %.0f  epilogue(g1) %.0f  barrier %.0f cycles (%d steps, counter ticks)\n", w / 4, w % 4,
+                       t[w * 4] / t[w * 4 + 3] / 3, t[w * 4 + 1] / t[w * 4 + 3] / 3, t[w * 4 + 2] / t[w * 4 + 3] / 3, (int)t[w * 4 + 3]);
+        }
         run<3, 59 + 64>(p, nb, reps, "LDS reads + MFMA, no slot pins", px * 2 * 1152 * 128, by);
         run<3, 64>(p, nb, reps, "full, no slot pins", px * 2 * 1152 * 128, by);
         run<1, 0>(p, nb, reps, "full", px * 2 * 128 * 128, by);

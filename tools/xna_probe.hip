@@ -40,17 +40,63 @@ __global__ __launch_bounds__(256) void stream_copy(u32x4_t* __restrict__ out, co
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
 }
 
-template <int ABL>
-float run(const XnaMfmaParams& p, int reps, const char* name, double bytes) {
-    constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, PROBE_DVT>();
-    auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, ABL>;
+// write-pattern experiment: same work decomposition as the attention kernel (one workgroup per (cell, head), 4 waves,
+// 4 tiles of 16 queries each), reads the Q tile, writes the 16 px x 384 B output region of each tile
+//   MODE 0: as the kernel does: 6 instructions, each 16 px x 64 B pieces
+//   MODE 1: 6 instructions, each 1 KiB = 2.67 px x 384 B contiguous pieces (what LDS-staged stores would give)
+template <int MODE>
+__global__ __launch_bounds__(256) void pattern_kernel(const XnaMfmaParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, grp = lane >> 4;
+    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    const int head = L % p.heads; L /= p.heads;
+    const int cx = L % p.w; L /= p.w;
+    const int cy = L % p.h;
+    const bf16_t* qb = p.q + head * p.qs[1] + (int64_t)(cy * p.dy) * p.qs[2] + (int64_t)(cx * p.dx) * p.qs[3];
+    bf16_t* ob = reinterpret_cast<bf16_t*>(p.out) + head * p.os[1] + (int64_t)(cy * p.dy) * p.os[2] + (int64_t)(cx * p.dx) * p.os[3];
+    for (int t = wave; t < 16; t += 4) {
+        const bf16_t* qp = qb + t * p.qs[2] + col * p.qs[3] + grp * 8;
+        u32x4_t a = *reinterpret_cast<const u32x4_t*>(qp);
+        u32x4_t b = *reinterpret_cast<const u32x4_t*>(qp + 32);
+        a[0] ^= b[1];
+        bf16_t* orow = ob + t * p.os[2];
+        if (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                *reinterpret_cast<u32x4_t*>(orow + col * p.os[3] + c * 32 + (grp & 1) * 16 + (grp >> 1) * 8) = a;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int i = c * 64 + lane;          // 16-byte chunk index in the 16 px x 24 chunk tile
+                const int px = i / 24, ch = i - px * 24;
+                *reinterpret_cast<u32x4_t*>(orow + px * p.os[3] + ch * 8) = a;
+            }
+        }
+    }
+}
+template <int MODE>
+void run_pattern(const XnaMfmaParams& p, int reps, const char* name, double bytes) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(pattern_kernel<MODE>, dim3(p.nblocks), dim3(256), 0, 0, p);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(pattern_kernel<MODE>, dim3(p.nblocks), dim3(256), 0, 0, p);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
+    printf("%-44s %8.4f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6);
+}
+
+template <int ABL, bool STG = true, int CB = 1, int NW = 4>
+float run(XnaMfmaParams p, int reps, const char* name, double bytes) {
+    constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, CB, PROBE_DVT, STG, NW>();
+    auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, STG, CB, ABL, NW>;
+    p.nblocks = (uint32_t)(p.B * ((p.h + CB - 1) / CB) * ((p.w + CB - 1) / CB) * p.heads * p.nchunk);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NW * 64), lds, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NW * 64), lds, 0, p);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -115,6 +161,11 @@ int main(int argc, char** argv) {
             printf("stream_copy   grid %5d: %.4f ms  %.1f GB/s (1 read : 1 write)\n", grid, ms, nin * 32.0 / ms / 1e6);
         }
     }
+    if (PROBE_DVT == 192 && d == 16) {
+        run_pattern<0>(p, reps, "pattern: 16 px x 64 B pieces (kernel's)", bytes);
+        run_pattern<1>(p, reps, "pattern: 384 B contiguous pieces", bytes);
+        run_pattern<0>(p, reps, "pattern: 16 px x 64 B pieces (again)", bytes);
+    }
     run<0>(p, reps, "full kernel", bytes);
     run<1>(p, reps, "no output stores", bytes);
     run<2>(p, reps, "no PV mfma / V reads", bytes);
@@ -125,8 +176,13 @@ int main(int argc, char** argv) {
     run<1 | 2 | 16>(p, reps, "no mfma, no stores", bytes);
     run<1 | 4>(p, reps, "no Q loads, no stores (compute only)", bytes);
     run<1 | 4 | 8>(p, reps, "compute only, no staging", bytes);
-    run<64>(p, reps, "narrow 8 B stores (old)", bytes);
-    run<32>(p, reps, "non-temporal stores", bytes);
+    run<0, false, 1, 4>(p, reps, "4 waves, unstaged stores", bytes);
+    run<0, true, 1, 8>(p, reps, "8 waves, staged stores", bytes);
+    run<0, false, 1, 8>(p, reps, "8 waves, unstaged stores", bytes);
+    run<0, true, 2, 4>(p, reps, "2x2 cells, 4 waves, staged", bytes);
+    run<0, true, 2, 8>(p, reps, "2x2 cells, 8 waves, staged", bytes);
+    run<0, false, 2, 8>(p, reps, "2x2 cells, 8 waves, unstaged", bytes);
+    run<64, false>(p, reps, "unstaged narrow 8 B stores", bytes);
     run<0>(p, reps, "full kernel (again)", bytes);
     return 0;
 }
