@@ -51,6 +51,7 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
     }
+    if (a->ksize == 1) ncu *= 2;                           // 1x1 layer: two workgroups fit a CU
     const int64_t strips = (int64_t)a->B * p.tiles_x;
     int64_t segs = (ncu + strips - 1) / strips;            // smallest count that gives >= ncu workgroups
     if (segs < 1) segs = 1;

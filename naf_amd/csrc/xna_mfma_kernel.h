@@ -23,6 +23,8 @@
 //   1/sum is applied in registers.  The MFMA contraction order over keys is a free permutation; the same
 //   (g, j) -> key slot map is used for P and V^T so no cross-lane movement of P is needed.
 #pragma once
+#include <stdlib.h>
+
 #include "naf_common.h"
 
 struct XnaMfmaParams {
@@ -426,12 +428,18 @@ struct XnaMfmaPlan {
 // staged whole-row stores for bf16 output when the tile count is even and the staging tiles still fit.
 inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
     static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
+    // tuning knob for A/B runs: NAF_XNA_STAGE=0 never stages, =1 stages whenever it fits
+    static const int force = [] { const char* e = getenv("NAF_XNA_STAGE"); return e ? atoi(e) : -1; }();
     for (int c : cand) {
         if (Dv % c) continue;
         const bool can_stage = (out_dtype == NAF_BF16) && (c % 32 == 0);
         for (int cb = xna_mfma_cb(ks); cb >= 1; --cb) {
             for (int st = can_stage ? 1 : 0; st >= 0; --st) {
                 const size_t lds = xna_mfma_lds_for(ks, cb, c, st != 0);
+                // staging must not push residency below 3 workgroups per CU when the unstaged kernel would
+                // keep more (G3, Dv = 256: 2 staged vs 4 unstaged workgroups/CU measured 0.73 vs 0.66 ms)
+                if (st && force == 0) continue;
+                if (st && force != 1 && 3 * lds > 160 * 1024 && 3 * xna_mfma_lds_for(ks, cb, c, false) <= 160 * 1024) continue;
                 if (lds <= 160 * 1024) {
                     pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->lds = lds;
                     return true;
