@@ -79,7 +79,7 @@ __device__ __forceinline__ void xna_store4(float* dst, f32x4_t v) { *reinterpret
 // ABL: ablation bits for tools/xna_probe.hip only (the library instantiates ABL = 0):
 //   1 no output stores, 2 no PV MFMAs / V reads, 4 no Q loads, 8 no K/V staging loads, 16 no QK MFMAs,
 //   64 narrow (8 B / lane) bf16 stores on the unstaged path
-template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4>
+template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4, int TPW = 1>
 __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p) {
     constexpr int NT = NW * 64;  // threads per workgroup
     using G = XnaGeom<KS, CB>;
@@ -134,17 +134,19 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     };
 
     // first tile's queries: issued before the window staging so their HBM latency hides under it
-    bf16x8_t qf[2];
-    {
-        const bf16_t* qp = q_ptr(wave);
+    // TPW tiles (16 queries each) are processed together by a wave: the K and V^T fragments read from LDS
+    // feed TPW MFMAs each, halving LDS traffic per FLOP at TPW = 2 (large windows are LDS/MFMA-bound).
+    bf16x8_t qf[TPW][2];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const bf16_t* qp = q_ptr(wave * TPW + u);
         if (!(ABL & 4)) {
-            qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-            qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+            qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+            qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
         } else {
-            qf[0] = qf[1] = bf16x8_t{};
+            qf[u][0] = qf[u][1] = bf16x8_t{};
         }
     }
-
 
     // ---- stage the K and V windows (L2 -> registers -> LDS).  Slots outside the grid (only possible for the
     // extra row / column of a CB = 2 window at the border) load a clamped cell; no query attends to them.
@@ -194,97 +196,119 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const int row = (blk * 16 + 15 < NSLOT) ? r : min(r, NSLOT - 1);
         return Vs + row * VROW + (col & 3) * 4;
     };
-    for (int tt = wave; tt < ttot; tt += NW) {
-        // prefetch the next tile's queries (clamped address when there is none)
-        bf16x8_t qn[2];
-        {
-            const bf16_t* qp = q_ptr(tt + NW);
+    for (int tb = wave * TPW; tb < ttot; tb += NW * TPW) {
+        // prefetch the next tiles' queries (clamped address when there is none)
+        bf16x8_t qn[TPW][2];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const bf16_t* qp = q_ptr(tb + NW * TPW + u);
             if (!(ABL & 4)) {
-                qn[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-                qn[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+                qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
             } else {
-                qn[0] = qn[1] = bf16x8_t{};
+                qn[u][0] = qn[u][1] = bf16x8_t{};
             }
         }
-        const int ci = tt / ntile, t = tt - ci * ntile;
-        const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
-        const int cy = cy0 + cyi, cx = cx0 + cxi;
-        // this cell's own window inside the staged (union) window
-        const int oy = (CB == 1) ? 0 : min(max(cy - KS / 2, 0), p.h - KS) - y0;
-        const int ox = (CB == 1) ? 0 : min(max(cx - KS / 2, 0), p.w - KS) - x0;
+        // per-tile bookkeeping: cell of the tile, its own window inside the staged (union) window
+        int cyv[TPW], cxv[TPW], tv[TPW], oyv[TPW], oxv[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tt = min(tb + u, ttot - 1);
+            const int ci = tt / ntile;
+            tv[u] = tt - ci * ntile;
+            const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
+            cyv[u] = cy0 + cyi;
+            cxv[u] = cx0 + cxi;
+            oyv[u] = (CB == 1) ? 0 : min(max(cyv[u] - KS / 2, 0), p.h - KS) - y0;
+            oxv[u] = (CB == 1) ? 0 : min(max(cxv[u] - KS / 2, 0), p.w - KS) - x0;
+        }
 
         // ---- S^T = K . Q^T ----
-        f32x4_t s[MT];
+        f32x4_t s[TPW][MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (!(ABL & 16)) {
                     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
                 } else {
-                    acc[ks] += (float)qf[ks][mt & 7];
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
                 }
             }
-            s[mt] = acc;
         }
 
         // ---- softmax over key slots (fp32) ----
-        float m = -INFINITY;
+        float inv[TPW];
+        bf16x8_t pf[TPW][KST];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int u = 0; u < TPW; ++u) {
+            float m = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (CB == 1) {
-                    if (mt * 16 + 15 >= NSLOT) {  // tile contains pad slots: mask them
-                        const bool valid = (mt * 16 + r + grp * 4) < NSLOT;
-                        s[mt][r] = valid ? s[mt][r] : -INFINITY;
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (CB == 1) {
+                        if (mt * 16 + 15 >= NSLOT) {  // tile contains pad slots: mask them
+                            const bool valid = (mt * 16 + r + grp * 4) < NSLOT;
+                            s[u][mt][r] = valid ? s[u][mt][r] : -INFINITY;
+                        }
+                    } else {
+                        const int sl = mt * 16 + grp * 4 + r;
+                        const int ry = sl / WS, rx = sl - ry * WS;
+                        const bool valid = ((unsigned)(ry - oyv[u]) < (unsigned)KS) && ((unsigned)(rx - oxv[u]) < (unsigned)KS) && (sl < NSLOT);
+                        s[u][mt][r] = valid ? s[u][mt][r] : -INFINITY;
                     }
-                } else {
-                    const int sl = mt * 16 + grp * 4 + r;
-                    const int ry = sl / WS, rx = sl - ry * WS;
-                    const bool valid = ((unsigned)(ry - oy) < (unsigned)KS) && ((unsigned)(rx - ox) < (unsigned)KS) && (sl < NSLOT);
-                    s[mt][r] = valid ? s[mt][r] : -INFINITY;
+                    m = fmaxf(m, s[u][mt][r]);
                 }
-                m = fmaxf(m, s[mt][r]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float sum = 0.f;
-        const float mc = m * p.scale_log2e;
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float sum = 0.f;
+            const float mc = m * p.scale_log2e;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2e, -mc));
-                s[mt][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-
-        // ---- pack P to bf16 B-fragments: k index (g, j) <-> slot ks*32 + (j>>2)*16 + g*4 + (j&3) ----
-        bf16x8_t pf[KST];
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[u][mt][r], p.scale_log2e, -mc));
+                    s[u][mt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            inv[u] = 1.0f / sum;
+            // pack P to bf16 B-fragments: k index (g, j) <-> slot ks*32 + (j>>2)*16 + g*4 + (j&3)
 #pragma unroll
-        for (int ks = 0; ks < KST; ++ks)
+            for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16_t)s[2 * ks + (j >> 2)][j & 3];
+                for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
+        }
 
         // ---- O^T = V^T . P^T, normalise, store ----
-        const int ps = t * 16 + col;
-        const bool pvalid = ps < npix;
-        const int psc = min(ps, npix - 1);
-        const int py = psc / p.dx, px = psc - py * p.dx;
-        OutT* ob = obb + (int64_t)(cy * p.dy) * p.os[2] + (int64_t)(cx * p.dx) * p.os[3];
-        OutT* op = ob + py * p.os[2] + px * p.os[3];
-        auto pv_tile = [&](int ct) -> f32x4_t {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        OutT* obv[TPW];
+        OutT* opv[TPW];
+        bool pvalidv[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int ps = tv[u] * 16 + col;
+            pvalidv[u] = (ps < npix) && (tb + u < ttot);
+            const int psc = min(ps, npix - 1);
+            const int py = psc / p.dx, px = psc - py * p.dx;
+            obv[u] = obb + (int64_t)(cyv[u] * p.dy) * p.os[2] + (int64_t)(cxv[u] * p.dx) * p.os[3];
+            opv[u] = obv[u] + py * p.os[2] + px * p.os[3];
+        }
+        // one 16-channel tile of every query tile: V^T fragments are read once and feed TPW MFMAs
+        auto pv_tile = [&](int ct, f32x4_t (&acc)[TPW]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 if (ABL & 2) {
-                    acc[ks & 3] += (float)pf[ks][ct & 7];
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) acc[u][ks & 3] += (float)pf[u][ks][ct & 7];
                     continue;
                 }
                 const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
@@ -292,25 +316,29 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 bf16x8_t a;
                 a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
                 a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[u][ks], acc[u], 0, 0, 0);
             }
-            return acc * inv;
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) acc[u] *= inv[u];
         };
         if constexpr (STG) {
-            // bf16, whole-row stores: the wave's 16 px x DVT result goes through its private LDS tile and
+            // bf16, whole-row stores: a tile's 16 px x DVT result goes through the wave's private LDS tile and
             // leaves as 16-byte chunks in memory order, so one store instruction writes 1 KiB made of
             // DVT*2-byte contiguous runs (full 128-byte lines) instead of 64 scattered 16-byte pieces.
-            static_assert(sizeof(OutT) == 2 && (CT % 2) == 0, "staged stores: bf16, even tile count");
+            static_assert(sizeof(OutT) == 2 && (CT % 2) == 0 && TPW == 1, "staged stores: bf16, even tile count, one tile");
             bf16_t* ow = Os + wave * 16 * OROW;
             bf16_t* owl = ow + col * OROW + (grp & 1) * 16 + (grp >> 1) * 8;
 #pragma unroll
             for (int ct = 0; ct < CT; ct += 2) {
-                const f32x4_t a = pv_tile(ct), bq = pv_tile(ct + 1);
+                f32x4_t a[TPW], bq[TPW];
+                pv_tile(ct, a);
+                pv_tile(ct + 1, bq);
                 bf16x4_t ab, bb;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ab[i] = (bf16_t)a[i];
-                    bb[i] = (bf16_t)bq[i];
+                    ab[i] = (bf16_t)a[0][i];
+                    bb[i] = (bf16_t)bq[0][i];
                 }
                 const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
                 const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             }
             constexpr int NCH = 16 * VCH;  // 16-byte chunks in the tile
             const bool rowrun = (p.dx & 15) == 0;  // a tile is 16 consecutive pixels of one row
-            const int t0 = t * 16;
+            const int t0 = tv[0] * 16;
             const int ty = rowrun ? t0 / p.dx : 0, tx0 = rowrun ? t0 - ty * p.dx : 0;
 #pragma unroll
             for (int it = 0; it < (NCH + 63) / 64; ++it) {
@@ -339,63 +367,69 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     if (ABL & 1) {
                         asm volatile("" ::"v"(wv));
                     } else if (t0 + pp < npix) {
-                        *reinterpret_cast<u32x4_t*>(ob + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
+                        *reinterpret_cast<u32x4_t*>(obv[0] + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
                     }
                 }
             }
-            qf[0] = qn[0];
-            qf[1] = qn[1];
-            continue;
-        }
-        constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
-        constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
-        if constexpr (kWide) {
-            // bf16: lane (px, g) holds channels g*4..g*4+3 of a 16-channel tile (8 B).  Exchange halves
-            // between the lane pairs (g, g^1) of two adjacent tiles with v_permlane16_swap so that every
-            // lane owns 8 consecutive channels -> one 16-byte store, 64 contiguous bytes per pixel.
-            OutT* opw = op + (grp & 1) * 16 + (grp >> 1) * 8;
+        } else {
+            constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
+            constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
+            if constexpr (kWide) {
+                // bf16: lane (px, g) holds channels g*4..g*4+3 of a 16-channel tile (8 B).  Exchange halves
+                // between the lane pairs (g, g^1) of two adjacent tiles with v_permlane16_swap so that every
+                // lane owns 8 consecutive channels -> one 16-byte store, 64 contiguous bytes per pixel.
 #pragma unroll
-            for (int ct = 0; ct < CTP; ct += 2) {
-                const f32x4_t a = pv_tile(ct), bq = pv_tile(ct + 1);
-                bf16x4_t ab, bb;
+                for (int ct = 0; ct < CTP; ct += 2) {
+                    f32x4_t a[TPW], bq[TPW];
+                    pv_tile(ct, a);
+                    pv_tile(ct + 1, bq);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ab[i] = (bf16_t)a[i];
-                    bb[i] = (bf16_t)bq[i];
+                    for (int u = 0; u < TPW; ++u) {
+                        bf16x4_t ab, bb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ab[i] = (bf16_t)a[u][i];
+                            bb[i] = (bf16_t)bq[u][i];
+                        }
+                        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                        const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
+                        if (ABL & 1) {
+                            asm volatile("" ::"v"(wv));
+                        } else if (pvalidv[u]) {
+                            *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = wv;
+                        }
+                    }
                 }
-                const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
-                const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
-                if (ABL & 1) {
-                    asm volatile("" ::"v"(wv));
-                } else if (pvalid) {
-                    if (ABL & 32)
-                        __builtin_nontemporal_store(wv, reinterpret_cast<u32x4_t*>(opw + ct * 16));
-                    else
-                        *reinterpret_cast<u32x4_t*>(opw + ct * 16) = wv;
+            }
+#pragma unroll
+            for (int ct = CTP; ct < CT; ++ct) {
+                f32x4_t acc[TPW];
+                pv_tile(ct, acc);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    if (ABL & 1) {
+                        asm volatile("" ::"v"(acc[u]));
+                    } else if (pvalidv[u]) {
+                        xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int ct = CTP; ct < CT; ++ct) {
-            const f32x4_t acc = pv_tile(ct);
-            if (ABL & 1) {
-                asm volatile("" ::"v"(acc));
-            } else if (pvalid) {
-                xna_store4(op + grp * 4 + ct * 16, acc);
-            }
+        for (int u = 0; u < TPW; ++u) {
+            qf[u][0] = qn[u][0];
+            qf[u][1] = qn[u][1];
         }
-        qf[0] = qn[0];
-        qf[1] = qn[1];
     }
 }
 
-template <int KS, int DVT, typename OutT, bool STG, int CB>
+template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4>
 static int xna_mfma_launch_one(const XnaMfmaParams& p, hipStream_t s) {
-    constexpr size_t lds = xna_mfma_lds_bytes<KS, CB, DVT, STG>();
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, CB, DVT, STG, NW>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_mfma_kernel<KS, DVT, OutT, STG, CB>;
+    auto kern = xna_mfma_kernel<KS, DVT, OutT, STG, CB, 0, NW, TPW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -404,7 +438,7 @@ static int xna_mfma_launch_one(const XnaMfmaParams& p, hipStream_t s) {
             return NAF_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(NW * 64), lds, s, p);
     return naf_check_launch("xna_mfma_kernel");
 }
 
@@ -421,8 +455,17 @@ struct XnaMfmaPlan {
     int dvt;      // Dv tile (channels per workgroup)
     int cb;       // cells per workgroup edge
     bool staged;  // whole-row stores through LDS (bf16 output)
+    int tpw;      // 16-query tiles a wave processes together (2: K / V^T fragments feed two MFMAs each)
     size_t lds;
 };
+
+// Windows of 11x11 and up are LDS/MFMA-bound (G2, k = 11 / 15): pair the tiles.  Smaller windows are HBM-bound
+// and prefer the staged whole-row stores (one tile at a time).
+constexpr int xna_mfma_tpw(int ks) { return ks >= 11 ? 2 : 1; }
+// Workgroups whose windows fill more than half the LDS run alone on a CU: give them 8 waves (2 per SIMD).
+constexpr int xna_mfma_nw(int ks, int cb, int dvt, bool staged) {
+    return (!staged && xna_mfma_lds_for(ks, cb, dvt, false) > 80 * 1024) ? 8 : 4;
+}
 
 // The largest Dv tile that divides Dv and fits 160 KiB; 2x2 cell blocks when free (KS = 7, 15) and they fit;
 // staged whole-row stores for bf16 output when the tile count is even and the staging tiles still fit.
@@ -432,7 +475,8 @@ inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
     static const int force = [] { const char* e = getenv("NAF_XNA_STAGE"); return e ? atoi(e) : -1; }();
     for (int c : cand) {
         if (Dv % c) continue;
-        const bool can_stage = (out_dtype == NAF_BF16) && (c % 32 == 0);
+        const int tpw = xna_mfma_tpw(ks);
+        const bool can_stage = (out_dtype == NAF_BF16) && (c % 32 == 0) && tpw == 1;
         for (int cb = xna_mfma_cb(ks); cb >= 1; --cb) {
             for (int st = can_stage ? 1 : 0; st >= 0; --st) {
                 const size_t lds = xna_mfma_lds_for(ks, cb, c, st != 0);
@@ -441,7 +485,7 @@ inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
                 if (st && force == 0) continue;
                 if (st && force != 1 && 3 * lds > 160 * 1024 && 3 * xna_mfma_lds_for(ks, cb, c, false) <= 160 * 1024) continue;
                 if (lds <= 160 * 1024) {
-                    pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->lds = lds;
+                    pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->tpw = tpw; pl->lds = lds;
                     return true;
                 }
             }
@@ -454,8 +498,9 @@ template <int KS>
 static int xna_mfma_launch_ks(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s) {
     constexpr int CBM = xna_mfma_cb(KS);
 #define NAF_TRY(D, ST, CBV, T)                                                              \
-    if constexpr (xna_mfma_lds_for(KS, CBV, D, ST) <= 160 * 1024 && (!(ST) || (D % 32 == 0))) \
-        if (pl.dvt == D && pl.staged == ST && pl.cb == CBV) return xna_mfma_launch_one<KS, D, T, ST, CBV>(p, s);
+    if constexpr (xna_mfma_lds_for(KS, CBV, D, ST) <= 160 * 1024 && (!(ST) || ((D % 32 == 0) && xna_mfma_tpw(KS) == 1))) \
+        if (pl.dvt == D && pl.staged == ST && pl.cb == CBV)                                     \
+            return xna_mfma_launch_one<KS, D, T, ST, CBV, xna_mfma_tpw(KS), xna_mfma_nw(KS, CBV, D, ST)>(p, s);
 #define NAF_CASE(D)                                   \
     if (out_dtype == NAF_BF16) {                      \
         NAF_TRY(D, true, CBM, bf16_t)                 \

@@ -85,10 +85,10 @@ void run_pattern(const XnaMfmaParams& p, int reps, const char* name, double byte
     printf("%-44s %8.4f ms  %8.1f GB/s\n", name, ms, bytes / ms / 1e6);
 }
 
-template <int ABL, bool STG = true, int CB = 1, int NW = 4>
+template <int ABL, bool STG = true, int CB = 1, int NW = 4, int TPW = 1>
 float run(XnaMfmaParams p, int reps, const char* name, double bytes) {
     constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, CB, PROBE_DVT, STG, NW>();
-    auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, STG, CB, ABL, NW>;
+    auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, STG, CB, ABL, NW, TPW>;
     p.nblocks = (uint32_t)(p.B * ((p.h + CB - 1) / CB) * ((p.w + CB - 1) / CB) * p.heads * p.nchunk);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b;
@@ -177,6 +177,7 @@ int main(int argc, char** argv) {
     run<1 | 4>(p, reps, "no Q loads, no stores (compute only)", bytes);
     run<1 | 4 | 8>(p, reps, "compute only, no staging", bytes);
     run<0, false, 1, 4>(p, reps, "4 waves, unstaged stores", bytes);
+    run<0, false, 1, 4, 2>(p, reps, "4 waves, unstaged, 2 tiles per wave", bytes);
     run<0, true, 1, 8>(p, reps, "8 waves, staged stores", bytes);
     run<0, false, 1, 8>(p, reps, "8 waves, unstaged stores", bytes);
     run<0, true, 2, 4>(p, reps, "2x2 cells, 4 waves, staged", bytes);
