@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
 
     const T* xb = reinterpret_cast<const T*>(p.x) + b * p.xs[0];
     if (active) {
+#pragma unroll 4
         for (int pi = plane; pi < npix; pi += nplanes) {
             const int py = pi / wx, px = pi - py * wx;
             const int y = ys + py, x = xs + px;
@@ -128,13 +129,29 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
             float v1[VEC], v2[VEC], cs[VEC], sn[VEC];
             load_vec<T, VEC>(xp + (int64_t)c1 * p.xs[1], p.xs[1], v1);
             load_vec<T, VEC>(xp + (int64_t)(c1 + half) * p.xs[1], p.xs[1], v2);
+            if constexpr (VEC == 8) {
+                // Dh % 32 == 0: the 8 angle indices t0..t0+7 are all row angles or all column angles ->
+                // four 16-byte table loads instead of sixteen scalar ones
+                const float* tb = (t0 < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + t0)
+                                                 : (p.tab_x + (int64_t)x * 2 * quarter + (t0 - quarter));
+                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(tb), c1v = *reinterpret_cast<const f32x4_t*>(tb + 4);
+                const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(tb + quarter), s1v = *reinterpret_cast<const f32x4_t*>(tb + quarter + 4);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const int a = t0 + i;
-                const float* tb = (a < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + a)
-                                                : (p.tab_x + (int64_t)x * 2 * quarter + (a - quarter));
-                cs[i] = tb[0];
-                sn[i] = tb[quarter];
+                for (int i = 0; i < 4; ++i) {
+                    cs[i] = c0[i];
+                    cs[4 + i] = c1v[i];
+                    sn[i] = s0[i];
+                    sn[4 + i] = s1v[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int a = t0 + i;
+                    const float* tb = (a < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + a)
+                                                    : (p.tab_x + (int64_t)x * 2 * quarter + (a - quarter));
+                    cs[i] = tb[0];
+                    sn[i] = tb[quarter];
+                }
             }
             float o1[VEC], o2[VEC];
 #pragma unroll
