@@ -39,6 +39,7 @@ int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, i
 
 int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);            // stem_conv0.hip
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s);              // stem_conv.hip
+int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s);           // stem_conv1x1.hip
 
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }

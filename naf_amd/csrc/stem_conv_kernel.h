@@ -113,13 +113,13 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     __syncthreads();
 
     // GroupNorm scale / shift of this thread's 8 input channels (3x3 schedule keeps them in registers)
-    float ga[8], gb[8], ga2[8], gb2[8];  // y = x*ga + gb ; -log2(e)*y = x*ga2 + gb2
+    f32x2_t gav[4], gbv[4], ga2v[4], gb2v[4];  // channel pairs: y = x*ga + gb ; -log2(e)*y = x*ga2 + gb2
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        ga[e] = cvec[C + chunk * 8 + e];
-        gb[e] = cvec[2 * C + chunk * 8 + e];
-        ga2[e] = ga[e] * -1.4426950408889634f;
-        gb2[e] = gb[e] * -1.4426950408889634f;
+    for (int e = 0; e < 4; ++e) {
+        gav[e] = f32x2_t{cvec[C + chunk * 8 + 2 * e], cvec[C + chunk * 8 + 2 * e + 1]};
+        gbv[e] = f32x2_t{cvec[2 * C + chunk * 8 + 2 * e], cvec[2 * C + chunk * 8 + 2 * e + 1]};
+        ga2v[e] = gav[e] * -1.4426950408889634f;
+        gb2v[e] = gbv[e] * -1.4426950408889634f;
     }
     const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
     bf16_t* yb = p.y + (int64_t)b * p.ys[0] + chunk * 8;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
 #pragma unroll
     for (int n = 0; n < NLD; ++n) issue_one(PRE, n);
 
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    f32x2_t s1p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}}, s2p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};  // GroupNorm sums (pairs)
     long long tmacc[3] = {0, 0, 0};  // probe only (ABL & 128): cycles in MFMA block / epilogue / barrier
     const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before tap shift)
 
@@ -228,17 +228,18 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
                 return;
             }
             const int orow = sy + step * RS + g;
-            const bool valid = !EDGE || ((orow < sy_end) && (sx + n32 < p.W));
+            const float vmask = (!EDGE || ((orow < sy_end) && (sx + n32 < p.W))) ? 1.0f : 0.0f;
             const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
+            f32x2_t v0 = f32x2_t{acc[g][j * 4], acc[g][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
+            f32x2_t v1 = f32x2_t{acc[g][j * 4 + 2], acc[g][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
             bf16x4_t o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = acc[g][j * 4 + i] + bj[i];
-                o[i] = (bf16_t)v;
-                const float vm = valid ? v : 0.f;
-                s1[j >> 1] += vm;
-                s2[j >> 1] = fmaf(vm, vm, s2[j >> 1]);
+            o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
+            if constexpr (EDGE) {
+                v0 = v0 * vmask;
+                v1 = v1 * vmask;
             }
+            s1p[j >> 1] += v0 + v1;
+            s2p[j >> 1] += v0 * v0 + v1 * v1;
             *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
         };
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
             };
             const bf16_t* next_row0 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS, p.H) * p.xs[1];
             const bf16_t* next_row1 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS + 1, p.H) * p.xs[1];
-            float cy0[8], cu0[8], cy1[8], cu1[8];
+            f32x2_t cy0[4], cu0[4], cy1[4], cu1[4];
             uint32_t co0[4], co1[4];
             u32x4_t stv = {0u, 0u, 0u, 0u};
 #define NAF_PIN1(a) asm volatile("" : "+v"(a))
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     if (p.stats_out) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            float a = s1[g], q = s2[g];
+            float a = s1p[g][0] + s1p[g][1], q = s2p[g][0] + s2p[g][1];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 a += __shfl_xor(a, o);

@@ -41,22 +41,19 @@ ops = [[] for _ in range(NSLOT)]
 def commit_ops(n, v):
     """GroupNorm affine + SiLU + bf16 of load piece n (8 channels of one ring pixel), variable set v.
     y = x*ga + gb ; u = x*ga2 + gb2 = -log2(e)*y ; out = y * rcp(1 + exp2(u))."""
-    cy, cu, co = f"cy{v}", f"cu{v}", f"co{v}"
+    cy, cu, co = f"cy{v}", f"cu{v}", f"co{v}"      # f32x2_t [4] pairs (v_pk_fma / v_pk_add / v_pk_mul)
     o = {}
     for p in range(4):
-        a, b = 2 * p, 2 * p + 1
-        o[f"A{p}"] = (f"{{ const uint32_t w_ = ld[{n}][{p}]; {cy}[{a}] = __uint_as_float(w_ << 16); "
-                      f"{cy}[{b}] = __uint_as_float(w_ & 0xffff0000u); NAF_PIN2({cy}[{a}], {cy}[{b}]); }}")
-        o[f"B{p}"] = (f"{{ const float x0_ = {cy}[{a}], x1_ = {cy}[{b}]; "
-                      f"{cy}[{a}] = fmaf(x0_, ga[{a}], gb[{a}]); {cy}[{b}] = fmaf(x1_, ga[{b}], gb[{b}]); "
-                      f"{cu}[{a}] = fmaf(x0_, ga2[{a}], gb2[{a}]); {cu}[{b}] = fmaf(x1_, ga2[{b}], gb2[{b}]); "
-                      f"NAF_PIN4({cy}[{a}], {cy}[{b}], {cu}[{a}], {cu}[{b}]); }}")
-        o[f"C{p}"] = (f"{{ {cu}[{a}] = __builtin_amdgcn_exp2f({cu}[{a}]); {cu}[{b}] = __builtin_amdgcn_exp2f({cu}[{b}]); "
-                      f"NAF_PIN2({cu}[{a}], {cu}[{b}]); }}")
-        o[f"D{p}"] = f"{{ {cu}[{a}] += 1.0f; {cu}[{b}] += 1.0f; NAF_PIN2({cu}[{a}], {cu}[{b}]); }}"
-        o[f"E{p}"] = (f"{{ {cu}[{a}] = __builtin_amdgcn_rcpf({cu}[{a}]); {cu}[{b}] = __builtin_amdgcn_rcpf({cu}[{b}]); "
-                      f"NAF_PIN2({cu}[{a}], {cu}[{b}]); }}")
-        o[f"F{p}"] = (f"{{ bf16x2_t o_; o_[0] = (bf16_t)({cy}[{a}] * {cu}[{a}]); o_[1] = (bf16_t)({cy}[{b}] * {cu}[{b}]); "
+        o[f"A{p}"] = (f"{{ const uint32_t w_ = ld[{n}][{p}]; {cy}[{p}] = f32x2_t{{__uint_as_float(w_ << 16), "
+                      f"__uint_as_float(w_ & 0xffff0000u)}}; NAF_PIN1({cy}[{p}]); }}")
+        o[f"B{p}"] = (f"{{ const f32x2_t x_ = {cy}[{p}]; {cy}[{p}] = x_ * gav[{p}] + gbv[{p}]; {cu}[{p}] = x_ * ga2v[{p}] + gb2v[{p}]; "
+                      f"NAF_PIN2({cy}[{p}], {cu}[{p}]); }}")
+        o[f"C{p}"] = (f"{{ {cu}[{p}] = f32x2_t{{__builtin_amdgcn_exp2f({cu}[{p}][0]), __builtin_amdgcn_exp2f({cu}[{p}][1])}}; "
+                      f"NAF_PIN1({cu}[{p}]); }}")
+        o[f"D{p}"] = f"{{ {cu}[{p}] = {cu}[{p}] + 1.0f; NAF_PIN1({cu}[{p}]); }}"
+        o[f"E{p}"] = (f"{{ {cu}[{p}] = f32x2_t{{__builtin_amdgcn_rcpf({cu}[{p}][0]), __builtin_amdgcn_rcpf({cu}[{p}][1])}}; "
+                      f"NAF_PIN1({cu}[{p}]); }}")
+        o[f"F{p}"] = (f"{{ const f32x2_t r_ = {cy}[{p}] * {cu}[{p}]; bf16x2_t o_; o_[0] = (bf16_t)r_[0]; o_[1] = (bf16_t)r_[1]; "
                       f"{co}[{p}] = __builtin_bit_cast(uint32_t, o_); NAF_PIN1({co}[{p}]); }}")
     o["G"] = (f"*reinterpret_cast<u32x4_t*>(ring + (commit_slot + c_rr[{n}]) * ROWE + c_pxoff[{n}]) = "
               f"u32x4_t{{{co}[0], {co}[1], {co}[2], {co}[3]}};")
