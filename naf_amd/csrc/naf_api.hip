@@ -120,9 +120,8 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     NAF_REQUIRE(al16(a->x) && al16(a->y) && al16(a->w_packed), "naf_stem_conv_fwd: tensors must be 16-byte aligned");
     for (int i = 0; i < 3; ++i)
         NAF_REQUIRE(a->x_stride[i] % 8 == 0 && a->y_stride[i] % 8 == 0, "naf_stem_conv_fwd: strides must be multiples of 8 elements");
-    // 1x1 layers are HBM-bound: independent-wave kernel; NAF_STEM_1X1=strip selects the strip kernel (A/B runs)
-    static const bool strip1 = [] { const char* e = getenv("NAF_STEM_1X1"); return e && !strcmp(e, "strip"); }();
-    if (a->ksize == 1 && !strip1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream));
+    // 1x1 layers are HBM-bound (independent-wave kernel); 3x3 layers are MFMA-bound (weight-stationary strips)
+    if (a->ksize == 1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream));
 }
 

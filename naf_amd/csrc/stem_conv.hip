@@ -51,7 +51,6 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
     }
-    if (a->ksize == 1) ncu *= 2;                           // 1x1 layer: two workgroups fit a CU
     const int64_t strips = (int64_t)a->B * p.tiles_x;
     int64_t segs = (ncu + strips - 1) / strips;            // smallest count that gives >= ncu workgroups
     if (segs < 1) segs = 1;
@@ -66,14 +65,11 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         naf_set_error("naf_stem_conv_fwd: grid out of range");
         return NAF_ERR_INVALID;
     }
-    if (a->ksize == 3) {
-        const size_t lds = stem_conv_lds<3>();
-        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(stem_conv_kernel<3>, dim3((uint32_t)nb), dim3(256), lds, s, p);
-    } else {
-        const size_t lds = stem_conv_lds<1>();
-        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(stem_conv_kernel<1>, dim3((uint32_t)nb), dim3(256), lds, s, p);
+    const size_t lds = stem_conv_lds<3>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", lds);
+        return NAF_ERR_LAUNCH;
     }
+    hipLaunchKernelGGL(stem_conv_kernel<3>, dim3((uint32_t)nb), dim3(256), lds, s, p);
     return naf_check_launch("stem_conv_kernel");
 }

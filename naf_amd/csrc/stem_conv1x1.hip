@@ -231,7 +231,10 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
         naf_set_error("naf_stem_conv_fwd: batch %d out of range", a->B);
         return NAF_ERR_INVALID;
     }
-    hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", (size_t)lds);
+        return NAF_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(stem_conv1x1_kernel, dim3((uint32_t)nbx, (uint32_t)a->B), dim3(256), lds, s, p);
     return naf_check_launch("stem_conv1x1_kernel");
 }

@@ -61,7 +61,8 @@ struct StemGeom {
 // (bias, sums, LDS tile), 4 no LDS B-fragment reads (MFMA on stale registers), 8 no row stores, 16 no global loads,
 // 32 no per-step barrier, 64 no per-slot scheduling pins
 template <int KS, int ABL = 0>
-__global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const StemConvParams p) {
+__global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams p) {
+    static_assert(KS == 3, "the 1x1 layers have their own kernel (stem_conv1x1.hip)");
     using G = StemGeom<KS>;
     constexpr int HALO = G::HALO, PXR = G::PXR, NROW = G::NROW, RING = G::RING, ROWE = G::ROWE;
     constexpr int NLD = G::NLD, NST = G::NST, TAPS = G::TAPS, KH = G::KH, NSETS = G::NSETS, PRE = G::PRE;
@@ -84,16 +85,6 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     const int sy_end = min(p.H, sy + p.seg_h);
     const int nstep = (sy_end - sy + RS - 1) / RS;
 
-    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
-    bf16x8_t wreg[TAPS * 8];
-    {
-        const bf16_t* wp = p.w + (size_t)(wave * 32 + n32) * C + half * 8;
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
-    }
     // per-channel vectors in LDS (kept out of the register file, which the weights fill):
     //   cvec[0][c] conv bias, cvec[1][c] / cvec[2][c] GroupNorm scale / shift of the INPUT channel c
     const int chunk = tid & 15, pl = tid >> 4;
@@ -121,41 +112,39 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
         ga2v[e] = gav[e] * -1.4426950408889634f;
         gb2v[e] = gbv[e] * -1.4426950408889634f;
     }
-    const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
-    bf16_t* yb = p.y + (int64_t)b * p.ys[0] + chunk * 8;
+    // Addressing: wave-uniform 64-bit row bases (SGPR) + per-lane 32-bit byte offsets inside a row, so that a
+    // load / store is one global instruction with no per-lane 64-bit arithmetic and half the registers.
+    const char* xbu = reinterpret_cast<const char*>(p.x + (int64_t)b * p.xs[0]);
+    char* ybu = reinterpret_cast<char*>(p.y + (int64_t)b * p.ys[0]);
 
     // Loads.  Piece n of a batch is ring pixel (rr, px) = divmod(pl + 16 n, PXR); its image column is
     // fixed for the whole kernel (reflect padding = coordinate map), only the row advances.  Pieces past
     // the pixels the MFMAs read are padding: they load a clamped pixel and are never consumed, which
     // keeps every piece unconditional (no per-lane branch in the step body).
-    int64_t col_off[NLD];
-#pragma unroll
-    for (int n = 0; n < NLD; ++n) {
-        const int px = (pl + 16 * n) % PXR;
-        col_off[n] = (int64_t)reflect(sx - HALO + px, p.W) * p.xs[2];
-    }
-    // per-piece constants of the 3x3 schedule: ring row (0/1) and in-row LDS offset of load piece n;
-    // LDS offset and global offset (relative to the tile's first row) of store piece n
-    int c_rr[NLD], c_pxoff[NLD], st_lds[NST];
-    int64_t st_goff[NST];
+    uint32_t col_off[NLD];   // bytes from the row base
+    int c_off[NLD];          // ring offset (elements) of piece n relative to the batch's first ring row
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
         const int i = pl + 16 * n;
-        c_rr[n] = i / PXR;
-        c_pxoff[n] = (i - c_rr[n] * PXR) * PXE + chunk * 8;
+        const int rr = i / PXR, px = i - rr * PXR;
+        col_off[n] = (uint32_t)(reflect(sx - HALO + px, p.W) * (int)p.xs[2] + chunk * 8) * 2u;
+        c_off[n] = rr * ROWE + px * PXE + chunk * 8;
     }
+    // store piece n: LDS offset in the output tile, byte offset from its row base (row = (16 n) / TW)
+    int st_lds[NST];
+    uint32_t st_goff[NST];
 #pragma unroll
     for (int n = 0; n < NST; ++n) {
         const int opx = pl + 16 * n;
-        const int g = opx / TW, px = opx - g * TW;
+        const int px = opx % TW;
         st_lds[n] = opx * PXE + chunk * 8;
-        st_goff[n] = (int64_t)g * p.ys[1] + (int64_t)(sx + px) * p.ys[2];
+        st_goff[n] = (uint32_t)((sx + px) * (int)p.ys[2] + chunk * 8) * 2u;
     }
     u32x4_t ld[NLD];
     auto issue_one = [&](int batch, int n) __attribute__((always_inline)) {
         const int rr = (pl + 16 * n) / PXR;
         const int row = reflect(sy - HALO + batch * RS + rr, p.H);
-        ld[n] = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)row * p.xs[1] + col_off[n]);
+        ld[n] = *reinterpret_cast<const u32x4_t*>(xbu + (int64_t)row * p.xs[1] * 2 + col_off[n]);
     };
     // GroupNorm affine + SiLU + bf16, into ring slot (input row index % RING)
     auto commit_one = [&](int batch, int n) __attribute__((always_inline)) {
@@ -184,7 +173,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
         const int orow = sy + st * RS + g;
         if (!decltype(edge)::value || (orow < sy_end && sx + px < p.W)) {
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ot + opx * PXE + chunk * 8);
-            *reinterpret_cast<u32x4_t*>(yb + (int64_t)orow * p.ys[1] + (int64_t)(sx + px) * p.ys[2]) = v;
+            *reinterpret_cast<u32x4_t*>(ybu + (int64_t)orow * p.ys[1] * 2 + st_goff[n]) = v;
         }
     };
 
@@ -197,6 +186,20 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
         for (int n = 0; n < NLD; ++n) commit_one(k, n);
     }
     __syncthreads();
+    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
+    // (after the prologue: loaded earlier, the compiler spilled ~70 of these registers around the prologue's
+    //  GroupNorm/SiLU code and reloaded them -- 38 MB of scratch traffic per launch)
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t wreg[TAPS * 8];
+    {
+        const bf16_t* wp = p.w + (size_t)(wave * 32 + n32) * C + half * 8;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NLD; ++n) issue_one(PRE, n);
 
@@ -204,12 +207,14 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     long long tmacc[3] = {0, 0, 0};  // probe only (ABL & 128): cycles in MFMA block / epilogue / barrier
     const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before tap shift)
 
-    // One step = RS output rows.  FIRST: no previous tile to store.  EDGE: per-lane validity checks.
-    // Rows past the segment are loaded (clamped by reflect) and committed but never used, so the body
-    // has no "is there a next step" branches: with FIRST = EDGE = false it is ONE basic block and the
-    // scheduler is free to sink the side work into the MFMA shadow.
-    auto step_body = [&](int step, auto first, auto edge) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first)::value, EDGE = decltype(edge)::value;
+    // One step = RS output rows.  EDGE: per-lane validity checks.  Rows past the segment are loaded (clamped
+    // by reflect) and committed but never used, and step 0 "stores" its not-yet-computed tile to the rows
+    // step 1 rewrites (same lanes, same addresses, program order), so the body has no "is there a
+    // previous / next step" branches: ONE basic block, one instance (a separate first-step instance of
+    // this body used to spill ~240 registers per lane).
+    auto step_body = [&](int step, auto edge) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge)::value;
+        const int pst = max(step - 1, 0);   // tile whose rows leave during this step
         f32x16_t acc[RS];
 #pragma unroll
         for (int g = 0; g < RS; ++g) {
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
         load_set(0, bb[0]);
         long long tm0 = 0;
         if constexpr ((ABL & 128) != 0) tm0 = __builtin_readcyclecounter();
-        if constexpr (KS == 3) {
+        {
             // Hand-placed schedule, generated by tools/gen_stem_sched.py: 144 MFMA slots; GroupNorm+SiLU of
             // the next rows, row stores of the previous tile, loads two steps ahead and the epilogue of
             // output row 0 are cut into micro-ops of a few independent instructions and pinned behind
@@ -263,14 +268,15 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
             static_assert(NLD == 5 && NST == 4 && NSETS == 24 && KH == 4 && RS == 2 && RING == 6, "schedule geometry");
             const int commit_slot = ((step + PRE) * RS) % RING;
             const bf16_t* prev_tile = otile + ((step - 1) & 1) * (RS * TW * PXE);
-            bf16_t* prev_rows = yb + (int64_t)(sy + (step - 1) * RS) * p.ys[1];
+            char* prev_row0 = ybu + (int64_t)(sy + pst * RS) * p.ys[1] * 2;   // uniform
+            char* prev_row1 = prev_row0 + p.ys[1] * 2;
             auto st_ok = [&](int st, int n) __attribute__((always_inline)) {
                 const int opx = pl + 16 * n;
                 const int g = opx / TW, px = opx - g * TW;
                 return (sy + st * RS + g < sy_end) && (sx + px < p.W);
             };
-            const bf16_t* next_row0 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS, p.H) * p.xs[1];
-            const bf16_t* next_row1 = xb + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS + 1, p.H) * p.xs[1];
+            const char* next_row0 = xbu + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS, p.H) * p.xs[1] * 2;   // uniform
+            const char* next_row1 = xbu + (int64_t)reflect(sy - HALO + (step + 1 + PRE) * RS + 1, p.H) * p.xs[1] * 2;
             f32x2_t cy0[4], cu0[4], cy1[4], cu1[4];
             uint32_t co0[4], co1[4];
             u32x4_t stv = {0u, 0u, 0u, 0u};
@@ -299,38 +305,6 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
                 tmacc[2] += tm3 - tm2;
                 return;
             }
-        } else {
-#pragma unroll
-            for (int sidx = 0; sidx < NSETS; ++sidx) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (sidx + 1 < NSETS) load_set(sidx + 1, bb[(sidx + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const int rt = sidx / (8 / KH), kh = sidx - rt * (8 / KH);
-                const int i = rt / KS, dx = rt - i * KS;
-#pragma unroll
-                for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-                    for (int g = 0; g < RS; ++g) {
-                        const int dy = i - g;
-                        if (dy >= 0 && dy < KS)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(dy * KS + dx) * 8 + kh * KH + ks],
-                                                                             bb[sidx & 1][ks], acc[g], 0, 0, 0);
-                    }
-                }
-            }
-            // 1x1 (HBM-bound): too few MFMAs to hide anything behind; plain order
-#pragma unroll
-            for (int n = 0; n < NLD; ++n) commit_one(step + PRE, n);
-            if constexpr (!FIRST) {
-#pragma unroll
-                for (int n = 0; n < NST; ++n) store_one(step - 1, n, edge);
-            }
-#pragma unroll
-            for (int n = 0; n < NLD; ++n) issue_one(step + 1 + PRE, n);
-#pragma unroll
-            for (int g = 0; g < RS; ++g)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) epi(g, j);
         }
         if (!(ABL & 32)) __syncthreads();
     };
@@ -339,13 +313,11 @@ __global__ __launch_bounds__(256, (KS == 1 ? 2 : 1)) void stem_conv_kernel(const
     using F = std::false_type;
     const bool edge = (sx + TW > p.W) || ((sy_end - sy) % RS != 0);
     if (!edge) {
-        step_body(0, T{}, F{});
-        for (int step = 1; step < nstep; ++step) step_body(step, F{}, F{});
+        for (int step = 0; step < nstep; ++step) step_body(step, F{});
 #pragma unroll
         for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, F{});
     } else {
-        step_body(0, T{}, T{});
-        for (int step = 1; step < nstep; ++step) step_body(step, F{}, T{});
+        for (int step = 0; step < nstep; ++step) step_body(step, T{});
 #pragma unroll
         for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, T{});
     }

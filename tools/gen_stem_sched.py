@@ -19,6 +19,7 @@ import os
 
 KS, RS, KH, NROW = 3, 2, 4, 4
 NLD, NST = 5, 4
+TW, PXR = 32, 40
 NSETS = NROW * KS * (8 // KH)
 
 # ---- slots --------------------------------------------------------------------------------------
@@ -55,7 +56,7 @@ def commit_ops(n, v):
                       f"NAF_PIN1({cu}[{p}]); }}")
         o[f"F{p}"] = (f"{{ const f32x2_t r_ = {cy}[{p}] * {cu}[{p}]; bf16x2_t o_; o_[0] = (bf16_t)r_[0]; o_[1] = (bf16_t)r_[1]; "
                       f"{co}[{p}] = __builtin_bit_cast(uint32_t, o_); NAF_PIN1({co}[{p}]); }}")
-    o["G"] = (f"*reinterpret_cast<u32x4_t*>(ring + (commit_slot + c_rr[{n}]) * ROWE + c_pxoff[{n}]) = "
+    o["G"] = (f"*reinterpret_cast<u32x4_t*>(ring + commit_slot * ROWE + c_off[{n}]) = "
               f"u32x4_t{{{co}[0], {co}[1], {co}[2], {co}[3]}};")
     return o
 
@@ -76,12 +77,14 @@ ST_BASE = 60
 assert ST_BASE > last_commit_read
 for n in range(NST):
     ops[ST_BASE + 3 * n].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
-    ops[ST_BASE + 3 * n + 2].append(("store", f"if (!EDGE || st_ok(step - 1, {n})) *reinterpret_cast<u32x4_t*>(prev_rows + st_goff[{n}]) = stv;"))
+    ops[ST_BASE + 3 * n + 2].append(("store", f"if (!EDGE || st_ok(pst, {n})) *reinterpret_cast<u32x4_t*>(prev_row{16 * n // TW} + st_goff[{n}]) = stv;"))
 
 # global loads for the step after next (ld[n] was consumed by A-stages before slot 60)
 LD_BASE = ST_BASE + 3 * NST + 2
 for n in range(NLD):
-    ops[LD_BASE + 2 * n].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>((c_rr[{n}] ? next_row1 : next_row0) + col_off[{n}]);"))
+    r_lo, r_hi = (16 * n) // PXR, (16 * n + 15) // PXR
+    base = f"next_row{r_lo}" if r_lo == r_hi else f"(pl + {16 * n} >= {PXR} ? next_row1 : next_row0)"
+    ops[LD_BASE + 2 * n].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>({base} + col_off[{n}]);"))
 
 # epilogue of output row 0: its accumulator is final once input row 2 is done (slot 119)
 first_row3 = next(k for k, s in enumerate(slots) if s[0] >= 18)
@@ -104,7 +107,7 @@ for k, (sidx, ks, g, dy, dx, kh, first) in enumerate(slots):
     out.append(f"acc[{g}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[{widx}], bb[{sidx & 1}][{ks}], acc[{g}], 0, 0, 0);  // slot {k}")
     for kind, code in ops[k]:
         if kind == "store":
-            out.append(f"if constexpr (!(ABL & 8) && !FIRST) {{ {code} }}")
+            out.append(f"if constexpr (!(ABL & 8)) {{ {code} }}")
         elif kind == "epi":
             out.append(code)
         elif kind == "load":

@@ -77,7 +77,6 @@ int main(int argc, char** argv) {
         }
         run<3, 59 + 64>(p, nb, reps, "LDS reads + MFMA, no slot pins", px * 2 * 1152 * 128, by);
         run<3, 64>(p, nb, reps, "full, no slot pins", px * 2 * 1152 * 128, by);
-        run<1, 0>(p, nb, reps, "full", px * 2 * 128 * 128, by);
         if (segs_in > 0) break;
     }
     return 0;
