@@ -19,6 +19,10 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libnaf_hip.so")
 ARCH = "gfx950"
+# MFMA results in VGPRs (no v_accvgpr_read per result register) wherever the kernel does not need the AGPR half
+# of the register file; the weight-stationary 3x3 stem layer fills all 512 registers and keeps the default.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+NO_VGPR_FORM = {"stem_conv.hip"}
 
 
 def _hipcc() -> str:
@@ -45,7 +49,7 @@ def _compile(src: str, force: bool, hdr_mtime: float, extra) -> str:
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(spath), hdr_mtime):
         return obj
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", *extra, "-c", spath, "-o", obj]
+           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", *([] if src in NO_VGPR_FORM else VGPR_FORM), *extra, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

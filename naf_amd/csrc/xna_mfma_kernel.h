@@ -25,6 +25,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "naf_common.h"
 
 struct XnaMfmaParams {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping runs on the SALU
     const int col = lane & 15;  // MFMA column index (query within tile) / A-row index (key or channel)
     const int grp = lane >> 4;  // MFMA k-group / result row group
 
@@ -131,6 +133,20 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const int ps = min(t * 16 + col, npix - 1);
         const int py = ps / p.dx, px = ps - py * p.dx;
         return qbb + (int64_t)((cy0 + cyi) * p.dy + py) * p.qs[2] + (int64_t)((cx0 + cxi) * p.dx + px) * p.qs[3] + grp * 8;
+    };
+
+    // FAST path (see tile_loop): tiles per cell row, magic multiplier for t / tpr (exact for t, tpr <= 1024),
+    // uniform cell origins, per-lane byte offset of this lane's query inside a tile
+    const bool fast = (CB == 1) && ((p.dx & 15) == 0) && (ntile <= 1024);
+    const int tpr = max(p.dx >> 4, 1);
+    const uint32_t tmagic = (1u << 20) / (uint32_t)tpr + 1u;
+    const bf16_t* q_cell = qbb + (int64_t)(cy0 * p.dy) * p.qs[2] + (int64_t)(cx0 * p.dx) * p.qs[3];
+    OutT* o_cell = obb + (int64_t)(cy0 * p.dy) * p.os[2] + (int64_t)(cx0 * p.dx) * p.os[3];
+    const uint32_t q_lane = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u;
+    auto q_ptr_fast = [&](int tt) __attribute__((always_inline)) {
+        const int ttc = min(tt, ttot - 1);
+        const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
+        return reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(q_cell + (int64_t)ty * p.qs[2] + (int64_t)tx0 * p.qs[3]) + q_lane);
     };
 
     // first tile's queries: issued before the window staging so their HBM latency hides under it
@@ -196,233 +212,256 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const int row = (blk * 16 + 15 < NSLOT) ? r : min(r, NSLOT - 1);
         return Vs + row * VROW + (col & 3) * 4;
     };
-    for (int tb = wave * TPW; tb < ttot; tb += NW * TPW) {
-        // prefetch the next tiles' queries (clamped address when there is none)
-        bf16x8_t qn[TPW][2];
+    // store pieces of the staged path: 16-byte chunk i = it*64 + lane of the wave's [16 px][DVT] tile; its LDS
+    // offset and its byte offset from the tile's first pixel are per-lane constants of the whole kernel
+    constexpr int NCH = 16 * VCH;            // 16-byte chunks in a tile
+    constexpr int NIT = STG ? (NCH + 63) / 64 : 1;
+    int st_lds[NIT];
+    uint32_t st_goff[NIT];
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            const bf16_t* qp = q_ptr(tb + NW * TPW + u);
-            if (!(ABL & 4)) {
-                qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
-                qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-            } else {
-                qn[u][0] = qn[u][1] = bf16x8_t{};
-            }
-        }
-        // per-tile bookkeeping: cell of the tile, its own window inside the staged (union) window
-        int cyv[TPW], cxv[TPW], tv[TPW], oyv[TPW], oxv[TPW];
-#pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            const int tt = min(tb + u, ttot - 1);
-            const int ci = tt / ntile;
-            tv[u] = tt - ci * ntile;
-            const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
-            cyv[u] = cy0 + cyi;
-            cxv[u] = cx0 + cxi;
-            oyv[u] = (CB == 1) ? 0 : min(max(cyv[u] - KS / 2, 0), p.h - KS) - y0;
-            oxv[u] = (CB == 1) ? 0 : min(max(cxv[u] - KS / 2, 0), p.w - KS) - x0;
-        }
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(it * 64 + lane, NCH - 1);
+        const int pp = i / VCH, ch = i - pp * VCH;
+        st_lds[it] = pp * OROW + ch * 8;
+        st_goff[it] = (uint32_t)(pp * (int)p.os[3] + ch * 8) * (uint32_t)sizeof(OutT);
+    }
+    const uint32_t o_lane = (uint32_t)(col * (int)p.os[3]) * (uint32_t)sizeof(OutT);   // unstaged: this lane's pixel
 
-        // ---- S^T = K . Q^T ----
-        f32x4_t s[TPW][MT];
+    // FAST (CB == 1, dx a multiple of 16, the usual integer ratios): a tile is 16 consecutive pixels of one
+    // cell row, every per-tile quantity (row, first column, base pointers) is wave-uniform scalar work and a
+    // lane only adds constant 32-bit offsets.  Otherwise tiles straddle rows and each lane divides.
+    auto tile_loop = [&](auto fastc) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fastc)::value && (CB == 1);
+        for (int tb = wave * TPW; tb < ttot; tb += NW * TPW) {
+            // prefetch the next tiles' queries (clamped address when there is none)
+            bf16x8_t qn[TPW][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (!(ABL & 16)) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
+            for (int u = 0; u < TPW; ++u) {
+                const bf16_t* qp = FAST ? q_ptr_fast(tb + NW * TPW + u) : q_ptr(tb + NW * TPW + u);
+                if (!(ABL & 4)) {
+                    qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                    qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
                 } else {
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
+                    qn[u][0] = qn[u][1] = bf16x8_t{};
                 }
             }
-        }
+            // per-tile bookkeeping: cell of the tile, its own window inside the staged (union) window
+            int cyv[TPW], cxv[TPW], tv[TPW], oyv[TPW], oxv[TPW];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int tt = min(tb + u, ttot - 1);
+                const int ci = (CB == 1) ? 0 : tt / ntile;
+                tv[u] = tt - ci * ntile;
+                const int cyi = (CB == 1) ? 0 : ci / ncx, cxi = (CB == 1) ? 0 : ci - cyi * ncx;
+                cyv[u] = cy0 + cyi;
+                cxv[u] = cx0 + cxi;
+                oyv[u] = (CB == 1) ? 0 : min(max(cyv[u] - KS / 2, 0), p.h - KS) - y0;
+                oxv[u] = (CB == 1) ? 0 : min(max(cxv[u] - KS / 2, 0), p.w - KS) - x0;
+            }
 
-        // ---- softmax over key slots (fp32) ----
-        float inv[TPW];
-        bf16x8_t pf[TPW][KST];
+            // ---- S^T = K . Q^T ----
+            f32x4_t s[TPW][MT];
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            float m = -INFINITY;
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (CB == 1) {
-                        if (mt * 16 + 15 >= NSLOT) {  // tile contains pad slots: mask them
-                            const bool valid = (mt * 16 + r + grp * 4) < NSLOT;
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (!(ABL & 16)) {
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
+                    }
+                }
+            }
+
+            // ---- softmax over key slots (fp32); P is normalised BEFORE it is rounded to bf16 (as the reference
+            // does: softmax, then attn . V), so the PV result needs no rescale ----
+            bf16x8_t pf[TPW][KST];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (CB == 1) {
+                            if (mt * 16 + 15 >= NSLOT) {  // tile contains pad slots: mask them
+                                const bool valid = (mt * 16 + r + grp * 4) < NSLOT;
+                                s[u][mt][r] = valid ? s[u][mt][r] : -INFINITY;
+                            }
+                        } else {
+                            const int sl = mt * 16 + grp * 4 + r;
+                            const int ry = sl / WS, rx = sl - ry * WS;
+                            const bool valid = ((unsigned)(ry - oyv[u]) < (unsigned)KS) && ((unsigned)(rx - oxv[u]) < (unsigned)KS) && (sl < NSLOT);
                             s[u][mt][r] = valid ? s[u][mt][r] : -INFINITY;
                         }
-                    } else {
-                        const int sl = mt * 16 + grp * 4 + r;
-                        const int ry = sl / WS, rx = sl - ry * WS;
-                        const bool valid = ((unsigned)(ry - oyv[u]) < (unsigned)KS) && ((unsigned)(rx - oxv[u]) < (unsigned)KS) && (sl < NSLOT);
-                        s[u][mt][r] = valid ? s[u][mt][r] : -INFINITY;
+                        m = fmaxf(m, s[u][mt][r]);
                     }
-                    m = fmaxf(m, s[u][mt][r]);
-                }
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float sum = 0.f;
-            const float mc = m * p.scale_log2e;
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float sum = 0.f;
+                const float mc = m * p.scale_log2e;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[u][mt][r], p.scale_log2e, -mc));
-                    s[u][mt][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            inv[u] = 1.0f / sum;
-            // pack P to bf16 B-fragments: k index (g, j) <-> slot ks*32 + (j>>2)*16 + g*4 + (j&3)
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[u][mt][r], p.scale_log2e, -mc));
+                        s[u][mt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);   // sum >= 1 (the max slot contributes exp2(0))
+                // pack P to bf16 B-fragments: k index (g, j) <-> slot ks*32 + (j>>2)*16 + g*4 + (j&3)
 #pragma unroll
-            for (int ks = 0; ks < KST; ++ks)
+                for (int mt = 0; mt < MT; ++mt) s[u][mt] *= inv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
-        }
+                for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
+            }
 
-        // ---- O^T = V^T . P^T, normalise, store ----
-        OutT* obv[TPW];
-        OutT* opv[TPW];
-        bool pvalidv[TPW];
+            // ---- O^T = V^T . P^T, store ----
+            // FAST: o_tile = first pixel of the tile (uniform); generic: per-lane pixel pointer
+            OutT* obv[TPW];      // cell origin (generic) / tile origin (FAST)
+            OutT* opv[TPW];      // this lane's pixel (unstaged stores)
+            bool pvalidv[TPW];
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            const int ps = tv[u] * 16 + col;
-            pvalidv[u] = (ps < npix) && (tb + u < ttot);
-            const int psc = min(ps, npix - 1);
-            const int py = psc / p.dx, px = psc - py * p.dx;
-            obv[u] = obb + (int64_t)(cyv[u] * p.dy) * p.os[2] + (int64_t)(cxv[u] * p.dx) * p.os[3];
-            opv[u] = obv[u] + py * p.os[2] + px * p.os[3];
-        }
-        // one 16-channel tile of every query tile: V^T fragments are read once and feed TPW MFMAs
-        auto pv_tile = [&](int ct, f32x4_t (&acc)[TPW]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KST; ++ks) {
-                if (ABL & 2) {
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) acc[u][ks & 3] += (float)pf[u][ks][ct & 7];
-                    continue;
+            for (int u = 0; u < TPW; ++u) {
+                if constexpr (FAST) {
+                    const int ttc = min(tb + u, ttot - 1);
+                    const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
+                    obv[u] = o_cell + (int64_t)ty * p.os[2] + (int64_t)tx0 * p.os[3];
+                    opv[u] = reinterpret_cast<OutT*>(reinterpret_cast<char*>(obv[u]) + o_lane);
+                    pvalidv[u] = (tb + u < ttot);
+                } else {
+                    const int ps = tv[u] * 16 + col;
+                    pvalidv[u] = (ps < npix) && (tb + u < ttot);
+                    const int psc = min(ps, npix - 1);
+                    const int py = psc / p.dx, px = psc - py * p.dx;
+                    obv[u] = obb + (int64_t)(cyv[u] * p.dy) * p.os[2] + (int64_t)(cxv[u] * p.dx) * p.os[3];
+                    opv[u] = obv[u] + py * p.os[2] + px * p.os[3];
                 }
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
-                bf16x8_t a;
-                a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-                a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[u][ks], acc[u], 0, 0, 0);
             }
+            // one 16-channel tile of every query tile: V^T fragments are read once and feed TPW MFMAs
+            auto pv_tile = [&](int ct, f32x4_t (&acc)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < TPW; ++u) acc[u] *= inv[u];
-        };
-        if constexpr (STG) {
-            // bf16, whole-row stores: a tile's 16 px x DVT result goes through the wave's private LDS tile and
-            // leaves as 16-byte chunks in memory order, so one store instruction writes 1 KiB made of
-            // DVT*2-byte contiguous runs (full 128-byte lines) instead of 64 scattered 16-byte pieces.
-            static_assert(sizeof(OutT) == 2 && (CT % 2) == 0 && TPW == 1, "staged stores: bf16, even tile count, one tile");
-            bf16_t* ow = Os + wave * 16 * OROW;
-            bf16_t* owl = ow + col * OROW + (grp & 1) * 16 + (grp >> 1) * 8;
+                for (int u = 0; u < TPW; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ct = 0; ct < CT; ct += 2) {
-                f32x4_t a[TPW], bq[TPW];
-                pv_tile(ct, a);
-                pv_tile(ct + 1, bq);
-                bf16x4_t ab, bb;
+                for (int ks = 0; ks < KST; ++ks) {
+                    if (ABL & 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ab[i] = (bf16_t)a[0][i];
-                    bb[i] = (bf16_t)bq[0][i];
-                }
-                const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
-                const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                *reinterpret_cast<u32x4_t*>(owl + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-            }
-            constexpr int NCH = 16 * VCH;  // 16-byte chunks in the tile
-            const bool rowrun = (p.dx & 15) == 0;  // a tile is 16 consecutive pixels of one row
-            const int t0 = tv[0] * 16;
-            const int ty = rowrun ? t0 / p.dx : 0, tx0 = rowrun ? t0 - ty * p.dx : 0;
-#pragma unroll
-            for (int it = 0; it < (NCH + 63) / 64; ++it) {
-                const int i = it * 64 + lane;
-                if ((NCH % 64 == 0) || i < NCH) {
-                    const int pp = i / VCH, ch = i - pp * VCH;
-                    const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + pp * OROW + ch * 8);
-                    int yy, xx;
-                    if (rowrun) {
-                        yy = ty;
-                        xx = tx0 + pp;
-                    } else {
-                        const int sp = min(t0 + pp, npix - 1);
-                        yy = sp / p.dx;
-                        xx = sp - yy * p.dx;
+                        for (int u = 0; u < TPW; ++u) acc[u][ks & 3] += (float)pf[u][ks][ct & 7];
+                        continue;
                     }
-                    if (ABL & 1) {
-                        asm volatile("" ::"v"(wv));
-                    } else if (t0 + pp < npix) {
-                        *reinterpret_cast<u32x4_t*>(obv[0] + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
-                    }
-                }
-            }
-        } else {
-            constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
-            constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
-            if constexpr (kWide) {
-                // bf16: lane (px, g) holds channels g*4..g*4+3 of a 16-channel tile (8 B).  Exchange halves
-                // between the lane pairs (g, g^1) of two adjacent tiles with v_permlane16_swap so that every
-                // lane owns 8 consecutive channels -> one 16-byte store, 64 contiguous bytes per pixel.
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
+                    bf16x8_t a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
 #pragma unroll
-                for (int ct = 0; ct < CTP; ct += 2) {
+                    for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[u][ks], acc[u], 0, 0, 0);
+                }
+            };
+            if constexpr (STG) {
+                // bf16, whole-row stores: a tile's 16 px x DVT result goes through the wave's private LDS tile and
+                // leaves as 16-byte chunks in memory order, so one store instruction writes 1 KiB made of
+                // DVT*2-byte contiguous runs (full 128-byte lines) instead of 64 scattered 16-byte pieces.
+                static_assert(sizeof(OutT) == 2 && (CT % 2) == 0 && TPW == 1, "staged stores: bf16, even tile count, one tile");
+                bf16_t* ow = Os + wave * 16 * OROW;
+                bf16_t* owl = ow + col * OROW + (grp & 1) * 16 + (grp >> 1) * 8;
+#pragma unroll
+                for (int ct = 0; ct < CT; ct += 2) {
                     f32x4_t a[TPW], bq[TPW];
                     pv_tile(ct, a);
                     pv_tile(ct + 1, bq);
+                    bf16x4_t ab, bb;
 #pragma unroll
-                    for (int u = 0; u < TPW; ++u) {
-                        bf16x4_t ab, bb;
+                    for (int i = 0; i < 4; ++i) {
+                        ab[i] = (bf16_t)a[0][i];
+                        bb[i] = (bf16_t)bq[0][i];
+                    }
+                    const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    *reinterpret_cast<u32x4_t*>(owl + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                }
+                const int t0 = tv[0] * 16;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            ab[i] = (bf16_t)a[u][i];
-                            bb[i] = (bf16_t)bq[u][i];
-                        }
-                        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
-                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                        const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
+                for (int it = 0; it < NIT; ++it) {
+                    if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
+                        const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
                         if (ABL & 1) {
                             asm volatile("" ::"v"(wv));
+                        } else if constexpr (FAST) {
+                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv;
+                        } else {
+                            const int pp = (it * 64 + lane) / VCH, ch = (it * 64 + lane) - pp * VCH;
+                            const int sp = min(t0 + pp, npix - 1);
+                            const int yy = sp / p.dx, xx = sp - yy * p.dx;
+                            if (t0 + pp < npix) *reinterpret_cast<u32x4_t*>(obv[0] + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
+                        }
+                    }
+                }
+            } else {
+                constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
+                constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
+                if constexpr (kWide) {
+                    // bf16: lane (px, g) holds channels g*4..g*4+3 of a 16-channel tile (8 B).  Exchange halves
+                    // between the lane pairs (g, g^1) of two adjacent tiles with v_permlane16_swap so that every
+                    // lane owns 8 consecutive channels -> one 16-byte store, 64 contiguous bytes per pixel.
+#pragma unroll
+                    for (int ct = 0; ct < CTP; ct += 2) {
+                        f32x4_t a[TPW], bq[TPW];
+                        pv_tile(ct, a);
+                        pv_tile(ct + 1, bq);
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) {
+                            bf16x4_t ab, bb;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                ab[i] = (bf16_t)a[u][i];
+                                bb[i] = (bf16_t)bq[u][i];
+                            }
+                            const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                            const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                            const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
+                            if (ABL & 1) {
+                                asm volatile("" ::"v"(wv));
+                            } else if (pvalidv[u]) {
+                                *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = wv;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ct = CTP; ct < CT; ++ct) {
+                    f32x4_t acc[TPW];
+                    pv_tile(ct, acc);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        if (ABL & 1) {
+                            asm volatile("" ::"v"(acc[u]));
                         } else if (pvalidv[u]) {
-                            *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = wv;
+                            xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int ct = CTP; ct < CT; ++ct) {
-                f32x4_t acc[TPW];
-                pv_tile(ct, acc);
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) {
-                    if (ABL & 1) {
-                        asm volatile("" ::"v"(acc[u]));
-                    } else if (pvalidv[u]) {
-                        xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
-                    }
-                }
+            for (int u = 0; u < TPW; ++u) {
+                qf[u][0] = qn[u][0];
+                qf[u][1] = qn[u][1];
             }
         }
-#pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            qf[u][0] = qn[u][0];
-            qf[u][1] = qn[u][1];
-        }
-    }
+    };
+    if (fast) tile_loop(std::true_type{});
+    else tile_loop(std::false_type{});
 }
 
 template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4>
