@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
+    ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +139,7 @@ def main():
     B = args.per_gpu_batch
     torch.manual_seed(0)                                        # same random-init weights on every rank...
     model = NAF(kernel_size=ksz).to(dev).eval()
+    model.fuse_rope = not args.no_fuse_rope
     if world > 1:
         nd.broadcast_parameters(model, src=0)                   # ...and made identical by one RCCL broadcast
     g = torch.Generator(device=dev).manual_seed(1000 + rank)    # each rank owns different images
@@ -149,10 +151,11 @@ def main():
     ops.KERNEL_TIMER = timer
 
     if args.attention_only:
-        q5, k5 = model.guidance_qk(image, feats.shape[-2:], size)
+        q5, k5, tabs = model.guidance_qk(image, feats.shape[-2:], size,
+                                         fuse_for=(C // model.upsampler.num_heads, torch.bfloat16))
 
         def step():
-            return model.upsampler(q5, k5, feats)
+            return model.upsampler(q5, k5, feats, rope_tables=tabs)
     else:
         def step():
             return model(image, feats, size)

@@ -121,7 +121,8 @@ int naf_rope_tables(float* tab_y, float* tab_x, const float* periods, int32_t n_
  *   x      device, x_dtype, logical [B, Cq, Ho, Wo], element strides x_stride = {b, c, y, x}
  *   q      device bf16, logical [B, heads, Ho, Wo, Dh], strides q_stride = {b, head, y, x}, Dh contiguous
  *   k_lr   device bf16, logical [B, heads, h, w, Dh],   strides k_stride = {b, head, y, x}, Dh contiguous
- * Dh = Cq / heads, Dh % 4 == 0.  Pool window of low-res row i: [floor(i*Ho/h), ceil((i+1)*Ho/h)). */
+ * Dh = Cq / heads, Dh % 4 == 0.  Pool window of low-res row i: [floor(i*Ho/h), ceil((i+1)*Ho/h)).
+ * q may be NULL: keys only (the queries are then rotated on load by naf_xna_fwd, see rope_tab_y there). */
 typedef struct naf_rope_pool_args {
     const void* x;
     void* q;
@@ -156,6 +157,12 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
  *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.
  *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the
  *          generic path, ignored by the MFMA path (closed form, integer ratio).
+ *   rope_tab_y / rope_tab_x  optional device float [Ho][2][Dq/4] / [Wo][2][Dq/4] from naf_rope_tables.  When
+ *          both are given, `q` holds the UN-rotated guidance and the kernel applies RoPE (rope.py:15-34,139-153,
+ *          same arithmetic and bf16 rounding as naf_rope_pool_fwd) to every query as it is loaded, so the
+ *          rotated queries never make a round trip through HBM (pair with naf_rope_pool_fwd(q = NULL) for the
+ *          keys).  Only the MFMA path with Wo/w a multiple of 16 serves this; naf_xna_select reports
+ *          NAF_ERR_UNSUPPORTED otherwise and the caller falls back to materialised queries.  NULL = off.
  * scale <= 0 selects the reference default Dq^-0.5 (attentions.py:46). */
 typedef struct naf_xna_args {
     const void* q;
@@ -165,6 +172,8 @@ typedef struct naf_xna_args {
     float* logits;
     const int32_t* idx_y;
     const int32_t* idx_x;
+    const float* rope_tab_y;
+    const float* rope_tab_x;
     int32_t B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx;
     int32_t out_dtype; /* naf_dtype */
     int32_t path;      /* naf_xna_path */

@@ -33,7 +33,7 @@ class RopePoolArgs(C.Structure):
 class XnaArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k_lr", C.c_void_p), ("v_lr", C.c_void_p), ("out", C.c_void_p), ("logits", C.c_void_p),
-        ("idx_y", C.c_void_p), ("idx_x", C.c_void_p),
+        ("idx_y", C.c_void_p), ("idx_x", C.c_void_p), ("rope_tab_y", C.c_void_p), ("rope_tab_x", C.c_void_p),
         ("B", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
         ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
         ("out_dtype", C.c_int32), ("path", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32),

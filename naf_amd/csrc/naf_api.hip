@@ -77,7 +77,7 @@ int naf_rope_tables(float* tab_y, float* tab_x, const float* periods, int32_t n_
 
 int naf_rope_pool_fwd(const naf_rope_pool_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_rope_pool_fwd: args is NULL");
-    NAF_REQUIRE(a->x && a->q && a->k_lr && a->tab_y && a->tab_x, "naf_rope_pool_fwd: NULL tensor pointer");
+    NAF_REQUIRE(a->x && a->k_lr && a->tab_y && a->tab_x, "naf_rope_pool_fwd: NULL tensor pointer");
     NAF_REQUIRE(a->x_dtype == NAF_BF16 || a->x_dtype == NAF_F32, "naf_rope_pool_fwd: x_dtype %d", a->x_dtype);
     NAF_REQUIRE(a->B > 0 && a->Cq > 0 && a->heads > 0 && a->Ho > 0 && a->Wo > 0 && a->h > 0 && a->w > 0,
                 "naf_rope_pool_fwd: non-positive size");
@@ -138,14 +138,24 @@ static int xna_validate(const naf_xna_args* a) {
                 "naf_xna_fwd: kernel_size * dilation exceeds the output extent (k=%dx%d, dilation=%dx%d, out=%dx%d)",
                 a->ky, a->kx, a->Ho / a->h, a->Wo / a->w, a->Ho, a->Wo);
     NAF_REQUIRE(a->path == NAF_XNA_AUTO || a->path == NAF_XNA_MFMA || a->path == NAF_XNA_GENERIC, "naf_xna_fwd: path %d", a->path);
+    NAF_REQUIRE((a->rope_tab_y == nullptr) == (a->rope_tab_x == nullptr), "naf_xna_fwd: rope_tab_y and rope_tab_x must be given together");
     return NAF_OK;
 }
 
 int naf_xna_select(const naf_xna_args* a) {
     const int rc = xna_validate(a);
     if (rc != NAF_OK) return -rc;
-    if (a->path == NAF_XNA_GENERIC) return NAF_XNA_GENERIC;
     const bool ok = naf_xna_mfma_eligible(a, nullptr, nullptr) != 0;
+    if (a->rope_tab_y != nullptr) {
+        // rotate-on-load lives in the MFMA kernel's row-tile path only
+        if (a->path == NAF_XNA_GENERIC || !ok || !naf_xna_mfma_rope_ok(a)) {
+            naf_set_error("naf_xna_select: rotate-on-load (rope_tab_*) needs the MFMA path with Wo/w %% 16 == 0 (got path %d, %dx%d -> %dx%d)",
+                          a->path, a->h, a->w, a->Ho, a->Wo);
+            return -NAF_ERR_UNSUPPORTED;
+        }
+        return NAF_XNA_MFMA;
+    }
+    if (a->path == NAF_XNA_GENERIC) return NAF_XNA_GENERIC;
     if (a->path == NAF_XNA_MFMA) {
         if (!ok) {
             naf_set_error("naf_xna_select: MFMA path requested but the arguments are not eligible");

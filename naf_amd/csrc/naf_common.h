@@ -31,6 +31,7 @@ int naf_check_launch(const char* what);
 // ---- kernel launchers implemented in the .hip files ----
 int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s);      // xna_mfma.hip
 int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out);  // xna_mfma.hip
+int naf_xna_mfma_rope_ok(const naf_xna_args* a);                                   // xna_mfma.hip
 int naf_launch_xna_generic(const naf_xna_args* a, float scale, hipStream_t s);   // xna_generic.hip
 int naf_launch_rope_tables(float* ty, float* tx, const float* periods, int np, int Ho, int Wo, hipStream_t s);
 int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);             // rope_pool.hip
@@ -46,6 +47,13 @@ __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_
 
 // Bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD one contiguous
 // range of logical ids so neighbouring cells (which share K/V windows) meet in the same L2.
+// RoPE pair rotation (rope.py:15-34): one definition for naf_rope_pool_fwd and for the rotate-on-load of
+// naf_xna_fwd, so both round identically (explicit fma, the inner products are rounded on their own).
+__device__ __forceinline__ void naf_rope_rotate(float a, float b, float c, float s, float& o1, float& o2) {
+    o1 = __builtin_fmaf(a, c, -(b * s));
+    o2 = __builtin_fmaf(b, c, a * s);
+}
+
 __device__ __forceinline__ uint32_t naf_xcd_remap(uint32_t bid, uint32_t n) {
     const uint32_t q = n >> 3, r = n & 7u, xcd = bid & 7u, idx = bid >> 3;
     const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;

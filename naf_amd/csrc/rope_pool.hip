@@ -156,12 +156,11 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
             float o1[VEC], o2[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                o1[i] = v1[i] * cs[i] - v2[i] * sn[i];
-                o2[i] = v2[i] * cs[i] + v1[i] * sn[i];
+                naf_rope_rotate(v1[i], v2[i], cs[i], sn[i], o1[i], o2[i]);
                 acc1[i] += o1[i];
                 acc2[i] += o2[i];
             }
-            if (y < yo && x < xo) {
+            if (p.q != nullptr && y < yo && x < xo) {   // q == NULL: keys only (queries are rotated on load by naf_xna_fwd)
                 bf16_t* qp = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)y * p.qs[2] + (int64_t)x * p.qs[3] + t0;
                 store_bf16<VEC>(qp, o1);
                 store_bf16<VEC>(qp + half, o2);
@@ -200,7 +199,7 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
     const size_t esz = a->x_dtype == NAF_BF16 ? 2 : 4;
     bool vec = (p.Dh % 32 == 0);
     vec = vec && (reinterpret_cast<uintptr_t>(a->q) % 16 == 0) && (reinterpret_cast<uintptr_t>(a->x) % 16 == 0);
-    for (int i = 0; i < 4; ++i) vec = vec && (a->q_stride[i] % 8 == 0);
+    for (int i = 0; i < 4; ++i) vec = vec && (a->q == nullptr || a->q_stride[i] % 8 == 0);
     if (a->x_stride[1] == 1) {
         vec = vec && (a->x_stride[0] * esz % 16 == 0) && (a->x_stride[2] * esz % 16 == 0) && (a->x_stride[3] * esz % 16 == 0);
     }

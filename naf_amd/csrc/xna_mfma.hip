@@ -29,6 +29,14 @@ int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) 
     return 1;
 }
 
+// Rotate-on-load (rope_tab_*) is implemented by the kernel's row-tile path: a 16-query tile must be 16 consecutive
+// pixels of one cell row (dx % 16 == 0, <= 1024 tiles per cell).
+int naf_xna_mfma_rope_ok(const naf_xna_args* a) {
+    const int dy = a->Ho / a->h, dx = a->Wo / a->w;
+    if (dx % 16 != 0 || (int64_t)dy * dx / 16 > 1024) return 0;
+    return naf_xna_mfma_eligible(a, nullptr, nullptr);
+}
+
 int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     int dvt = 0;
     size_t lds = 0;
@@ -46,6 +54,11 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.out = a->out;
     p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
     p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
+    p.tab_y = a->rope_tab_y; p.tab_x = a->rope_tab_x;
+    if (a->rope_tab_y != nullptr && !naf_xna_mfma_rope_ok(a)) {
+        naf_set_error("naf_xna_fwd: rotate-on-load needs Wo/w %% 16 == 0 (got %dx%d -> %dx%d)", a->h, a->w, a->Ho, a->Wo);
+        return NAF_ERR_UNSUPPORTED;
+    }
     XnaMfmaPlan pl;
     xna_mfma_plan(a->ky, a->Dv, a->out_dtype, &pl);
     p.nchunk = a->Dv / pl.dvt;

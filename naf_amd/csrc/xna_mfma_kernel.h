@@ -34,6 +34,8 @@ struct XnaMfmaParams {
     const bf16_t* k;
     const bf16_t* v;
     void* out;
+    const float* tab_y;  // rotate-on-load: RoPE tables [Ho][2][16] / [Wo][2][16], or nullptr
+    const float* tab_x;
     int32_t B, heads, Ho, Wo, h, w, dy, dx, nchunk;
     uint32_t nblocks;
     float scale_log2e;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             }
         }
     }
+    const bool rope = p.tab_y != nullptr;   // rotate-on-load (host guarantees the FAST path then)
     __syncthreads();
 
     // key slots >= NSLOT are not stored: clamp their row to the last real key (their logits are masked, P = 0)
@@ -230,8 +233,41 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     // FAST (CB == 1, dx a multiple of 16, the usual integer ratios): a tile is 16 consecutive pixels of one
     // cell row, every per-tile quantity (row, first column, base pointers) is wave-uniform scalar work and a
     // lane only adds constant 32-bit offsets.  Otherwise tiles straddle rows and each lane divides.
-    auto tile_loop = [&](auto fastc) __attribute__((always_inline)) {
+    // rotate-on-load: RoPE on a tile's queries.  The lane holds head dims [grp*8, +8) (qf[0]) and their partners
+    // +32 (qf[1]); dims < 16 turn with the row angle, dims >= 16 with the column angle.  The table values of the
+    // NEXT tile are fetched from LDS at the top of an iteration and applied at its bottom, when the prefetched
+    // queries have landed, so neither latency sits on the tile's critical path.
+    auto rope_fetch = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        const int ttc = min(tt, ttot - 1);
+        const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
+        // straight from the tables (128 KB each, L1/L2-resident): an LDS copy would cost the third resident workgroup
+        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx0 * p.dx + tx0 + col) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
+        cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
+        cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
+        cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
+        cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
+    };
+    auto rope_apply = [&](bf16x8_t (&qv)[2], const f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float o1, o2;
+            naf_rope_rotate((float)qv[0][i], (float)qv[1][i], cs[i >> 2][i & 3], cs[2 + (i >> 2)][i & 3], o1, o2);
+            qv[0][i] = (bf16_t)o1;
+            qv[1][i] = (bf16_t)o2;
+        }
+    };
+
+    auto tile_loop = [&](auto fastc, auto ropec) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fastc)::value && (CB == 1);
+        constexpr bool ROPE = FAST && decltype(ropec)::value;
+        if constexpr (ROPE) {
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                f32x4_t cs0[4];
+                rope_fetch(wave * TPW + u, cs0);
+                rope_apply(qf[u], cs0);
+            }
+        }
         for (int tb = wave * TPW; tb < ttot; tb += NW * TPW) {
             // prefetch the next tiles' queries (clamped address when there is none)
             bf16x8_t qn[TPW][2];
@@ -245,6 +281,12 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     qn[u][0] = qn[u][1] = bf16x8_t{};
                 }
             }
+            f32x4_t csn[TPW][4];
+            if constexpr (ROPE) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) rope_fetch(tb + NW * TPW + u, csn[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued first: it has the whole tile to land
             // per-tile bookkeeping: cell of the tile, its own window inside the staged (union) window
             int cyv[TPW], cxv[TPW], tv[TPW], oyv[TPW], oxv[TPW];
 #pragma unroll
@@ -453,15 +495,33 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     }
                 }
             }
+            // keep the consumption of the prefetch (and its vmcnt wait) BELOW this tile's stores: hoisted above
+            // them, the wait would also cover the previous tile's stores
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 qf[u][0] = qn[u][0];
                 qf[u][1] = qn[u][1];
             }
+            if constexpr (ROPE) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) rope_apply(qf[u], csn[u]);
+            }
         }
+        // Drain the (unused) prefetch of the tile after the last one HERE, per loop instance.  The three instances
+        // are laid out one after another behind flag tests and hipcc's waitcnt pass is path-insensitive: loads
+        // left in flight at the exit of one instance count as "maybe pending" at the header of the next, which
+        // then waits for vmcnt(0) -- i.e. for the previous tile's six row stores -- at the top of EVERY iteration.
+        // An asm that reads the prefetched registers makes the compiler put the wait at this exit; the instance
+        // number keeps the three copies from being tail-merged into one block at the end of the kernel.
+        constexpr int LOOP_ID = FAST ? (ROPE ? 2 : 1) : 0;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) asm volatile("; xna tile loop %0 drained" ::"n"(LOOP_ID), "v"(qf[u][0]), "v"(qf[u][1]));
     };
-    if (fast) tile_loop(std::true_type{});
-    else tile_loop(std::false_type{});
+    // (the host only passes tables when the FAST conditions hold)
+    if (fast && rope) tile_loop(std::true_type{}, std::true_type{});
+    else if (fast) tile_loop(std::true_type{}, std::false_type{});
+    else tile_loop(std::false_type{}, std::false_type{});
 }
 
 template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4>

@@ -201,8 +201,9 @@ class CrossAttention(nn.Module):
         self.scale = (dim // num_heads) ** -0.5
         self.dilation = None
 
-    def forward(self, q5, k5, values, return_weights=False, path="auto"):
-        """q5/k5: 5-D bf16 views from ops.rope_pool; values: [B, C, h, w] features."""
+    def forward(self, q5, k5, values, return_weights=False, path="auto", rope_tables=None):
+        """q5/k5: 5-D bf16 views from ops.rope_pool; values: [B, C, h, w] features.  With ``rope_tables`` q5 is
+        the un-rotated guidance and the attention kernel rotates it on load."""
         B, C = values.shape[:2]
         if C % self.num_heads:
             raise ValueError(f"feature channels {C} not divisible by {self.num_heads} heads")   # einops error in the reference
@@ -213,7 +214,7 @@ class CrossAttention(nn.Module):
         v5 = vp.view(B, h, w, self.num_heads, C // self.num_heads).permute(0, 3, 1, 2, 4)
         out_dtype = torch.bfloat16 if values.dtype == torch.bfloat16 else torch.float32
         res = ops.xna_forward(q5, k5, v5, self.kernel_size, out_dtype=out_dtype, return_logits=return_weights,
-                              path="generic" if return_weights else path, scale=self.scale)
+                              path="generic" if return_weights else path, scale=self.scale, rope_tables=rope_tables)
         out5, logits = res if return_weights else (res, None)
         # [B, heads, Ho, Wo, Dv] view of a channels-last buffer -> logical [B, C, Ho, Wo]
         out = out5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, C).permute(0, 3, 1, 2)
@@ -235,9 +236,13 @@ class NAF(nn.Module):
         self.key_encoder = KeyEncoder()
         self.upsampler = CrossAttention(dim=dim, num_heads=heads_attn, kernel_size=(kernel_size, kernel_size))
         self.xna_path = "auto"
+        self.fuse_rope = True      # rotate queries inside the attention kernel when the shapes allow it
 
-    def guidance_qk(self, image, lr_size, output_size):
-        """RoPE'd bf16 queries and pooled keys (5-D views) for ``image``."""
+    def guidance_qk(self, image, lr_size, output_size, fuse_for=None):
+        """bf16 queries and pooled RoPE'd keys (5-D views) for ``image``.  Returns (q5, k5, rope_tables):
+        rope_tables is None when q5 is already rotated, or the (tab_y, tab_x) pair when q5 is the un-rotated
+        guidance that the attention kernel rotates on load (``fuse_for`` = (Dv, out_dtype) of the attention call
+        asks for that; it is granted when the shapes allow it, see ops.xna_rope_fusable)."""
         ho, wo = int(output_size[0]), int(output_size[1])
         enc = self.image_encoder
         with ops._Timed("stem"):
@@ -245,14 +250,24 @@ class NAF(nn.Module):
         tab_y, tab_x = enc.rope.tables(ho, wo)
         heads_rope, heads_attn = enc.rope.num_heads, self.upsampler.num_heads
         same = heads_attn == heads_rope
-        q5, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, q_layout="head_major" if same else "channels_last")
+        if fuse_for is not None and self.fuse_rope and same and x.dtype == torch.bfloat16:
+            B, Cq = x.shape[:2]
+            xq = x.permute(0, 2, 3, 1)                                            # [B, Ho, Wo, C] view
+            if xq.stride(3) == 1:
+                q5 = xq.unflatten(3, (heads_rope, Cq // heads_rope)).permute(0, 3, 1, 2, 4)
+                if ops.xna_rope_fusable(q5, lr_size, fuse_for[0], self.upsampler.kernel_size, (tab_y, tab_x),
+                                        out_dtype=fuse_for[1], path=self.xna_path):
+                    _, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, write_q=False)
+                    return q5, k5, (tab_y, tab_x)
+        import os as _os
+        q5, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, q_layout="head_major" if (same and not _os.environ.get("NAF_QL")) else "channels_last")
         if not same:        # re-split the channel axis for attention: pure views of channels-last buffers
             B, _, Ho, Wo, _ = q5.shape
             dim = enc.out_channels
             q5 = q5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, heads_attn, dim // heads_attn).permute(0, 3, 1, 2, 4)
             h, w = k5.shape[2:4]
             k5 = k5.permute(0, 2, 3, 1, 4).reshape(B, h, w, heads_attn, dim // heads_attn).permute(0, 3, 1, 2, 4)
-        return q5, k5
+        return q5, k5, None
 
     @torch.no_grad()
     def forward(self, image, features, output_size, return_weights=False, *args, **kwargs):
@@ -261,6 +276,10 @@ class NAF(nn.Module):
                                f"image on {image.device}, features on {features.device}")
         if image.dim() != 4 or features.dim() != 4 or image.shape[0] != features.shape[0]:
             raise ValueError(f"expected image [B,3,H,W] and features [B,C,h,w], got {tuple(image.shape)} / {tuple(features.shape)}")
-        q5, k5 = self.guidance_qk(image, features.shape[-2:], output_size)
+        fuse_for = None
+        if not return_weights and features.shape[1] % self.upsampler.num_heads == 0:
+            fuse_for = (features.shape[1] // self.upsampler.num_heads,
+                        torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32)
+        q5, k5, tabs = self.guidance_qk(image, features.shape[-2:], output_size, fuse_for=fuse_for)
         with ops._Timed("attention"):
-            return self.upsampler(q5, k5, features, return_weights=return_weights, path=self.xna_path)
+            return self.upsampler(q5, k5, features, return_weights=return_weights, path=self.xna_path, rope_tables=tabs)

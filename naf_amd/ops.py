@@ -143,10 +143,12 @@ def rope_tables(periods: torch.Tensor, Ho: int, Wo: int) -> Tuple[torch.Tensor, 
 
 
 def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: int, lr_size,
-              q_layout: str = "head_major") -> Tuple[torch.Tensor, torch.Tensor]:
+              q_layout: str = "head_major", write_q: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """x: logical [B, Cq, Ho, Wo] (bf16/fp32, any strides; channels-last is the fast layout).
     Returns q [B, heads, Ho, Wo, Dh] bf16 (RoPE'd queries) and k_lr [B, heads, h, w, Dh] bf16
-    (adaptive-avg-pooled RoPE'd keys), both as 5-D strided views with Dh contiguous."""
+    (adaptive-avg-pooled RoPE'd keys), both as 5-D strided views with Dh contiguous.
+    ``write_q=False``: keys only (q is None) -- for ``xna_forward(..., rope_tables=...)`` which rotates the
+    queries as it loads them."""
     _gpu(x, "guidance features")
     lib = _lib.load()
     if x.dtype not in _DT:
@@ -157,7 +159,9 @@ def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: 
         raise ValueError(f"rope_pool: {Cq} channels not divisible by {heads} heads")
     Dh = Cq // heads
     dev = x.device
-    if q_layout == "head_major":
+    if not write_q:
+        q = None
+    elif q_layout == "head_major":
         q = torch.empty((B, heads, Ho, Wo, Dh), dtype=torch.bfloat16, device=dev)
     elif q_layout == "channels_last":
         q = torch.empty((B, Ho, Wo, heads, Dh), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
@@ -165,12 +169,12 @@ def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: 
         raise ValueError(f"unknown q_layout {q_layout!r}")
     k = torch.empty((B, h, w, heads, Dh), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
     a = RopePoolArgs()
-    a.x, a.q, a.k_lr = x.data_ptr(), q.data_ptr(), k.data_ptr()
+    a.x, a.q, a.k_lr = x.data_ptr(), (q.data_ptr() if q is not None else None), k.data_ptr()
     a.tab_y, a.tab_x = tab_y.data_ptr(), tab_x.data_ptr()
     a.x_dtype = _DT[x.dtype]
     a.B, a.Cq, a.heads, a.Ho, a.Wo, a.h, a.w = B, Cq, heads, Ho, Wo, h, w
     a.x_stride = _strides4(x, (0, 1, 2, 3))
-    a.q_stride = _strides4(q, (0, 1, 2, 3))
+    a.q_stride = _strides4(q, (0, 1, 2, 3)) if q is not None else I64x4(0, 0, 0, 0)
     a.k_stride = _strides4(k, (0, 1, 2, 3))
     if tab_y.shape != (Ho, 2, Dh // 4) or tab_x.shape != (Wo, 2, Dh // 4):
         raise ValueError(f"rope_pool: tables {tuple(tab_y.shape)}/{tuple(tab_x.shape)} do not match Ho={Ho} Wo={Wo} Dh/4={Dh // 4}")
@@ -195,7 +199,7 @@ def pack_values(v: torch.Tensor) -> torch.Tensor:
     return vp
 
 
-def _fill_xna(q, k, v, out, logits, idx_y, idx_x, ky, kx, path, scale) -> XnaArgs:
+def _fill_xna(q, k, v, out, logits, idx_y, idx_x, ky, kx, path, scale, rope_tables=None) -> XnaArgs:
     B, heads, Ho, Wo, Dq = q.shape
     _, _, h, w, Dv = v.shape
     a = XnaArgs()
@@ -203,6 +207,12 @@ def _fill_xna(q, k, v, out, logits, idx_y, idx_x, ky, kx, path, scale) -> XnaArg
     a.logits = logits.data_ptr() if logits is not None else None
     a.idx_y = idx_y.data_ptr() if idx_y is not None else None
     a.idx_x = idx_x.data_ptr() if idx_x is not None else None
+    if rope_tables is not None:
+        ty, tx = rope_tables
+        if ty.dtype != torch.float32 or tx.dtype != torch.float32 or tuple(ty.shape) != (q.shape[2], 2, q.shape[4] // 4) \
+                or tuple(tx.shape) != (q.shape[3], 2, q.shape[4] // 4) or not (ty.is_contiguous() and tx.is_contiguous()):
+            raise ValueError("xna: rope_tables must be the fp32 [Ho,2,Dq/4] / [Wo,2,Dq/4] pair from ops.rope_tables")
+        a.rope_tab_y, a.rope_tab_x = ty.data_ptr(), tx.data_ptr()
     a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx
     a.out_dtype = _DT[out.dtype]
     a.path = _PATH[path]
@@ -216,8 +226,11 @@ def _fill_xna(q, k, v, out, logits, idx_y, idx_x, ky, kx, path, scale) -> XnaArg
 
 def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size, *,
                 out_dtype: torch.dtype = torch.bfloat16, return_logits: bool = False, path: str = "auto",
-                scale: Optional[float] = None, out: Optional[torch.Tensor] = None):
+                scale: Optional[float] = None, out: Optional[torch.Tensor] = None, rope_tables=None):
     """Cross-scale neighbourhood attention forward.
+
+    ``rope_tables=(tab_y, tab_x)``: ``q`` is the UN-rotated guidance and the kernel applies RoPE while loading
+    it (see ``xna_rope_fusable``; raises NafHipError when the shapes do not allow it).
 
     q [B, heads, Ho, Wo, Dq] bf16, k_lr [B, heads, h, w, Dq] bf16, v_lr [B, heads, h, w, Dv] bf16 --
     5-D strided views with the last dim contiguous.  Returns ``out`` as a [B, heads, Ho, Wo, Dv] view
@@ -242,7 +255,7 @@ def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_
     if out is None:
         out = torch.empty((B, Ho, Wo, heads, Dv), dtype=out_dtype, device=dev).permute(0, 3, 1, 2, 4)
     logits = torch.empty((B, heads, Ho, Wo, ky * kx), dtype=torch.float32, device=dev) if return_logits else None
-    a = _fill_xna(q, k_lr, v_lr, out, logits, None, None, ky, kx, path, scale)
+    a = _fill_xna(q, k_lr, v_lr, out, logits, None, None, ky, kx, path, scale, rope_tables)
     sel = lib.naf_xna_select(C.byref(a))
     if sel < 0:
         _lib.check(-sel, "naf_xna_select")
@@ -254,6 +267,28 @@ def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_
         rc = lib.naf_xna_fwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_fwd")
     return (out, logits) if return_logits else out
+
+
+def xna_rope_fusable(q: torch.Tensor, lr_size, Dv: int, kernel_size, rope_tables, out_dtype=torch.bfloat16,
+                     path: str = "auto") -> bool:
+    """True when ``xna_forward(q, ..., rope_tables=...)`` can rotate the queries on load for these shapes (MFMA path,
+    Wo/w a multiple of 16).  ``q``: the un-rotated guidance as a 5-D [B, heads, Ho, Wo, Dq] bf16 view."""
+    if q.dtype != torch.bfloat16 or q.dim() != 5 or q.stride(4) != 1 or out_dtype not in _DT:
+        return False
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else tuple(kernel_size)
+    B, heads, Ho, Wo, Dq = q.shape
+    h, w = int(lr_size[0]), int(lr_size[1])
+    a = XnaArgs()
+    a.q = a.k_lr = a.v_lr = a.out = q.data_ptr()      # shape / alignment query only: nothing is dereferenced
+    a.rope_tab_y, a.rope_tab_x = rope_tables[0].data_ptr(), rope_tables[1].data_ptr()
+    a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, int(Dv), ky, kx
+    a.out_dtype, a.path, a.scale = _DT[out_dtype], _PATH[path], 0.0
+    a.q_stride = _strides4(q, (0, 1, 2, 3))
+    a.k_stride = I64x4(h * w * heads * Dq, Dq, w * heads * Dq, heads * Dq)
+    a.v_stride = I64x4(h * w * heads * Dv, Dv, w * heads * Dv, heads * Dv)
+    a.o_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    return lib.naf_xna_select(C.byref(a)) == _lib.XNA_MFMA
 
 
 def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logits=False, path="auto") -> str:

@@ -373,6 +373,53 @@ def test_golden_F7_preshrink_and_pool(dev, golden_dir):
         assert_close(out.float().cpu(), torch.from_numpy(g[f"out_{tag}"]), 6e-2, 3e-2, f"F7{tag}")
 
 
+@pytest.mark.parametrize("B,C,lr,out_sz,ksz,out_dtype", [
+    (1, 64, (8, 8), (128, 128), 7, torch.bfloat16),        # d = 16: one row tile per cell row
+    (2, 128, (6, 5), (192, 160), 5, torch.float32),        # d = 32: two tiles per cell row, non-square grid
+    (1, 64, (12, 12), (96, 192), 3, torch.bfloat16),       # dy = 8, dx = 16
+])
+def test_rotate_on_load_equals_materialised_queries(dev, B, C, lr, out_sz, ksz, out_dtype):
+    """naf_xna_fwd(rope_tab_*) on un-rotated guidance == naf_rope_pool_fwd queries + plain naf_xna_fwd, bit for
+    bit (same rotation arithmetic, same bf16 rounding), and both match the oracle's rope + attention."""
+    from naf_amd import ops
+    heads, Dq = 4, 64
+    x = bf16r(O.hash_normal((B, heads * Dq, *out_sz), 310))
+    v = bf16r(O.hash_normal((B, C, *lr), 311))
+    per = O.rope_periods(heads * Dq, heads, 100.0)
+    xd = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ty, tx = ops.rope_tables(per.to(dev), *out_sz)
+    q_mat, k5 = ops.rope_pool(xd, ty, tx, heads, lr)
+    none_q, k5b = ops.rope_pool(xd, ty, tx, heads, lr, write_q=False)
+    assert none_q is None and torch.equal(k5, k5b)
+    q_raw = xd.permute(0, 2, 3, 1).unflatten(3, (heads, Dq)).permute(0, 3, 1, 2, 4)
+    assert ops.xna_rope_fusable(q_raw, lr, C // heads, ksz, (ty, tx), out_dtype=out_dtype)
+    vp = ops.pack_values(v.to(dev))
+    v5 = vp.view(B, *lr, heads, C // heads).permute(0, 3, 1, 2, 4)
+    a = ops.xna_forward(q_mat, k5, v5, ksz, out_dtype=out_dtype, path="mfma")
+    b = ops.xna_forward(q_raw, k5, v5, ksz, out_dtype=out_dtype, path="mfma", rope_tables=(ty, tx))
+    assert torch.equal(a, b), f"rotate-on-load differs from materialised queries: {float((a.float() - b.float()).abs().max())}"
+    ref_q = bf16r(O.rope(x, per, heads))
+    ref_k = bf16r(O.key_pool(O.rope(x, per, heads), lr))
+    ref = O.xna_lowres(ref_q, ref_k, v, ksz, heads)
+    got = b.permute(0, 1, 4, 2, 3).reshape(B, C, *out_sz).float().cpu()
+    assert_close(got, ref, 2e-2, 2e-2, "rotate-on-load vs oracle")
+
+
+def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
+    from naf_amd import ops
+    from naf_amd._lib import NafHipError
+    heads, Dq = 4, 64
+    xd = torch.zeros((1, 40, 40, heads * Dq), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)   # d = 8
+    per = O.rope_periods(heads * Dq, heads, 100.0)
+    ty, tx = ops.rope_tables(per.to(dev), 40, 40)
+    q_raw = xd.permute(0, 2, 3, 1).unflatten(3, (heads, Dq)).permute(0, 3, 1, 2, 4)
+    assert not ops.xna_rope_fusable(q_raw, (5, 5), 16, 3, (ty, tx))
+    _, k5 = ops.rope_pool(xd, ty, tx, heads, (5, 5), write_q=False)
+    v5 = torch.zeros((1, 5, 5, heads, 16), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
+    with pytest.raises(NafHipError):
+        ops.xna_forward(q_raw, k5, v5, 3, rope_tables=(ty, tx))
+
+
 def test_heads_rope_differs_from_heads_attn(dev):
     p = O.make_params(dim=64, heads_rope=1, seed=8)
     m = _load_model(dev, p, dim=64, heads_attn=4, heads_rope=1, kernel_size=3)

@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(q, hq.data(), nq * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(k, hk.data(), nk * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(v, hv.data(), nv * 2, hipMemcpyHostToDevice));
-    XnaMfmaParams p;
+    XnaMfmaParams p{};
     p.q = q; p.k = k; p.v = v; p.out = o;
     p.B = B; p.heads = heads; p.Ho = Ho; p.Wo = Wo; p.h = lr; p.w = lr; p.dy = d; p.dx = d; p.nchunk = Dv / PROBE_DVT;
     p.nblocks = (uint32_t)(B * lr * lr * heads * p.nchunk);
