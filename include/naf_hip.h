@@ -154,7 +154,8 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
  *   out    device out_dtype [B, heads, Ho, Wo, Dv] strides {b, head, y, x}, Dv contiguous
  *          (a channels-last [B, Ho, Wo, heads*Dv] buffer is {Ho*Wo*C, Dv, Wo*C, C})
  *   logits optional device float [B, heads, Ho, Wo, ky*kx] dense: scaled pre-softmax scores, i.e. what
- *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.
+ *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.  Both paths
+ *          produce them (the MFMA kernel writes them from its S^T accumulators).
  *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the
  *          generic path, ignored by the MFMA path (closed form, integer ratio).
  *   rope_tab_y / rope_tab_x  optional device float [Ho][2][Dq/4] / [Wo][2][Dq/4] from naf_rope_tables.  When

@@ -14,7 +14,6 @@ int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) 
     const int ks = a->ky;
     if (ks < 3 || ks > 15 || (ks & 1) == 0) return 0;
     if (a->Dq != 64) return 0;
-    if (a->logits != nullptr) return 0;
     if (a->h < ks || a->w < ks) return 0;
     if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
     if (a->Dv % 16 != 0) return 0;
@@ -43,7 +42,7 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     if (!naf_xna_mfma_eligible(a, &dvt, &lds)) {
         naf_set_error(
             "naf_xna_fwd: MFMA path needs square odd kernel 3..15, Dq=64, integer ratio, h,w >= kernel, Dv %% 16 == 0, "
-            "16-byte aligned tensors and no logits output (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
+            "16-byte aligned tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
             a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;
     }
@@ -52,6 +51,7 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.k = static_cast<const bf16_t*>(a->k_lr);
     p.v = static_cast<const bf16_t*>(a->v_lr);
     p.out = a->out;
+    p.logits = a->logits;
     p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
     p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
     p.tab_y = a->rope_tab_y; p.tab_x = a->rope_tab_x;
@@ -70,6 +70,7 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     }
     p.nblocks = (uint32_t)nb;
     p.scale_log2e = scale * 1.4426950408889634f;
+    p.scale = scale;
     for (int i = 0; i < 4; ++i) {
         p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i]; p.os[i] = a->o_stride[i];
     }

@@ -34,11 +34,12 @@ struct XnaMfmaParams {
     const bf16_t* k;
     const bf16_t* v;
     void* out;
+    float* logits;       // optional [B, heads, Ho, Wo, KS*KS] scaled pre-softmax scores (return_weights), or nullptr
     const float* tab_y;  // rotate-on-load: RoPE tables [Ho][2][16] / [Wo][2][16], or nullptr
     const float* tab_x;
     int32_t B, heads, Ho, Wo, h, w, dy, dx, nchunk;
     uint32_t nblocks;
-    float scale_log2e;
+    float scale_log2e, scale;
     int64_t qs[4], ks[4], vs[4], os[4];  // {b, head, y, x} element strides
 };
 
@@ -316,6 +317,45 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     } else {
 #pragma unroll
                         for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
+                    }
+                }
+            }
+
+            // ---- return_weights: the scaled scores, key order = row-major window (attentions.py:21-28) ----
+            if (p.logits != nullptr && chunk == 0) {
+                typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    int Y, X;
+                    bool ok = tb + u < ttot;
+                    if constexpr (FAST) {
+                        const int ty = (int)(((uint32_t)(tb + u < ttot ? tb + u : ttot - 1) * tmagic) >> 20);
+                        const int tx0 = ((tb + u < ttot ? tb + u : ttot - 1) - ty * tpr) * 16;
+                        Y = cy0 * p.dy + ty;
+                        X = cx0 * p.dx + tx0 + col;
+                    } else {
+                        const int ps = tv[u] * 16 + col;
+                        ok = ok && ps < npix;
+                        const int psc = min(ps, npix - 1);
+                        const int py = psc / p.dx, px = psc - py * p.dx;
+                        Y = cyv[u] * p.dy + py;
+                        X = cxv[u] * p.dx + px;
+                    }
+                    float* lg = p.logits + ((((int64_t)b * p.heads + head) * p.Ho + Y) * p.Wo + X) * (KS * KS);
+                    if (ok) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const int s0 = mt * 16 + grp * 4;   // this lane's 4 consecutive key slots
+                            if constexpr (CB == 1) {
+                                if (mt * 16 + 15 < KS * KS) {
+                                    *reinterpret_cast<f32x4u_t*>(lg + s0) = s[u][mt] * p.scale;
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        if (s0 + r < KS * KS) lg[s0 + r] = s[u][mt][r] * p.scale;
+                                }
+                            }
+                        }
                     }
                 }
             }

@@ -214,7 +214,7 @@ class CrossAttention(nn.Module):
         v5 = vp.view(B, h, w, self.num_heads, C // self.num_heads).permute(0, 3, 1, 2, 4)
         out_dtype = torch.bfloat16 if values.dtype == torch.bfloat16 else torch.float32
         res = ops.xna_forward(q5, k5, v5, self.kernel_size, out_dtype=out_dtype, return_logits=return_weights,
-                              path="generic" if return_weights else path, scale=self.scale, rope_tables=rope_tables)
+                              path=path, scale=self.scale, rope_tables=rope_tables)
         out5, logits = res if return_weights else (res, None)
         # [B, heads, Ho, Wo, Dv] view of a channels-last buffer -> logical [B, C, Ho, Wo]
         out = out5.permute(0, 2, 3, 1, 4).reshape(B, Ho, Wo, C).permute(0, 3, 1, 2)
@@ -277,7 +277,7 @@ class NAF(nn.Module):
         if image.dim() != 4 or features.dim() != 4 or image.shape[0] != features.shape[0]:
             raise ValueError(f"expected image [B,3,H,W] and features [B,C,h,w], got {tuple(image.shape)} / {tuple(features.shape)}")
         fuse_for = None
-        if not return_weights and features.shape[1] % self.upsampler.num_heads == 0:
+        if features.shape[1] % self.upsampler.num_heads == 0:
             fuse_for = (features.shape[1] // self.upsampler.num_heads,
                         torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32)
         q5, k5, tabs = self.guidance_qk(image, features.shape[-2:], output_size, fuse_for=fuse_for)

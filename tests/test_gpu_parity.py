@@ -405,6 +405,20 @@ def test_rotate_on_load_equals_materialised_queries(dev, B, C, lr, out_sz, ksz, 
     assert_close(got, ref, 2e-2, 2e-2, "rotate-on-load vs oracle")
 
 
+@pytest.mark.parametrize("lr,out_sz,ksz", [((8, 8), (128, 128), 7), ((6, 5), (24, 30), 3), ((12, 12), (96, 192), 9)])
+def test_return_weights_from_the_mfma_kernel(dev, lr, out_sz, ksz):
+    """return_weights (attentions.py:27-28: scaled pre-softmax scores, row-major window order) straight from the MFMA
+    cell kernel: row-tile path (d = 16), generic tile path (d = 4 x 6) and a 9x9 window with pad slots."""
+    heads, C = 4, 64
+    q = bf16r(O.hash_normal((1, 256, *out_sz), 401))
+    k = bf16r(O.hash_normal((1, 256, *lr), 402))
+    v = bf16r(O.hash_normal((1, C, *lr), 403))
+    ref, ref_lg = O.xna(q, k, v, ksz, heads, return_logits=True)
+    out, lg = run_xna(dev, q, k, v, ksz, heads, path="mfma", return_logits=True)
+    assert_close(lg, ref_lg, 2e-5, 2e-5, "mfma logits")
+    assert_close(out, ref, 6e-3, 6e-3, "mfma out (with logits)")
+
+
 def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     from naf_amd import ops
     from naf_amd._lib import NafHipError
