@@ -60,20 +60,28 @@ def commit_ops(n, v):
               f"u32x4_t{{{co}[0], {co}[1], {co}[2], {co}[3]}};")
     return o
 
-PIECE_PLAN = [  # relative slot -> micro-op names
-    ["A0", "A1"], ["B0", "B1"], ["C0", "A2"], ["C1", "D0", "A3"], ["E0", "D1", "B2"], ["E1", "B3"],
-    ["C2", "F0"], ["C3", "F1", "D2"], ["E2", "D3"], ["E3", "F2"], ["F3"], ["G"],
-]
-COMMIT_BASE, COMMIT_STRIDE = 2, 11
+PLANS = {
+    # 12 rows, pieces pipelined every 11 slots (several rows carry a transcendental pair plus other work)
+    "dense": (11, [["A0", "A1"], ["B0", "B1"], ["C0", "A2"], ["C1", "D0", "A3"], ["E0", "D1", "B2"], ["E1", "B3"],
+                   ["C2", "F0"], ["C3", "F1", "D2"], ["E2", "D3"], ["E3", "F2"], ["F3"], ["G"]]),
+    # a transcendental pair (2 x 16 cycles) has its MFMA slot to itself
+    "lone": (14, [["A0", "A1"], ["B0", "B1"], ["C0"], ["C1"], ["D0", "D1", "A2", "A3"], ["E0"], ["E1"], ["B2", "B3", "F0"],
+                  ["C2"], ["C3"], ["F1", "D2", "D3"], ["E2"], ["E3"], ["F2", "F3"], ["G"]]),
+}
+PLAN = os.environ.get("NAF_STEM_PLAN", "dense")
+COMMIT_STRIDE, PIECE_PLAN = PLANS[PLAN]
+COMMIT_BASE = 2
 for n in range(NLD):
     o = commit_ops(n, n & 1)
     for r, names in enumerate(PIECE_PLAN):
         for nm in names:
             ops[COMMIT_BASE + COMMIT_STRIDE * n + r].append(("commit", o[nm]))
-last_commit_read = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + 3      # last A-stage of the last piece
+last_a = max(r for r, names in enumerate(PIECE_PLAN) if any(x.startswith("A") for x in names))
+last_commit_read = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + last_a      # last A-stage of the last piece
+last_commit = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + len(PIECE_PLAN) - 1
 
 # row stores of the previous output tile
-ST_BASE = 60
+ST_BASE = max(60, last_commit + 1)
 assert ST_BASE > last_commit_read
 for n in range(NST):
     ops[ST_BASE + 3 * n].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
