@@ -193,6 +193,39 @@ int naf_xna_select(const naf_xna_args* a);
 size_t naf_workspace_bytes(const naf_xna_args* a);
 int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
 
+/* ---- cross-scale neighbourhood attention backward --------------------------------------------------
+ * Replaces what autograd runs through legacy_attention (attentions.py:16-29: the backward of na2d_qk, the
+ * scale, the softmax and na2d_av) and through the K/V nearest-exact upsampling (attentions.py:60-61) in the
+ * reference's training step (train.py:127-137, test/backward_speed.py:22-69), on the low-res grid.
+ *   q, k_lr, v_lr   as in naf_xna_args (bf16, strides {b, head, y, x}, last dim contiguous)
+ *   dout   device bf16 [B, heads, Ho, Wo, Dv]   gradient of the output, strides {b, head, y, x}
+ *   dq     device bf16 [B, heads, Ho, Wo, Dq]   gradient of q, strides {b, head, y, x}
+ *   dk_lr  device float [B, h, w, heads, Dq] dense, dv_lr device float [B, h, w, heads, Dv] dense: the caller
+ *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
+ * Served shapes: what the MFMA forward serves with ky = kx <= 9, Wo/w a multiple of 16 and
+ * Dv in {32, 64, 96, 128, 192, 256}; NAF_ERR_UNSUPPORTED otherwise (naf_xna_bwd_supported tells in advance).
+ * scale <= 0 selects Dq^-0.5. */
+typedef struct naf_xna_bwd_args {
+    const void* q;
+    const void* k_lr;
+    const void* v_lr;
+    const void* dout;
+    void* dq;
+    float* dk_lr;
+    float* dv_lr;
+    int32_t B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx;
+    float scale;
+    int32_t reserved;
+    int64_t q_stride[4];
+    int64_t k_stride[4];
+    int64_t v_stride[4];
+    int64_t dout_stride[4];
+    int64_t dq_stride[4];
+} naf_xna_bwd_args;
+/* 1 when naf_xna_bwd serves these arguments, 0 when not, negative naf_status on invalid arguments. */
+int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
+int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,17 @@ class StemConvArgs(C.Structure):
     ]
 
 
+class XnaBwdArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k_lr", C.c_void_p), ("v_lr", C.c_void_p), ("dout", C.c_void_p), ("dq", C.c_void_p),
+        ("dk_lr", C.c_void_p), ("dv_lr", C.c_void_p),
+        ("B", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
+        ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
+        ("scale", C.c_float), ("reserved", C.c_int32),
+        ("q_stride", I64x4), ("k_stride", I64x4), ("v_stride", I64x4), ("dout_stride", I64x4), ("dq_stride", I64x4),
+    ]
+
+
 # symbol -> (restype, argtypes); must list every function include/naf_hip.h declares
 SIGNATURES = {
     "naf_version": (C.c_int, []),
@@ -75,6 +86,8 @@ SIGNATURES = {
     "naf_xna_select": (C.c_int, [C.POINTER(XnaArgs)]),
     "naf_workspace_bytes": (C.c_size_t, [C.POINTER(XnaArgs)]),
     "naf_xna_fwd": (C.c_int, [C.POINTER(XnaArgs), C.c_void_p]),
+    "naf_xna_bwd_supported": (C.c_int, [C.POINTER(XnaBwdArgs)]),
+    "naf_xna_bwd": (C.c_int, [C.POINTER(XnaBwdArgs), C.c_void_p]),
 }
 
 _lib = None

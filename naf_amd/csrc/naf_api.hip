@@ -181,4 +181,30 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream) {
     return naf_launch_xna_generic(a, scale, static_cast<hipStream_t>(stream));
 }
 
+static int xna_bwd_validate(const naf_xna_bwd_args* a) {
+    NAF_REQUIRE(a != nullptr, "naf_xna_bwd: args is NULL");
+    NAF_REQUIRE(a->q && a->k_lr && a->v_lr && a->dout && a->dq && a->dk_lr && a->dv_lr, "naf_xna_bwd: NULL tensor pointer");
+    NAF_REQUIRE(a->B > 0 && a->heads > 0 && a->Ho > 0 && a->Wo > 0 && a->h > 0 && a->w > 0 && a->Dq > 0 && a->Dv > 0,
+                "naf_xna_bwd: non-positive size");
+    NAF_REQUIRE(a->ky > 0 && a->kx > 0 && (a->ky & 1) && (a->kx & 1), "naf_xna_bwd: kernel size must be odd, got %dx%d", a->ky, a->kx);
+    NAF_REQUIRE(a->Ho >= a->h && a->Wo >= a->w, "naf_xna_bwd: output %dx%d smaller than feature grid %dx%d (dilation 0)", a->Ho, a->Wo, a->h, a->w);
+    NAF_REQUIRE((int64_t)a->ky * (a->Ho / a->h) <= a->Ho && (int64_t)a->kx * (a->Wo / a->w) <= a->Wo,
+                "naf_xna_bwd: kernel_size * dilation exceeds the output extent (k=%dx%d, dilation=%dx%d, out=%dx%d)",
+                a->ky, a->kx, a->Ho / a->h, a->Wo / a->w, a->Ho, a->Wo);
+    return NAF_OK;
+}
+
+int naf_xna_bwd_supported(const naf_xna_bwd_args* a) {
+    const int rc = xna_bwd_validate(a);
+    if (rc != NAF_OK) return -rc;
+    return naf_xna_bwd_eligible(a);
+}
+
+int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
+    const int rc = xna_bwd_validate(a);
+    if (rc != NAF_OK) return rc;
+    const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
+    return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

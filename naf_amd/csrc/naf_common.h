@@ -33,6 +33,8 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s);     
 int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out);  // xna_mfma.hip
 int naf_xna_mfma_rope_ok(const naf_xna_args* a);                                   // xna_mfma.hip
 int naf_launch_xna_generic(const naf_xna_args* a, float scale, hipStream_t s);   // xna_generic.hip
+int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);   // xna_bwd.hip
+int naf_xna_bwd_eligible(const naf_xna_bwd_args* a);                             // xna_bwd.hip
 int naf_launch_rope_tables(float* ty, float* tx, const float* periods, int np, int Ho, int Wo, hipStream_t s);
 int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);             // rope_pool.hip
 int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, int h, int w,
@@ -45,8 +47,6 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s);        
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
-// Bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD one contiguous
-// range of logical ids so neighbouring cells (which share K/V windows) meet in the same L2.
 // RoPE pair rotation (rope.py:15-34): one definition for naf_rope_pool_fwd and for the rotate-on-load of
 // naf_xna_fwd, so both round identically (explicit fma, the inner products are rounded on their own).
 __device__ __forceinline__ void naf_rope_rotate(float a, float b, float c, float s, float& o1, float& o2) {
@@ -54,6 +54,8 @@ __device__ __forceinline__ void naf_rope_rotate(float a, float b, float c, float
     o2 = __builtin_fmaf(b, c, a * s);
 }
 
+// Bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD one contiguous
+// range of logical ids so neighbouring cells (which share K/V windows) meet in the same L2.
 __device__ __forceinline__ uint32_t naf_xcd_remap(uint32_t bid, uint32_t n) {
     const uint32_t q = n >> 3, r = n & 7u, xcd = bid & 7u, idx = bid >> 3;
     const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;

@@ -1,0 +1,67 @@
+// Eligibility + dispatcher of the attention backward (see xna_bwd_kernel.h).
+#include "xna_bwd_kernel.h"
+
+#define NAF_DECL(K) int naf_xna_bwd_launch_k##K(const XnaBwdParams& p, int Dv, hipStream_t s);
+NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9)
+#undef NAF_DECL
+
+static bool bwd_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+// 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..9, Dq = 64, integer
+// ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0) and Dv in {32, 64, 96, 128, 192, 256}.
+int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
+    if (a->ky != a->kx) return 0;
+    const int ks = a->ky;
+    if (ks < 3 || ks > 9 || (ks & 1) == 0) return 0;
+    if (a->Dq != 64) return 0;
+    if (a->h < ks || a->w < ks) return 0;
+    if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
+    if ((a->Wo / a->w) % 16 != 0) return 0;
+    switch (a->Dv) {
+        case 32: case 64: case 96: case 128: case 192: case 256: break;
+        default: return 0;
+    }
+    if (!bwd_aligned(a->q) || !bwd_aligned(a->k_lr) || !bwd_aligned(a->v_lr) || !bwd_aligned(a->dout) || !bwd_aligned(a->dq)) return 0;
+    for (int i = 0; i < 4; ++i)
+        if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->dout_stride[i] % 8 || a->dq_stride[i] % 8) return 0;
+    return 1;
+}
+
+int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
+    if (!naf_xna_bwd_eligible(a)) {
+        naf_set_error(
+            "naf_xna_bwd: needs square odd kernel 3..9, Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
+            "Dv in {32,64,96,128,192,256} and 16-byte aligned tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
+            a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    XnaBwdParams p;
+    p.q = static_cast<const bf16_t*>(a->q);
+    p.k = static_cast<const bf16_t*>(a->k_lr);
+    p.v = static_cast<const bf16_t*>(a->v_lr);
+    p.dout = static_cast<const bf16_t*>(a->dout);
+    p.dq = static_cast<bf16_t*>(a->dq);
+    p.dk = a->dk_lr;
+    p.dv = a->dv_lr;
+    p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
+    p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
+    const int64_t nb = (int64_t)a->B * a->h * a->w * a->heads;
+    if (nb <= 0 || nb > 0x7fffffffLL) {
+        naf_set_error("naf_xna_bwd: grid of %lld workgroups out of range", (long long)nb);
+        return NAF_ERR_INVALID;
+    }
+    p.nblocks = (uint32_t)nb;
+    p.scale = scale;
+    p.scale_log2e = scale * 1.4426950408889634f;
+    for (int i = 0; i < 4; ++i) {
+        p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i];
+        p.gs[i] = a->dout_stride[i]; p.dqs[i] = a->dq_stride[i];
+    }
+    switch (a->ky) {
+        case 3: return naf_xna_bwd_launch_k3(p, a->Dv, s);
+        case 5: return naf_xna_bwd_launch_k5(p, a->Dv, s);
+        case 7: return naf_xna_bwd_launch_k7(p, a->Dv, s);
+        case 9: return naf_xna_bwd_launch_k9(p, a->Dv, s);
+    }
+    return NAF_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,4 @@
+// Instantiations of the attention backward cell kernel for kernel_size = 3.
+#include "xna_bwd_kernel.h"
+
+int naf_xna_bwd_launch_k3(const XnaBwdParams& p, int Dv, hipStream_t s) { return xna_bwd_launch_ks<3>(p, Dv, s); }

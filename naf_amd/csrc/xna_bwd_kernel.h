@@ -1,0 +1,364 @@
+// Cross-scale neighbourhood attention BACKWARD, MFMA cell kernel (gfx950 / CDNA4).
+//
+// Replaces what autograd runs through attentions.py:16-29 in the reference's training step (train.py:127-137,
+// test/backward_speed.py:22-69): the backward of na2d_qk -> *scale -> softmax -> na2d_av plus the backward of the
+// nearest-exact K/V upsampling (attentions.py:60-61), evaluated on the low-res grid like the forward
+// (xna_mfma_kernel.h): every query of low-res cell (cy, cx) shares one clamped KS x KS window.
+//
+//   S = scale q.k^T   P = softmax_keys(S)   O = P v
+//   dV[j] = sum_i P[i,j] dO[i]      dP[i,j] = dO[i].v[j]      delta[i] = sum_j P[i,j] dP[i,j]
+//   dS[i,j] = scale P[i,j] (dP[i,j] - delta[i])      dQ[i] = sum_j dS[i,j] k[j]      dK[j] = sum_i dS[i,j] q[i]
+//
+// One workgroup (4 waves) = one (batch, cell, head).  K and V windows live in LDS.  The cell's 16-query row tiles
+// are processed four at a time ("round", one tile per wave), in two phases:
+//   phase 1 (per wave, its tile): both operand orders of the same register fragments give S and dP twice --
+//     "swapped"  S^T[key][q]  = Kfrag x Qfrag,  dP^T = Vfrag x dOfrag : a lane owns one QUERY  -> softmax statistics,
+//                 delta and dS^T as the B operand of  dQ^T[d][q] = K^T[d][key] . dS^T[key][q]  (K^T by ds_read_tr);
+//     "straight" S[q][key]    = Qfrag x Kfrag,  dP    = dOfrag x Vfrag : a lane owns one KEY    -> P and dS in exactly
+//                 the register layout the A operand of a contraction over QUERIES needs (no transpose anywhere);
+//     P, dS (bf16x4 per lane per 16-key tile), Q and dO of the tile go to LDS.
+//   phase 2 (per wave, its slice of channels, all four tiles): dV[key][ch] += P^T . dO,  dK[key][d] += dS^T . Q with
+//     32 queries per MFMA (two tiles), Q / dO as B operands through ds_read_tr from their row-major LDS copies.
+//     Wave w accumulates channel tiles {w, w+4, ...} of dV and d-tile w of dK in registers for the whole cell.
+// At the end the cell's [KS*KS] x (64 + Dv) partial sums are added to the fp32 dK_lr / dV_lr accumulators with
+// atomics (a low-res key sits in up to KS*KS windows).
+#pragma once
+#include <type_traits>
+
+#include "naf_common.h"
+
+struct XnaBwdParams {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    const bf16_t* dout;
+    bf16_t* dq;
+    float* dk;   // [B, h, w, heads, 64] dense fp32 accumulator (pre-zeroed by the caller)
+    float* dv;   // [B, h, w, heads, Dv]
+    int32_t B, heads, Ho, Wo, h, w, dy, dx;
+    uint32_t nblocks;
+    float scale, scale_log2e;
+    int64_t qs[4], ks[4], vs[4], gs[4], dqs[4];  // {b, head, y, x} element strides (gs: dout)
+};
+
+template <int KS, int DV>
+struct XnaBwdGeom {
+    static constexpr int NSLOT = KS * KS;
+    static constexpr int KPAD = ((NSLOT + 31) / 32) * 32;
+    static constexpr int MT = KPAD / 16;      // 16-key tiles
+    static constexpr int KST = KPAD / 32;     // 32-key steps (dQ contraction)
+    static constexpr int KROW = 64 + 8;       // bf16 per K / Q row in LDS
+    static constexpr int VROW = DV + 8;       // bf16 per V / dO row in LDS
+    static constexpr int NVT = DV / 16;       // 16-channel tiles of dV
+    static constexpr int NVW = (NVT + 3) / 4; // ... per wave
+    static constexpr size_t lds_bytes() {
+        return (size_t)NSLOT * (KROW + VROW) * 2     // K, V windows
+               + 2 * (size_t)4 * MT * 64 * 8         // P, dS of the round (A-operand form)
+               + (size_t)4 * 16 * (KROW + VROW) * 2; // Q, dO of the round (row-major)
+    }
+};
+
+template <int KS, int DV>
+__global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
+    using G = XnaBwdGeom<KS, DV>;
+    constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
+    constexpr int DKS = DV / 32;   // 32-channel k-steps of the dP contraction
+    static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + NSLOT * KROW;
+    bf16x4_t* Pl = reinterpret_cast<bf16x4_t*>(Vs + NSLOT * VROW);   // [4 tiles][MT][64 lanes]
+    bf16x4_t* Sl = Pl + 4 * MT * 64;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(Sl + 4 * MT * 64);        // [4 tiles][16][KROW]
+    bf16_t* Gs = Qs + 4 * 16 * KROW;                                 // [4 tiles][16][VROW]  (dO)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+
+    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    const int head = L % p.heads;
+    L /= p.heads;
+    const int cx0 = L % p.w;
+    L /= p.w;
+    const int cy0 = L % p.h;
+    const int b = L / p.h;
+    const int y0 = min(max(cy0 - KS / 2, 0), p.h - KS), x0 = min(max(cx0 - KS / 2, 0), p.w - KS);
+
+    // ---- stage the K and V windows ----
+    {
+        const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
+        for (int i = tid; i < NSLOT * 8; i += 256) {
+            const int key = i >> 3, c = i & 7;
+            const int ry = key / KS, rx = key - ry * KS;
+            *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) =
+                *reinterpret_cast<const u32x4_t*>(kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)(x0 + rx) * p.ks[3] + c * 8);
+        }
+        const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1];
+        constexpr int VCH = DV / 8;
+        for (int i = tid; i < NSLOT * VCH; i += 256) {
+            const int key = i / VCH, c = i - key * VCH;
+            const int ry = key / KS, rx = key - ry * KS;
+            *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) =
+                *reinterpret_cast<const u32x4_t*>(vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)(x0 + rx) * p.vs[3] + c * 8);
+        }
+    }
+    __syncthreads();
+
+    // row tiles of the cell: tile t -> row ty = t / tpr, first column tx0 = (t % tpr) * 16   (dx % 16 == 0)
+    const int tpr = p.dx >> 4, ntile = p.dy * tpr;
+    const bf16_t* q_cell = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)(cy0 * p.dy) * p.qs[2] + (int64_t)(cx0 * p.dx) * p.qs[3];
+    const bf16_t* g_cell = p.dout + b * p.gs[0] + head * p.gs[1] + (int64_t)(cy0 * p.dy) * p.gs[2] + (int64_t)(cx0 * p.dx) * p.gs[3];
+    bf16_t* dq_cell = p.dq + b * p.dqs[0] + head * p.dqs[1] + (int64_t)(cy0 * p.dy) * p.dqs[2] + (int64_t)(cx0 * p.dx) * p.dqs[3];
+
+    // K / V rows this lane reads as an operand fragment: row mt*16 + col (pad slots clamp to the last real key)
+    auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
+    // K^T by ds_read_tr: rows blk*16 + grp*4 + (col>>2), 4 d's at (col&3)*4   (as V^T in the forward)
+    auto kt_of = [&](int blk) __attribute__((always_inline)) {
+        const int r = min(blk * 16 + grp * 4 + (col >> 2), NSLOT - 1);
+        return Ks + r * KROW + (col & 3) * 4;
+    };
+
+    f32x4_t accV[MT][NVW], accK[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        accK[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) accV[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+        // ================= phase 1: this wave's tile =================
+        const int t = t0 + wave;
+        const bool live = t < ntile;
+        const int tc = live ? t : ntile - 1;               // dead tiles compute on a real tile and contribute zeros
+        const int ty = tc / tpr, tx0 = (tc - ty * tpr) * 16;
+        const bf16_t* qp = q_cell + (int64_t)ty * p.qs[2] + (int64_t)(tx0 + col) * p.qs[3] + grp * 8;
+        const bf16_t* gp = g_cell + (int64_t)ty * p.gs[2] + (int64_t)(tx0 + col) * p.gs[3] + grp * 8;
+        bf16x8_t qf[2], gf[DKS];
+        qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+        qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) gf[ks] = *reinterpret_cast<const bf16x8_t*>(gp + ks * 32);
+        // row-major LDS copies for phase 2 (B operands through ds_read_tr)
+        {
+            bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
+            *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
+            *reinterpret_cast<bf16x8_t*>(qrow + 32) = qf[1];
+            bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
+        }
+
+        // S^T, dP^T (lane = query) and S, dP (lane = key) from the same fragments
+        f32x4_t sT[MT], gT[MT], sS[MT], gS[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            sT[mt] = gT[mt] = sS[mt] = gS[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sT[mt], 0, 0, 0);
+                sS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sS[mt], 0, 0, 0);
+            }
+            const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+                gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], gT[mt], 0, 0, 0);
+                gS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ks], vf, gS[mt], 0, 0, 0);
+            }
+        }
+
+        // ---- lane = query: softmax statistics, delta, dS^T ----
+        float m = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (mt * 16 + 15 >= NSLOT) sT[mt][r] = (mt * 16 + grp * 4 + r < NSLOT) ? sT[mt][r] : -INFINITY;
+                m = fmaxf(m, sT[mt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mc = m * p.scale_log2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sT[mt][r], p.scale_log2e, -mc));
+                sT[mt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        float delta = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sT[mt][r] *= inv;                       // P^T
+                delta = fmaf(sT[mt][r], gT[mt][r], delta);
+            }
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);
+        // dS^T = scale * P (dP - delta), packed as the B operand of dQ^T = K^T . dS^T  (k order as the forward's P)
+        bf16x8_t dsf[KST];
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int mt = 2 * ks + (j >> 2), r = j & 3;
+                dsf[ks][j] = (bf16_t)(p.scale * sT[mt][r] * (gT[mt][r] - delta));
+            }
+
+        // ---- dQ^T[d][q] = K^T . dS^T : lane (q, grp) gets 4 consecutive d per 16-d tile; pairs -> 16-byte stores ----
+        if (live) {
+            bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
+#pragma unroll
+            for (int ct = 0; ct < 4; ct += 2) {
+                f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    bf16x8_t k0, k1;
+                    {
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16));
+                        k0[0] = lo[0]; k0[1] = lo[1]; k0[2] = lo[2]; k0[3] = lo[3];
+                        k0[4] = hi[0]; k0[5] = hi[1]; k0[6] = hi[2]; k0[7] = hi[3];
+                    }
+                    {
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16 + 16));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16 + 16));
+                        k1[0] = lo[0]; k1[1] = lo[1]; k1[2] = lo[2]; k1[3] = lo[3];
+                        k1[4] = hi[0]; k1[5] = hi[1]; k1[6] = hi[2]; k1[7] = hi[3];
+                    }
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, dsf[ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, dsf[ks], a1, 0, 0, 0);
+                }
+                bf16x4_t ab, bb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ab[i] = (bf16_t)a0[i];
+                    bb[i] = (bf16_t)a1[i];
+                }
+                const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+            }
+        }
+
+        // ---- lane = key: P and dS in A-operand form for the contractions over queries ----
+        {
+            // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout
+            float mcq[4], invq[4], dlq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mcq[r] = __shfl(mc, grp * 4 + r);
+                invq[r] = __shfl(inv, grp * 4 + r);
+                dlq[r] = __shfl(delta, grp * 4 + r);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool kvalid = live && (mt * 16 + col < NSLOT);
+                bf16x4_t pk, sk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sS[mt][r], p.scale_log2e, -mcq[r])) * invq[r] : 0.f;
+                    pk[r] = (bf16_t)pr;
+                    sk[r] = (bf16_t)(p.scale * pr * (gS[mt][r] - dlq[r]));
+                }
+                Pl[(wave * MT + mt) * 64 + lane] = pk;
+                Sl[(wave * MT + mt) * 64 + lane] = sk;
+            }
+        }
+        __syncthreads();
+
+        // ================= phase 2: this wave's channel slice over the round's four tiles =================
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // B operands: queries 4*grp..+3 of tiles 2pr / 2pr+1 for column (16-wide tile nt, col)
+            auto tr_pair = [&](const bf16_t* base, int rowlen, int nt) __attribute__((always_inline)) {
+                const bf16_t* a = base + ((2 * pr) * 16 + grp * 4 + (col >> 2)) * rowlen + (col & 3) * 4 + nt * 16;
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a);
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(a + 16 * rowlen));
+                bf16x8_t o;
+                o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+                o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+                return o;
+            };
+            const bf16x8_t bq = tr_pair(Qs, KROW, wave);
+            bf16x8_t bg[NVW];
+#pragma unroll
+            for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, min(wave + 4 * i, NVT - 1));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x4_t p0 = Pl[((2 * pr) * MT + mt) * 64 + lane], p1 = Pl[((2 * pr + 1) * MT + mt) * 64 + lane];
+                const bf16x4_t s0 = Sl[((2 * pr) * MT + mt) * 64 + lane], s1 = Sl[((2 * pr + 1) * MT + mt) * 64 + lane];
+                bf16x8_t pa, sa;
+                pa[0] = p0[0]; pa[1] = p0[1]; pa[2] = p0[2]; pa[3] = p0[3];
+                pa[4] = p1[0]; pa[5] = p1[1]; pa[6] = p1[2]; pa[7] = p1[3];
+                sa[0] = s0[0]; sa[1] = s0[1]; sa[2] = s0[2]; sa[3] = s0[3];
+                sa[4] = s1[0]; sa[5] = s1[1]; sa[6] = s1[2]; sa[7] = s1[3];
+                accK[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, bq, accK[mt], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NVW; ++i)
+                    if (wave + 4 * i < NVT) accV[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, bg[i], accV[mt][i], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the round's LDS buffers are free again
+    }
+
+    // ---- the cell's partial sums -> fp32 accumulators.  acc[mt][r] is key mt*16 + grp*4 + r, column col ----
+    float* dkb = p.dk + (((int64_t)b * p.h) * p.w * p.heads + head) * 64;
+    float* dvb = p.dv + (((int64_t)b * p.h) * p.w * p.heads + head) * DV;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = mt * 16 + grp * 4 + r;
+            if (key < NSLOT) {
+                const int ry = key / KS, rx = key - ry * KS;
+                const int64_t cell = (int64_t)(y0 + ry) * p.w + (x0 + rx);
+                atomicAdd(dkb + cell * p.heads * 64 + wave * 16 + col, accK[mt][r]);
+#pragma unroll
+                for (int i = 0; i < NVW; ++i)
+                    if (wave + 4 * i < NVT) atomicAdd(dvb + cell * p.heads * DV + (wave + 4 * i) * 16 + col, accV[mt][i][r]);
+            }
+        }
+}
+
+template <int KS, int DV>
+static int xna_bwd_launch_one(const XnaBwdParams& p, hipStream_t s) {
+    constexpr size_t lds = XnaBwdGeom<KS, DV>::lds_bytes();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = xna_bwd_kernel<KS, DV>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+            return NAF_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, s, p);
+    return naf_check_launch("xna_bwd_kernel");
+}
+
+template <int KS>
+static int xna_bwd_launch_ks(const XnaBwdParams& p, int Dv, hipStream_t s) {
+    switch (Dv) {
+        case 32: return xna_bwd_launch_one<KS, 32>(p, s);
+        case 64: return xna_bwd_launch_one<KS, 64>(p, s);
+        case 96: return xna_bwd_launch_one<KS, 96>(p, s);
+        case 128: return xna_bwd_launch_one<KS, 128>(p, s);
+        case 192: return xna_bwd_launch_one<KS, 192>(p, s);
+        case 256: return xna_bwd_launch_one<KS, 256>(p, s);
+    }
+    naf_set_error("naf_xna_bwd: no kernel for Dv = %d (32, 64, 96, 128, 192, 256)", Dv);
+    return NAF_ERR_UNSUPPORTED;
+}

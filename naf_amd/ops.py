@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import XnaArgs, RopePoolArgs, StemConv0Args, StemConvArgs, I64x3, I64x4
+from ._lib import XnaArgs, XnaBwdArgs, RopePoolArgs, StemConv0Args, StemConvArgs, I64x3, I64x4
 
 _DT = {torch.bfloat16: _lib.NAF_BF16, torch.float32: _lib.NAF_F32}
 
@@ -267,6 +267,75 @@ def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_
         rc = lib.naf_xna_fwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_fwd")
     return (out, logits) if return_logits else out
+
+
+def _fill_xna_bwd(q, k, v, dout, dq, dk, dv, ky, kx, scale) -> XnaBwdArgs:
+    B, heads, Ho, Wo, Dq = q.shape
+    _, _, h, w, Dv = v.shape
+    a = XnaBwdArgs()
+    a.q, a.k_lr, a.v_lr, a.dout, a.dq = q.data_ptr(), k.data_ptr(), v.data_ptr(), dout.data_ptr(), dq.data_ptr()
+    a.dk_lr, a.dv_lr = dk.data_ptr(), dv.data_ptr()
+    a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx
+    a.scale = float(scale) if scale else 0.0
+    a.q_stride, a.k_stride, a.v_stride = _strides4(q, (0, 1, 2, 3)), _strides4(k, (0, 1, 2, 3)), _strides4(v, (0, 1, 2, 3))
+    a.dout_stride, a.dq_stride = _strides4(dout, (0, 1, 2, 3)), _strides4(dq, (0, 1, 2, 3))
+    return a
+
+
+def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> bool:
+    """True when ``xna_backward`` has a kernel for these shapes (see naf_xna_bwd in include/naf_hip.h)."""
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    a = _fill_xna_bwd(q, k_lr, v_lr, q, q, q, q, ky, kx, None)      # shape / alignment query only
+    B, heads, Ho, Wo, Dq = q.shape
+    Dv = v_lr.shape[-1]
+    a.dout_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    a.dq_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
+    return lib.naf_xna_bwd_supported(C.byref(a)) == 1
+
+
+def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: torch.Tensor, kernel_size, *,
+                 scale: Optional[float] = None):
+    """Gradients of ``xna_forward`` w.r.t. q, k_lr, v_lr given ``dout`` (5-D [B, heads, Ho, Wo, Dv], any strides with
+    Dv contiguous; cast to bf16).  Returns (dq bf16 [B,heads,Ho,Wo,Dq] view of a channels-last buffer,
+    dk_lr fp32 [B,heads,h,w,Dq] view, dv_lr fp32 [B,heads,h,w,Dv] view)."""
+    for t, n in ((q, "q"), (k_lr, "k_lr"), (v_lr, "v_lr")):
+        _gpu(t, n)
+        if t.dtype != torch.bfloat16 or t.dim() != 5 or t.stride(4) != 1:
+            raise TypeError(f"xna_backward: {n} must be a bfloat16 5-D [B, heads, H, W, D] view with D contiguous")
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    B, heads, Ho, Wo, Dq = q.shape
+    _, _, h, w, Dv = v_lr.shape
+    if tuple(dout.shape) != (B, heads, Ho, Wo, Dv):
+        raise ValueError(f"xna_backward: dout shape {tuple(dout.shape)} != {(B, heads, Ho, Wo, Dv)}")
+    if dout.dtype != torch.bfloat16 or dout.stride(4) != 1:
+        dout = dout.permute(0, 2, 3, 1, 4).to(torch.bfloat16).contiguous().permute(0, 3, 1, 2, 4)
+    dev = q.device
+    dq = torch.empty((B, Ho, Wo, heads, Dq), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
+    dk = torch.zeros((B, h, w, heads, Dq), dtype=torch.float32, device=dev)
+    dv = torch.zeros((B, h, w, heads, Dv), dtype=torch.float32, device=dev)
+    a = _fill_xna_bwd(q, k_lr, v_lr, dout, dq, dk, dv, ky, kx, scale)
+    with torch.cuda.device(dev), _Timed("xna_bwd"):
+        rc = lib.naf_xna_bwd(C.byref(a), _stream(q))
+    _lib.check(rc, "naf_xna_bwd")
+    return dq, dk.permute(0, 3, 1, 2, 4), dv.permute(0, 3, 1, 2, 4)
+
+
+class XnaFunction(torch.autograd.Function):
+    """Differentiable ``xna_forward`` (MFMA path): forward = naf_xna_fwd, backward = naf_xna_bwd."""
+
+    @staticmethod
+    def forward(ctx, q, k_lr, v_lr, kernel_size, scale, out_dtype):
+        ctx.save_for_backward(q, k_lr, v_lr)
+        ctx.kernel_size, ctx.scale = kernel_size, scale
+        return xna_forward(q, k_lr, v_lr, kernel_size, out_dtype=out_dtype, path="mfma", scale=scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k_lr, v_lr = ctx.saved_tensors
+        dq, dk, dv = xna_backward(q, k_lr, v_lr, dout, ctx.kernel_size, scale=ctx.scale)
+        return dq, dk.to(k_lr.dtype), dv.to(v_lr.dtype), None, None, None
 
 
 def xna_rope_fusable(q: torch.Tensor, lr_size, Dv: int, kernel_size, rope_tables, out_dtype=torch.bfloat16,

@@ -344,3 +344,16 @@ def naf_forward_fast(p: Dict[str, Tensor], image: Tensor, features: Tensor, outp
     x = image_encoder(image, out_size, p, heads_rope)
     k = key_pool(x, features.shape[-2:])
     return xna_lowres(x, k, features, kernel_size, heads_attn)
+
+
+# --------------------------------------------------------------------------------------------
+# backward of a8 (what autograd computes through attentions.py:16-29 + :60-61 in train.py:127-137)
+# --------------------------------------------------------------------------------------------
+def xna_backward(q: Tensor, k_lr: Tensor, v_lr: Tensor, dout: Tensor, kernel_size: int, heads: int):
+    """(dq, dk_lr, dv_lr) of ``xna(q, k_lr, v_lr)`` for the output gradient ``dout``: torch autograd through the
+    restated forward (fp64 for a clean reference).  The forward restatement is pinned against the imported
+    reference (tests/golden); its derivative is exact calculus, not a second restatement."""
+    qd, kd, vd = (t.detach().to(torch.float64).requires_grad_(True) for t in (q, k_lr, v_lr))
+    out = xna(qd, kd, vd, kernel_size, heads)
+    out.backward(dout.to(torch.float64))
+    return qd.grad.to(torch.float32), kd.grad.to(torch.float32), vd.grad.to(torch.float32)

@@ -434,6 +434,51 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
         ops.xna_forward(q_raw, k5, v5, 3, rope_tables=(ty, tx))
 
 
+@pytest.mark.parametrize("B,C,lr,out_sz,ksz", [
+    (1, 256, (8, 8), (128, 128), 7),       # Dv = 64, d = 16: four row tiles per wave round, full rounds
+    (2, 128, (5, 6), (40, 96), 3),         # Dv = 32, d = (8, 16): 8 tiles per cell, non-square grid
+    (1, 768, (7, 7), (7, 112), 7),         # Dv = 192, dy = 1: one tile per cell (three dead waves per round), k = h = w
+    (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
+])
+def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
+    """naf_xna_bwd vs autograd through the oracle's forward, same bf16-rounded q, k, v and output gradient."""
+    from naf_amd import ops
+    heads = 4
+    q = bf16r(O.hash_normal((B, 256, *out_sz), 501))
+    k = bf16r(O.hash_normal((B, 256, *lr), 502))
+    v = bf16r(O.hash_normal((B, C, *lr), 503))
+    dout = bf16r(O.hash_normal((B, C, *out_sz), 504))
+    rq, rk, rv = O.xna_backward(q, k, v, dout, ksz, heads)
+    q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, dout))
+    assert ops.xna_backward_supported(q5, k5, v5, ksz)
+    dq, dk, dv = ops.xna_backward(q5, k5, v5, g5, ksz)
+    back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
+    # dS and P pass through bf16 (relative 2^-8) before the contractions; sums of up to d^2 * k^2 terms
+    for got, ref, name in ((back(dq), rq, "dq"), (back(dk), rk, "dk"), (back(dv), rv, "dv")):
+        scale = float(ref.abs().max())
+        err = (got - ref).abs()
+        assert float(err.max()) <= 2e-2 * scale + 1e-3 and float(err.mean()) <= 3e-3 * scale + 1e-4, \
+            f"{name}: max err {float(err.max()):.3e} mean {float(err.mean()):.3e} (ref max {scale:.3e})"
+
+
+def test_xna_autograd_function(dev):
+    """ops.XnaFunction: torch autograd drives naf_xna_fwd / naf_xna_bwd."""
+    from naf_amd import ops
+    heads, ksz = 4, 5
+    k = bf16r(O.hash_normal((1, 256, 6, 6), 512))
+    q = bf16r(O.hash_normal((1, 256, 96, 96), 511))
+    v = bf16r(O.hash_normal((1, 128, 6, 6), 513))
+    q5, k5, v5 = (to5(t, heads).to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.XnaFunction.apply(q5, k5, v5, ksz, None, torch.float32)
+    w = to5(O.hash_normal((1, 128, 96, 96), 514), heads).to(dev).float()
+    (out * w).sum().backward()
+    rq, rk, rv = O.xna_backward(q, k, v, bf16r(O.hash_normal((1, 128, 96, 96), 514)), ksz, heads)
+    back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
+    for got, ref, name in ((back(q5.grad), rq, "dq"), (back(k5.grad), rk, "dk"), (back(v5.grad), rv, "dv")):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 3e-2 * scale + 1e-3, name
+
+
 def test_heads_rope_differs_from_heads_attn(dev):
     p = O.make_params(dim=64, heads_rope=1, seed=8)
     m = _load_model(dev, p, dim=64, heads_attn=4, heads_rope=1, kernel_size=3)

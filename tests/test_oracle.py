@@ -157,3 +157,27 @@ def test_natten_preconditions_raise():
         O.axis_index_table(20, 5, 7)      # 7 * 4 > 20
     with pytest.raises(ValueError):
         O.axis_index_table(4, 8, 3)       # dilation 0
+
+
+def test_xna_backward_matches_finite_differences():
+    """oracle.xna_backward (autograd through the restated forward) against central differences of the forward."""
+    torch.manual_seed(0)
+    heads, ks = 2, 3
+    q = torch.randn(1, 2 * 8, 8, 8, dtype=torch.float64)
+    k = torch.randn(1, 2 * 8, 4, 4, dtype=torch.float64)
+    v = torch.randn(1, 2 * 4, 4, 4, dtype=torch.float64)
+    dout = torch.randn(1, 2 * 4, 8, 8, dtype=torch.float64)
+    dq, dk, dv = O.xna_backward(q, k, v, dout, ks, heads)
+    f = lambda qq, kk, vv: float((O.xna(qq, kk, vv, ks, heads) * dout).sum())
+    eps = 1e-5
+    gen = torch.Generator().manual_seed(1)
+    for t, g, name in ((q, dq, "dq"), (k, dk, "dk"), (v, dv, "dv")):
+        for _ in range(6):
+            idx = tuple(int(torch.randint(0, n, (1,), generator=gen)) for n in t.shape)
+            tp, tm = t.clone(), t.clone()
+            tp[idx] += eps
+            tm[idx] -= eps
+            args_p = [tp if x is t else x for x in (q, k, v)]
+            args_m = [tm if x is t else x for x in (q, k, v)]
+            fd = (f(*args_p) - f(*args_m)) / (2 * eps)
+            assert abs(fd - float(g[idx])) <= 1e-5 + 1e-4 * abs(fd), (name, idx, fd, float(g[idx]))
