@@ -269,6 +269,46 @@ class NAF(nn.Module):
             k5 = k5.permute(0, 2, 3, 1, 4).reshape(B, h, w, heads_attn, dim // heads_attn).permute(0, 3, 1, 2, 4)
         return q5, k5, None
 
+    def forward_train(self, image, features, output_size):
+        """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
+        and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
+        ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
+        differentiate them (the fused inference stem has no backward).  Deterministic eval-mode RoPE coordinates
+        (the reference's train-time coordinate jitter, rope.py:107-124, is not implemented).  Needs the shapes
+        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9)."""
+        if not (image.is_cuda and features.is_cuda):
+            raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback)")
+        enc = self.image_encoder
+        ho, wo = int(output_size[0]), int(output_size[1])
+        h, w = features.shape[-2:]
+        heads_rope, heads = enc.rope.num_heads, self.upsampler.num_heads
+        x = image
+        if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
+            x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
+                              mode="bilinear", align_corners=False)
+        if enc.use_encoder:
+            x = x.float().contiguous(memory_format=torch.channels_last)
+            x = torch.cat([enc._branch(x, enc.encoder, torch.float32), enc._branch(x, enc.sem_encoder, torch.float32)], dim=1)
+        if x.shape[-2:] != (ho, wo):
+            x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
+        # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
+        tab_y, tab_x = enc.rope.tables(ho, wo)                                 # [Ho, 2, P], [Wo, 2, P]
+        B, Cq = x.shape[:2]
+        D = Cq // heads_rope
+        cos = torch.cat([tab_y[:, 0, None, :].expand(ho, wo, -1), tab_x[None, :, 0, :].expand(ho, wo, -1)], dim=-1)
+        sin = torch.cat([tab_y[:, 1, None, :].expand(ho, wo, -1), tab_x[None, :, 1, :].expand(ho, wo, -1)], dim=-1)
+        xh = x.reshape(B, heads_rope, D, ho, wo).permute(0, 1, 3, 4, 2)        # [B, n, Ho, Wo, D]
+        x1, x2 = xh[..., : D // 2], xh[..., D // 2:]
+        xr = torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
+        xr = xr.permute(0, 1, 4, 2, 3).reshape(B, Cq, ho, wo)
+        k = F.adaptive_avg_pool2d(xr, output_size=(h, w))                      # naf.py:63-69 (pooled AFTER RoPE)
+        Dq, C = Cq // heads, features.shape[1]
+        to5 = lambda t, d: t.reshape(B, heads, d, *t.shape[-2:]).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
+        q5, k5, v5 = to5(xr, Dq), to5(k, Dq), to5(features, C // heads)
+        out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
+        out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
+        return out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
+
     @torch.no_grad()
     def forward(self, image, features, output_size, return_weights=False, *args, **kwargs):
         if not (image.is_cuda and features.is_cuda):

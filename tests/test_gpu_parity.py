@@ -479,6 +479,40 @@ def test_xna_autograd_function(dev):
         assert float((got - ref).abs().max()) <= 3e-2 * scale + 1e-3, name
 
 
+def test_forward_train_gradients_match_oracle(dev):
+    """NAF.forward_train: loss gradients w.r.t. encoder parameters and features vs autograd through the oracle."""
+    p = O.make_params(seed=21)
+    m = _load_model(dev, p, kernel_size=3)
+    img = O.hash_normal((1, 3, 48, 48), 521)
+    ft = O.hash_normal((1, 128, 3, 3), 522)
+    wgt = O.hash_normal((1, 128, 48, 48), 523)
+    # oracle: fp32 autograd
+    po = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "periods" not in k) for k, v in p.items()}
+    fo = ft.clone().requires_grad_(True)
+    (O.naf_forward(po, img, fo, (48, 48), kernel_size=3) * wgt).sum().backward()
+    # HIP attention fwd + bwd, torch stem
+    for prm in m.parameters():
+        prm.requires_grad_(True)
+    fd = ft.to(dev).requires_grad_(True)
+    out = m.forward_train(img.to(dev), fd, (48, 48))
+    (out.float() * wgt.to(dev)).sum().backward()
+    ref_out = O.naf_forward(p, img, ft, (48, 48), kernel_size=3)
+    assert_close(out.float().cpu(), ref_out, 6e-2, 3e-2, "forward_train output")
+    checked = 0
+    for name, prm in m.named_parameters():
+        ref = po[name].grad
+        if ref is None:
+            continue
+        got = prm.grad.float().cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 5e-2 * scale + 1e-3, f"{name}: grad err {err:.3e} vs max {scale:.3e}"
+        checked += 1
+    assert checked >= 20
+    gs = float(fo.grad.abs().max())
+    assert float((fd.grad.float().cpu() - fo.grad).abs().max()) <= 3e-2 * gs + 1e-3
+
+
 def test_heads_rope_differs_from_heads_attn(dev):
     p = O.make_params(dim=64, heads_rope=1, seed=8)
     m = _load_model(dev, p, dim=64, heads_attn=4, heads_rope=1, kernel_size=3)
