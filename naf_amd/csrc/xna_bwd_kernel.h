@@ -128,19 +128,26 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
         for (int i = 0; i < NVW; ++i) accV[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
+    // fragments of tile tt (clamped): a lane's 16 query dims / Dv/4 gradient channels of its query
+    auto load_tile = [&](int tt, bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
+        const int tcc = min(tt, ntile - 1);
+        const int tyy = tcc / tpr, txx = (tcc - tyy * tpr) * 16;
+        const bf16_t* qp = q_cell + (int64_t)tyy * p.qs[2] + (int64_t)(txx + col) * p.qs[3] + grp * 8;
+        const bf16_t* gp = g_cell + (int64_t)tyy * p.gs[2] + (int64_t)(txx + col) * p.gs[3] + grp * 8;
+        qv[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+        qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + ks * 32);
+    };
+    bf16x8_t qf[2], gf[DKS];
+    load_tile(wave, qf, gf);
+
     for (int t0 = 0; t0 < ntile; t0 += 4) {
         // ================= phase 1: this wave's tile =================
         const int t = t0 + wave;
         const bool live = t < ntile;
         const int tc = live ? t : ntile - 1;               // dead tiles compute on a real tile and contribute zeros
         const int ty = tc / tpr, tx0 = (tc - ty * tpr) * 16;
-        const bf16_t* qp = q_cell + (int64_t)ty * p.qs[2] + (int64_t)(tx0 + col) * p.qs[3] + grp * 8;
-        const bf16_t* gp = g_cell + (int64_t)ty * p.gs[2] + (int64_t)(tx0 + col) * p.gs[3] + grp * 8;
-        bf16x8_t qf[2], gf[DKS];
-        qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-        qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-#pragma unroll
-        for (int ks = 0; ks < DKS; ++ks) gf[ks] = *reinterpret_cast<const bf16x8_t*>(gp + ks * 32);
         // row-major LDS copies for phase 2 (B operands through ds_read_tr)
         {
             bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
@@ -278,6 +285,9 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
             }
         }
         __syncthreads();
+        // next round's fragments travel during phase 2 (the phase-1 registers are dead by now)
+        load_tile(t0 + 4 + wave, qf, gf);
+        __builtin_amdgcn_sched_barrier(0);
 
         // ================= phase 2: this wave's channel slice over the round's four tiles =================
 #pragma unroll
