@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
     ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
+    ap.add_argument("--no-fuse-conv0", action="store_true", help="store the 1x1 branch's conv0 activation (A/B against recompute)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +141,7 @@ def main():
     torch.manual_seed(0)                                        # same random-init weights on every rank...
     model = NAF(kernel_size=ksz).to(dev).eval()
     model.fuse_rope = not args.no_fuse_rope
+    model.image_encoder.fuse_conv0 = not args.no_fuse_conv0
     if world > 1:
         nd.broadcast_parameters(model, src=0)                   # ...and made identical by one RCCL broadcast
     g = torch.Generator(device=dev).manual_seed(1000 + rank)    # each rank owns different images

@@ -99,27 +99,34 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_conv0_fwd: args is NULL");
-    NAF_REQUIRE(a->image && a->y && a->weight && a->bias && a->stats_out, "naf_stem_conv0_fwd: NULL pointer");
+    NAF_REQUIRE(a->image && a->weight && a->bias && a->stats_out, "naf_stem_conv0_fwd: NULL pointer");   // y may be NULL: statistics only
     NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_conv0_fwd: kernel size %d (1 or 3)", a->ksize);
     NAF_REQUIRE(a->image_dtype == NAF_BF16 || a->image_dtype == NAF_F32, "naf_stem_conv0_fwd: image_dtype %d", a->image_dtype);
     NAF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "naf_stem_conv0_fwd: non-positive size");
     // reflect padding needs pad < extent, like torch's ReflectionPad
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv0_fwd: reflect padding needs H, W >= 2");
-    NAF_REQUIRE(al16(a->y) && a->y_stride[0] % 8 == 0 && a->y_stride[1] % 8 == 0 && a->y_stride[2] % 8 == 0,
+    NAF_REQUIRE(a->y == nullptr || (al16(a->y) && a->y_stride[0] % 8 == 0 && a->y_stride[1] % 8 == 0 && a->y_stride[2] % 8 == 0),
                 "naf_stem_conv0_fwd: output must be 16-byte aligned with strides multiple of 8");
     return naf_launch_stem_conv0(a, static_cast<hipStream_t>(stream));
 }
 
 int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_conv_fwd: args is NULL");
-    NAF_REQUIRE(a->x && a->y && a->w_packed && a->bias && a->gn_weight && a->gn_bias && a->stats_in,
+    NAF_REQUIRE((a->x || a->first) && a->y && a->w_packed && a->bias && a->gn_weight && a->gn_bias && a->stats_in,
                 "naf_stem_conv_fwd: NULL pointer");
+    if (a->first != nullptr) {
+        const naf_stem_conv0_args* f = a->first;
+        NAF_REQUIRE(a->ksize == 1 && f->ksize == 1, "naf_stem_conv_fwd: `first` (recomputed conv0 input) exists for the 1x1 branch only");
+        NAF_REQUIRE(f->image && f->weight && f->bias, "naf_stem_conv_fwd: first: NULL pointer");
+        NAF_REQUIRE(f->image_dtype == NAF_BF16 || f->image_dtype == NAF_F32, "naf_stem_conv_fwd: first: image_dtype %d", f->image_dtype);
+        NAF_REQUIRE(f->B == a->B && f->H == a->H && f->W == a->W, "naf_stem_conv_fwd: first: image size differs from the layer's");
+    }
     NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_conv_fwd: kernel size %d (1 or 3)", a->ksize);
     NAF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "naf_stem_conv_fwd: non-positive size");
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv_fwd: reflect padding needs H, W >= 2");
-    NAF_REQUIRE(al16(a->x) && al16(a->y) && al16(a->w_packed), "naf_stem_conv_fwd: tensors must be 16-byte aligned");
+    NAF_REQUIRE((a->first || al16(a->x)) && al16(a->y) && al16(a->w_packed), "naf_stem_conv_fwd: tensors must be 16-byte aligned");
     for (int i = 0; i < 3; ++i)
-        NAF_REQUIRE(a->x_stride[i] % 8 == 0 && a->y_stride[i] % 8 == 0, "naf_stem_conv_fwd: strides must be multiples of 8 elements");
+        NAF_REQUIRE((a->first || a->x_stride[i] % 8 == 0) && a->y_stride[i] % 8 == 0, "naf_stem_conv_fwd: strides must be multiples of 8 elements");
     // 1x1 layers are HBM-bound (independent-wave kernel); 3x3 layers are MFMA-bound (weight-stationary strips)
     if (a->ksize == 1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream));

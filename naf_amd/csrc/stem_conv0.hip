@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
                     const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
                     s1p[m * 2 + (j >> 1)] += w0 + w1;
                     s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
-                    *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
+                    if (p.y != nullptr) *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
                 }
             }
         }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int pp = it * 4 + psub;
-            if (x0 + pp < p.W) {
+            if (p.y != nullptr && x0 + pp < p.W) {
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + pp * OPX + chk * 8);
                 *reinterpret_cast<u32x4_t*>(yr + (int64_t)it * 8 * p.ys[2] + st_lane) = v;
             }

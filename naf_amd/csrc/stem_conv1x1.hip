@@ -28,26 +28,37 @@ struct StemConv1Params {
     int32_t groups_per_image;  // ceil(H*W / 32)
     float eps;
     int64_t xs[3], ys[3];
+    // IMG variant: the input is bf16(conv0_1x1(image)) recomputed per 32-pixel group
+    const void* img;
+    const float* w0;   // [128][3]
+    const float* b0;   // [128]
+    int64_t ibs;       // image batch stride
+    int32_t is[4];     // {unused, c, y, x} element strides (< 2^31, validated by the launcher)
 };
 
 namespace {
 constexpr int C1 = 128, WROW = C1 + 8, OROW1 = C1 + 8;
+#ifndef NAF_C1X1_NW
+#define NAF_C1X1_NW 4
+#endif
+constexpr int NW1 = NAF_C1X1_NW;   // waves per workgroup: they share one LDS copy of the weights; 4 waves x 2 workgroups per CU measured faster than 12 x 1 (0.119 vs 0.128 ms): the layer is VALU/transcendental-bound, not latency-bound
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Params p) {
+template <bool IMG, typename T>
+__global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_kernel(const StemConv1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                           // [128][WROW] weights
-    bf16_t* ot = wl + C1 * WROW;                                            // [4 waves][32][OROW1]
-    float* cvec = reinterpret_cast<float*>(ot + 4 * 32 * OROW1);            // [3][128]: bias, GN scale, GN shift of image b
+    bf16_t* ot = wl + C1 * WROW;                                            // [NW1 waves][32][OROW1]
+    float* cvec = reinterpret_cast<float*>(ot + NW1 * 32 * OROW1);            // [4][128]: bias, GN scale, GN shift of image b, conv0 bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n32 = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;  // one image per grid row: GroupNorm statistics are per image
 
     // set-up: weights -> LDS (row stride padded: conflict-free ds_read_b128 A fragments), per-batch GN vectors
-    for (int i = tid; i < C1 * (C1 / 8); i += 256) {
+    for (int i = tid; i < C1 * (C1 / 8); i += NW1 * 64) {
         const int oc = i >> 4, c = i & 15;
         *reinterpret_cast<u32x4_t*>(wl + oc * WROW + c * 8) = *reinterpret_cast<const u32x4_t*>(p.w + oc * C1 + c * 8);
     }
@@ -63,11 +74,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
         cvec[c] = p.bias[c];
         cvec[C1 + c] = gmm * rstd;
         cvec[2 * C1 + c] = p.beta[c] - (float)mean * gmm * rstd;
+        if constexpr (IMG) cvec[3 * C1 + c] = p.b0[c];
     }
     __syncthreads();
 
     const int ngroups = p.groups_per_image;
-    const int gstride = gridDim.x * 4;
+    const int gstride = gridDim.x * NW1;
     const int npx = p.H * p.W;
     bf16_t* otw = ot + wave * 32 * OROW1;
 
@@ -104,11 +116,38 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
 #pragma unroll
     for (int g = 0; g < 8; ++g) s1p[g] = s2p[g] = f32x2_t{0.f, 0.f};
 
+    // IMG: conv0 weights as A fragments of v_mfma_f32_32x32x2_f32 (lane (oc = 32 m + n32, k = 2 ks + half), K = 3 -> 2
+    // k-steps, the 4th tap is a zero weight), image taps as B (lane (px = n32, k)): exactly stem_conv0_kernel<1>'s
+    // arithmetic, so the recomputed activation is bit-identical to the one that kernel would have stored
+    float w0r[4][2];
+    const T* ib = nullptr;
+    if constexpr (IMG) {
+        ib = reinterpret_cast<const T*>(p.img) + (int64_t)b * p.ibs;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int k = 2 * ks + half;
+                w0r[m][ks] = (k < 3) ? p.w0[(32 * m + n32) * 3 + k] : 0.f;
+            }
+    }
+    auto load_taps = [&](int g, float (&sv)[2]) __attribute__((always_inline)) {
+        const int gc = g < ngroups ? g : ngroups - 1;
+        const int n = min(gc * 32 + n32, npx - 1);
+        const int yy = n / p.W, xx = n - yy * p.W;
+        const int o = yy * p.is[2] + xx * p.is[3];
+        sv[0] = (float)ib[o + half * p.is[1]];            // k = 0 / 1 -> channel 0 / 1
+        sv[1] = (float)ib[o + 2 * p.is[1]];               // k = 2 -> channel 2 (k = 3: zero weight)
+    };
+
     u32x4_t raw[8], nxt[8];
-    int g = blockIdx.x * 4 + wave;
-    load_group(g, raw);
+    float sv[2] = {0.f, 0.f}, svn[2] = {0.f, 0.f};
+    int g = blockIdx.x * NW1 + wave;
+    if constexpr (IMG) load_taps(g, sv);
+    else load_group(g, raw);
     for (; g < ngroups; g += gstride) {
-        load_group(g + gstride, nxt);
+        if constexpr (IMG) load_taps(g + gstride, svn);
+        else load_group(g + gstride, nxt);
         const int n0 = g * 32;
         const float* cv = cvec;
 
@@ -117,6 +156,48 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        if constexpr (IMG) {
+            // conv0 (exact fp32) -> + bias -> bf16 (= the activation conv0 would have stored) -> GroupNorm affine + SiLU
+            // -> the wave's LDS tile as [px][ch]; lane (px = n32, half) owns channels 32 m + 8 j + 4 half + i
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+                f32x16_t a0[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a0[q][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) a0[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0r[2 * mp + q][ks], sv[ks], a0[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int m = 2 * mp + q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c0 = 32 * m + 8 * j + 4 * half;
+                        const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cv + 3 * C1 + c0);
+                        const f32x4_t gaj = *reinterpret_cast<const f32x4_t*>(cv + C1 + c0);
+                        const f32x4_t gbj = *reinterpret_cast<const f32x4_t*>(cv + 2 * C1 + c0);
+                        bf16x4_t o;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const f32x2_t v = f32x2_t{a0[q][j * 4 + 2 * e], a0[q][j * 4 + 2 * e + 1]} + f32x2_t{bj[2 * e], bj[2 * e + 1]};
+                            bf16x2_t xb;
+                            xb[0] = (bf16_t)v[0];
+                            xb[1] = (bf16_t)v[1];
+                            const f32x2_t x = {(float)xb[0], (float)xb[1]};
+                            const f32x2_t y = x * f32x2_t{gaj[2 * e], gaj[2 * e + 1]} + f32x2_t{gbj[2 * e], gbj[2 * e + 1]};
+                            f32x2_t u = y * -1.4426950408889634f;
+                            u = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+                            const f32x2_t r = y * f32x2_t{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+                            o[2 * e] = (bf16_t)r[0];
+                            o[2 * e + 1] = (bf16_t)r[1];
+                        }
+                        *reinterpret_cast<bf16x4_t*>(otw + n32 * OROW1 + c0) = o;
+                    }
+                }
+            }
+        } else {
         // GroupNorm affine + SiLU in registers, then into the wave's LDS tile as [px][ch]
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -134,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
                 o[2 * e + 1] = (bf16_t)r[1];
             }
             *reinterpret_cast<bf16x8_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8) = o;
+        }
         }
         // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each
 #pragma unroll
@@ -179,14 +261,19 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
                 *reinterpret_cast<u32x4_t*>(yb + off + ch * 8) = v;
             }
         }
+        if constexpr (IMG) {
+            sv[0] = svn[0];
+            sv[1] = svn[1];
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) raw[ks] = nxt[ks];
+            for (int ks = 0; ks < 8; ++ks) raw[ks] = nxt[ks];
+        }
     }
 
     if (p.stats_out) {
         // wave sums -> one set of fp64 atomics per WORKGROUP (atomics on 16 addresses serialise in L2)
         __syncthreads();                      // every wave is done with its LDS tile
-        float* red = reinterpret_cast<float*>(ot);   // [4 waves][16]
+        float* red = reinterpret_cast<float*>(ot);   // [NW1 waves][16]
 #pragma unroll
         for (int gq = 0; gq < 8; ++gq) {
             float a = s1p[gq][0] + s1p[gq][1], q = s2p[gq][0] + s2p[gq][1];
@@ -202,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv1x1_kernel(const StemConv1Par
         }
         __syncthreads();
         if (tid < 16) {
-            const float a = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            float a = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW1; ++wv) a += red[wv * 16 + tid];
             atomicAdd(&p.stats_out[(b * 8 + (tid & 7)) * 2 + (tid >> 3)], (double)a);
         }
     }
@@ -218,23 +307,52 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.eps = a->eps;
     for (int i = 0; i < 3; ++i) { p.xs[i] = a->x_stride[i]; p.ys[i] = a->y_stride[i]; }
     p.groups_per_image = (int)(((int64_t)a->H * a->W + 31) / 32);
-    const size_t lds = (size_t)(C1 * WROW + 4 * 32 * OROW1) * 2 + 3 * C1 * sizeof(float);
-    // ~4 workgroups' worth of 32-pixel groups per workgroup keeps the weight staging amortised while still
-    // giving every CU several workgroups
+    const size_t lds = (size_t)(C1 * WROW + NW1 * 32 * OROW1) * 2 + 4 * C1 * sizeof(float);
     // persistent-style grid: ~4 workgroups per CU in total (2 resident), each wave walks many groups, so the
     // 32 KB weight staging and the GroupNorm atomics are paid ~1k times, not once per 16 groups
-    int64_t nbx = (1024 + a->B - 1) / a->B;
-    const int64_t maxb = (p.groups_per_image + 3) / 4;
+    // one workgroup (NW1 waves, ~140 KB of LDS) per CU, all resident, every wave walks many groups
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return prop.multiProcessorCount;
+        return 256;
+    }();
+    int64_t nbx = (((NW1 > 4) ? ncu : 4 * ncu) + a->B - 1) / a->B;
+    const int64_t maxb = (p.groups_per_image + NW1 - 1) / NW1;
     if (nbx > maxb) nbx = maxb;
     if (nbx < 1) nbx = 1;
     if (a->B > 65535) {
         naf_set_error("naf_stem_conv_fwd: batch %d out of range", a->B);
         return NAF_ERR_INVALID;
     }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", (size_t)lds);
-        return NAF_ERR_LAUNCH;
+    p.img = nullptr; p.w0 = nullptr; p.b0 = nullptr; p.ibs = 0;
+    for (int i = 0; i < 4; ++i) p.is[i] = 0;
+    int variant = 0;   // 0: x from memory, 1: f32 image, 2: bf16 image
+    if (a->first != nullptr) {
+        const naf_stem_conv0_args* f = a->first;
+        const int64_t span = 2 * llabs(f->image_stride[1]) + (int64_t)(a->H - 1) * llabs(f->image_stride[2]) +
+                             (int64_t)(a->W - 1) * llabs(f->image_stride[3]);
+        if (span >= 0x7fffffffLL) {
+            naf_set_error("naf_stem_conv_fwd: first: image too large for 32-bit tap offsets (span %lld elements)", (long long)span);
+            return NAF_ERR_UNSUPPORTED;
+        }
+        p.img = f->image; p.w0 = f->weight; p.b0 = f->bias; p.ibs = f->image_stride[0];
+        for (int i = 0; i < 4; ++i) p.is[i] = (int32_t)f->image_stride[i];
+        variant = f->image_dtype == NAF_BF16 ? 2 : 1;
     }
-    hipLaunchKernelGGL(stem_conv1x1_kernel, dim3((uint32_t)nbx, (uint32_t)a->B), dim3(256), lds, s, p);
+    const dim3 grid((uint32_t)nbx, (uint32_t)a->B), blk(NW1 * 64);
+#define NAF_LAUNCH_1X1(KERN)                                                                                              \
+    do {                                                                                                                  \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", (size_t)lds);                             \
+            return NAF_ERR_LAUNCH;                                                                                        \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(KERN, grid, blk, lds, s, p);                                                                   \
+    } while (0)
+    if (variant == 0) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float>));
+    else if (variant == 1) NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, float>));
+    else NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, bf16_t>));
+#undef NAF_LAUNCH_1X1
     return naf_check_launch("stem_conv1x1_kernel");
 }

@@ -97,6 +97,7 @@ class ImageEncoder(nn.Module):
         self.rope = RoPE(out_channels, num_heads=heads_rope, base=rope_base, rescale_coords=rope_rescale)
         self.stem_dtype = torch.bfloat16
         self.stem_impl = "hip"      # "hip": fused HIP stem (hidden width 128); "torch": MIOpen ops (any width)
+        self.fuse_conv0 = True      # 1x1 branch: first block layer recomputes conv0 instead of reading it
 
     @staticmethod
     def _conv(x, conv: nn.Conv2d, dt):
@@ -144,17 +145,22 @@ class ImageEncoder(nn.Module):
         bufs = [torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev) for _ in range(2)]
         for br, seq in enumerate(branches):
             conv0 = seq[0]
+            w0, b0 = conv0.weight.detach().float().contiguous(), conv0.bias.detach().float()
+            # 1x1 branch: the conv0 activation is never stored -- one statistics-only pass, then the first
+            # GroupNorm/SiLU/conv layer recomputes it from the image (bit-identical, 0.5 GB less traffic)
+            recompute = self.fuse_conv0 and conv0.kernel_size[0] == 1 and nstage > 1 and seq[1].conv1.kernel_size[0] == 1
             last = nstage == 1
             dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[0]
-            ops.stem_conv0(image, conv0.weight.detach().float().contiguous(), conv0.bias.detach().float(), dst, stats[br, 0])
+            ops.stem_conv0(image, w0, b0, None if recompute else dst, stats[br, 0])
             cur, st = dst, 0
             for blk in list(seq)[1:]:
                 for norm, conv in ((blk.norm1, blk.conv1), (blk.norm2, blk.conv2)):
                     st += 1
                     last = st == nstage - 1
                     dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[st % 2]
-                    ops.stem_conv(cur, stats[br, st - 1], norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
-                                  self._packed(conv), conv.bias.detach().float(), dst, None if last else stats[br, st])
+                    ops.stem_conv(None if (recompute and st == 1) else cur, stats[br, st - 1], norm.weight.detach().float(),
+                                  norm.bias.detach().float(), norm.eps, self._packed(conv), conv.bias.detach().float(), dst,
+                                  None if last else stats[br, st], first=(image, w0, b0) if (recompute and st == 1) else None)
                     cur = dst
         return cat.permute(0, 3, 1, 2)
 

@@ -83,39 +83,60 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
-def stem_conv0(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, y: torch.Tensor,
-               stats_out: torch.Tensor) -> None:
-    """Conv2d(3 -> 128, k in {1, 3}, reflect) + bias.  image [B,3,H,W] f32/bf16 (any strides); weight f32
-    [128,3,k,k]; y: bf16 [B,H,W,128] view (128 channels contiguous); stats_out f64 [B,8,2], pre-zeroed."""
-    _gpu(image, "image")
-    lib = _lib.load()
-    if image.dtype not in _DT:
-        image = image.float()
+def _fill_stem_conv0(image, weight, bias, y, stats_out) -> StemConv0Args:
     B, Cin, H, W = image.shape
     if Cin != 3 or tuple(weight.shape[:2]) != (128, 3) or weight.dtype != torch.float32 or not weight.is_contiguous():
         raise ValueError(f"stem_conv0: expected a 3-channel image and an f32 [128,3,k,k] weight, got {tuple(image.shape)} / {tuple(weight.shape)}")
     a = StemConv0Args()
-    a.image, a.y, a.weight, a.bias, a.stats_out = image.data_ptr(), y.data_ptr(), weight.data_ptr(), bias.data_ptr(), stats_out.data_ptr()
+    a.image, a.weight, a.bias = image.data_ptr(), weight.data_ptr(), bias.data_ptr()
+    a.y = y.data_ptr() if y is not None else None
+    a.stats_out = stats_out.data_ptr() if stats_out is not None else None
     a.image_dtype, a.ksize, a.B, a.H, a.W = _DT[image.dtype], int(weight.shape[-1]), B, H, W
     a.image_stride = _strides4(image, (0, 1, 2, 3))
-    a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
+    a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2))) if y is not None else I64x3(0, 0, 0)
+    return a
+
+
+def stem_conv0(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, y: Optional[torch.Tensor],
+               stats_out: torch.Tensor) -> None:
+    """Conv2d(3 -> 128, k in {1, 3}, reflect) + bias.  image [B,3,H,W] f32/bf16 (any strides); weight f32
+    [128,3,k,k]; y: bf16 [B,H,W,128] view (128 channels contiguous) or None (statistics only);
+    stats_out f64 [B,8,2], pre-zeroed."""
+    _gpu(image, "image")
+    lib = _lib.load()
+    if image.dtype not in _DT:
+        image = image.float()
+    a = _fill_stem_conv0(image, weight, bias, y, stats_out)
     with torch.cuda.device(image.device), _Timed("stem_conv0"):
         rc = lib.naf_stem_conv0_fwd(C.byref(a), _stream(image))
     _lib.check(rc, "naf_stem_conv0_fwd")
 
 
-def stem_conv(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor, eps: float,
-              w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor]) -> None:
+def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor, eps: float,
+              w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor],
+              first=None) -> None:
     """GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, k in {1,3}, reflect) + bias on bf16 [B,H,W,128] views.
-    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats f64 [B,8,2] (stats_out pre-zeroed or None)."""
-    _gpu(x, "x")
+    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats f64 [B,8,2] (stats_out pre-zeroed or None).
+    ``first=(image, conv0_weight, conv0_bias)`` (1x1 layers only, ``x=None``): the input is bf16(conv0(image))
+    recomputed on the fly; ``stats_in`` then come from ``stem_conv0(..., y=None, ...)``."""
     lib = _lib.load()
+    f0 = None
+    if first is not None:
+        image, w0, b0 = first
+        _gpu(image, "image")
+        if image.dtype not in _DT:
+            image = image.float()
+        f0 = _fill_stem_conv0(image, w0, b0, None, None)
+        x = y                                                        # shape / device donor only
+    _gpu(x, "x")
     B, H, W, Cc = x.shape
     if Cc != 128 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
         raise ValueError("stem_conv: activations must be bf16 [B,H,W,128] with channels contiguous")
     taps = w_packed.shape[0]
     a = StemConvArgs()
-    a.x, a.y, a.w_packed, a.bias = x.data_ptr(), y.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
+    a.x, a.y, a.w_packed, a.bias = (None if first is not None else x.data_ptr()), y.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
+    if f0 is not None:
+        a.first = C.pointer(f0)
     a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
     a.stats_out = stats_out.data_ptr() if stats_out is not None else None
     a.ksize = {1: 1, 9: 3}[int(taps)]

@@ -513,6 +513,33 @@ def test_forward_train_gradients_match_oracle(dev):
     assert float((fd.grad.float().cpu() - fo.grad).abs().max()) <= 3e-2 * gs + 1e-3
 
 
+@pytest.mark.parametrize("shape,fmt", [((1, 3, 40, 56), "f32"), ((2, 3, 33, 47), "bf16_strided")])
+def test_first_1x1_layer_recomputes_conv0_bit_exactly(dev, shape, fmt):
+    """naf_stem_conv_fwd(first = conv0 args) == naf_stem_conv0_fwd + naf_stem_conv_fwd, bit for bit, and the
+    statistics-only conv0 pass produces the same sums as the storing pass."""
+    from naf_amd import ops
+    B, _, H, W = shape
+    img = O.hash_normal(shape, 601).to(dev)
+    if fmt == "bf16_strided":
+        img = img.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # NHWC storage
+    w0 = (O.hash_normal((128, 3, 1, 1), 602) * 0.5).to(dev)
+    b0 = (O.hash_normal((128,), 603) * 0.1).to(dev)
+    gw = (1.0 + 0.1 * O.hash_normal((128,), 604)).to(dev)
+    gb = (0.1 * O.hash_normal((128,), 605)).to(dev)
+    wp = (O.hash_normal((1, 128, 128), 606) * 0.09).to(torch.bfloat16).to(dev)
+    cb = (O.hash_normal((128,), 607) * 0.1).to(dev)
+    x0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+    st = torch.zeros((4, B, 8, 2), dtype=torch.float64, device=dev)
+    ops.stem_conv0(img, w0, b0, x0, st[0])
+    ops.stem_conv0(img, w0, b0, None, st[1])
+    assert torch.equal(st[0], st[1])
+    ya, yb = torch.empty_like(x0), torch.empty_like(x0)
+    ops.stem_conv(x0, st[0], gw, gb, 1e-5, wp, cb, ya, st[2])
+    ops.stem_conv(None, st[1], gw, gb, 1e-5, wp, cb, yb, st[3], first=(img, w0, b0))
+    assert torch.equal(ya, yb), float((ya.float() - yb.float()).abs().max())
+    assert torch.allclose(st[2], st[3], rtol=1e-12, atol=1e-9)
+
+
 def test_heads_rope_differs_from_heads_attn(dev):
     p = O.make_params(dim=64, heads_rope=1, seed=8)
     m = _load_model(dev, p, dim=64, heads_attn=4, heads_rope=1, kernel_size=3)
