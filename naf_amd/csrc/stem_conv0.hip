@@ -95,8 +95,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
     float sv[KSTEP], nx[KSTEP];
     int g = blockIdx.x * 4 + wave;
     load_taps(g, sv);
+    // The first segment's taps land BEFORE the loop: otherwise the loop header inherits "loads in flight, nothing
+    // younger" from this path and every iteration's wait for its taps also waits for the previous segment's stores.
+    {
+        float t0 = sv[0], t1 = sv[KSTEP - 1];
+        asm volatile("; conv0 first taps landed" : "+v"(t0), "+v"(t1));
+        sv[0] = t0;
+        sv[KSTEP - 1] = t1;
+    }
     for (; g < p.ngroups; g += gstride) {
         load_taps(g + gstride, nx);   // next segment's taps load while this one's MFMAs run
+        __builtin_amdgcn_sched_barrier(0);
         const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
 
         // two oc-tiles at a time (two interleaved accumulator chains keep the matrix pipe fed and only 32
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
                 *reinterpret_cast<u32x4_t*>(yr + (int64_t)it * 8 * p.ys[2] + st_lane) = v;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // consume the prefetch below the stores (exact vmcnt: the stores stay in flight)
 #pragma unroll
         for (int ks = 0; ks < KSTEP; ++ks) sv[ks] = nx[ks];
     }

@@ -13,6 +13,8 @@
 //   * the wave's 32 px x 128 ch result goes through its private LDS tile and leaves as whole 256-byte rows
 //     (4 px x 256 B = 1 KiB contiguous per store instruction);
 //   * no barrier after set-up; GroupNorm sums of the output stay in registers until the wave retires.
+#include <type_traits>
+
 #include "naf_common.h"
 
 struct StemConv1Params {
@@ -46,14 +48,17 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 }  // namespace
 
-template <bool IMG, typename T>
+// DENSE: rows are dense in x and y and H*W is a multiple of 32 -> every group is complete, one uniform base + one
+// constant lane offset per access, a branch-free loop body (which also keeps hipcc's vmcnt waits exact).
+template <bool IMG, typename T, bool DENSE>
 __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_kernel(const StemConv1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                           // [128][WROW] weights
     bf16_t* ot = wl + C1 * WROW;                                            // [NW1 waves][32][OROW1]
     float* cvec = reinterpret_cast<float*>(ot + NW1 * 32 * OROW1);            // [4][128]: bias, GN scale, GN shift of image b, conv0 bias
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: group indices and base addresses stay scalar
     const int n32 = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;  // one image per grid row: GroupNorm statistics are per image
 
@@ -87,10 +92,21 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     // (lane -> 16-byte chunk (lane & 15) of pixel 4*it + (lane >> 4))
     const int chk = lane & 15, psub = lane >> 4;
     // dense rows (the usual case): pixel n sits at n * stride_x, no (y, x) split needed
-    const bool xdense = p.xs[1] == (int64_t)p.W * p.xs[2], ydense = p.ys[1] == (int64_t)p.W * p.ys[2];
+    const bool xdense = DENSE || p.xs[1] == (int64_t)p.W * p.xs[2], ydense = DENSE || p.ys[1] == (int64_t)p.W * p.ys[2];
     const bf16_t* xbase = p.x + b * p.xs[0] + chk * 8;
+    // Dense rows and a group entirely inside the image (all but possibly the last one): a uniform 64-bit group base
+    // plus one constant 32-bit lane offset, no bounds checks.  Otherwise per-lane (y, x) arithmetic.
+    const uint32_t lane_x = (uint32_t)(psub * (int)p.xs[2] + chk * 8) * 2u, lane_y = (uint32_t)(psub * (int)p.ys[2] + chk * 8) * 2u;
+    const int nfull = npx >> 5;   // groups 0 .. nfull-1 are complete
     auto load_group = [&](int g, u32x4_t (&raw)[8]) __attribute__((always_inline)) {
         const int gc = g < ngroups ? g : ngroups - 1;
+        if (DENSE || (xdense && gc < nfull)) {
+            const char* xg = reinterpret_cast<const char*>(p.x + b * p.xs[0] + (int64_t)gc * 32 * p.xs[2]);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) raw[it] = *reinterpret_cast<const u32x4_t*>(xg + (int64_t)it * 8 * p.xs[2] + lane_x);
+            return;
+        }
+        if constexpr (!DENSE) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int n = min(gc * 32 + it * 4 + psub, npx - 1);
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                 off = (int64_t)yy * p.xs[1] + (int64_t)xx * p.xs[2];
             }
             raw[it] = *reinterpret_cast<const u32x4_t*>(xbase + off);
+        }
         }
     };
     // GroupNorm scale / shift of this lane's 8 input channels
@@ -140,14 +157,17 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         sv[1] = (float)ib[o + 2 * p.is[1]];               // k = 2 -> channel 2 (k = 3: zero weight)
     };
 
-    u32x4_t raw[8], nxt[8];
-    float sv[2] = {0.f, 0.f}, svn[2] = {0.f, 0.f};
+    u32x4_t raw[8];
+    float sv[2] = {0.f, 0.f};
     int g = blockIdx.x * NW1 + wave;
     if constexpr (IMG) load_taps(g, sv);
     else load_group(g, raw);
+    // First group landed BEFORE the loop is entered: otherwise the loop header inherits "8 loads in flight, nothing
+    // younger" from this path, and the per-register waits at the top of every iteration (vmcnt(7..0)) also wait for the
+    // previous group's eight stores.  With nothing pending here they become vmcnt(15..8).
+    if constexpr (IMG) asm volatile("; conv1x1 first group landed" ::"v"(sv[0]), "v"(sv[1]));
+    else asm volatile("; conv1x1 first group landed" ::"v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
     for (; g < ngroups; g += gstride) {
-        if constexpr (IMG) load_taps(g + gstride, svn);
-        else load_group(g + gstride, nxt);
         const int n0 = g * 32;
         const float* cv = cvec;
 
@@ -217,6 +237,13 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             *reinterpret_cast<bf16x8_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8) = o;
         }
         }
+        // The input registers are free again: refill them with the NEXT group now (no second register set; the loads
+        // have the MFMA / epilogue / store part of this group to land and are consumed by the next transform, whose
+        // vmcnt wait then leaves this group's eight stores in flight).
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (IMG) load_taps(g + gstride, sv);
+        else load_group(g + gstride, raw);
+        __builtin_amdgcn_sched_barrier(0);
         // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -228,48 +255,65 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             }
         }
         // epilogue: bias, GroupNorm sums, bf16 -> the wave's LDS tile (a lane outside the image adds zeros)
-        const float vmask = ((n0 + n32) < npx) ? 1.0f : 0.0f;
+        const bool full = DENSE || g < nfull;
+        auto epilogue = [&](auto fullc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(fullc)::value;
+            const float vmask = (FULL || (n0 + n32) < npx) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cv + 32 * m + 8 * j + 4 * half);
-                const f32x2_t v0 = f32x2_t{acc[m][j * 4], acc[m][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
-                const f32x2_t v1 = f32x2_t{acc[m][j * 4 + 2], acc[m][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
-                bf16x4_t o;
-                o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
-                const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
-                s1p[m * 2 + (j >> 1)] += w0 + w1;
-                s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
-                *reinterpret_cast<bf16x4_t*>(otw + n32 * OROW1 + 32 * m + 8 * j + 4 * half) = o;
-            }
-        // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
-        bf16_t* yb = p.y + b * p.ys[0];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pp = it * 4 + psub, ch = chk;
-            const int n = n0 + pp;
-            if (n < npx) {
-                int64_t off;
-                if (ydense) {
-                    off = (int64_t)n * p.ys[2];
-                } else {
-                    const int yy = n / p.W, xx = n - yy * p.W;
-                    off = (int64_t)yy * p.ys[1] + (int64_t)xx * p.ys[2];
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cv + 32 * m + 8 * j + 4 * half);
+                    const f32x2_t v0 = f32x2_t{acc[m][j * 4], acc[m][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
+                    const f32x2_t v1 = f32x2_t{acc[m][j * 4 + 2], acc[m][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+                    bf16x4_t o;
+                    o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
+                    const f32x2_t w0 = FULL ? v0 : v0 * vmask, w1 = FULL ? v1 : v1 * vmask;
+                    s1p[m * 2 + (j >> 1)] += w0 + w1;
+                    s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
+                    *reinterpret_cast<bf16x4_t*>(otw + n32 * OROW1 + 32 * m + 8 * j + 4 * half) = o;
                 }
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + pp * OROW1 + ch * 8);
-                *reinterpret_cast<u32x4_t*>(yb + off + ch * 8) = v;
-            }
-        }
-        if constexpr (IMG) {
-            sv[0] = svn[0];
-            sv[1] = svn[1];
-        } else {
+            // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
+            bf16_t* yb = p.y + b * p.ys[0];
+            if (FULL && (DENSE || ydense)) {
+                char* yg = reinterpret_cast<char*>(yb + (int64_t)g * 32 * p.ys[2]);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) raw[ks] = nxt[ks];
+                for (int it = 0; it < 8; ++it) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8);
+                    *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + lane_y) = v;
+                }
+                return;
+            }
+            if constexpr (!(FULL && DENSE)) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int pp = it * 4 + psub, ch = chk;
+                const int n = n0 + pp;
+                if (n < npx) {
+                    int64_t off;
+                    if (ydense) {
+                        off = (int64_t)n * p.ys[2];
+                    } else {
+                        const int yy = n / p.W, xx = n - yy * p.W;
+                        off = (int64_t)yy * p.ys[1] + (int64_t)xx * p.ys[2];
+                    }
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + pp * OROW1 + ch * 8);
+                    *reinterpret_cast<u32x4_t*>(yb + off + ch * 8) = v;
+                }
+            }
+            }
+        };
+        if constexpr (DENSE) {
+            epilogue(std::true_type{});
+        } else {
+            if (full) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
         }
     }
 
+    // the (unused) prefetch past the last group lands here, not at some later merge point
+    if constexpr (IMG) asm volatile("; conv1x1 loop drained" ::"v"(sv[0]), "v"(sv[1]));
+    else asm volatile("; conv1x1 loop drained" ::"v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
     if (p.stats_out) {
         // wave sums -> one set of fp64 atomics per WORKGROUP (atomics on 16 addresses serialise in L2)
         __syncthreads();                      // every wave is done with its LDS tile
@@ -350,9 +394,17 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
         }                                                                                                                 \
         hipLaunchKernelGGL(KERN, grid, blk, lds, s, p);                                                                   \
     } while (0)
-    if (variant == 0) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float>));
-    else if (variant == 1) NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, float>));
-    else NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, bf16_t>));
+    const bool dense = (a->x_stride[1] == (int64_t)a->W * a->x_stride[2] || a->first != nullptr) &&
+                       a->y_stride[1] == (int64_t)a->W * a->y_stride[2] && (((int64_t)a->H * a->W) % 32 == 0);
+    if (dense) {
+        if (variant == 0) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float, true>));
+        else if (variant == 1) NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, float, true>));
+        else NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, bf16_t, true>));
+    } else {
+        if (variant == 0) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float, false>));
+        else if (variant == 1) NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, float, false>));
+        else NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, bf16_t, false>));
+    }
 #undef NAF_LAUNCH_1X1
     return naf_check_launch("stem_conv1x1_kernel");
 }
