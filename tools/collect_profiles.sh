@@ -10,6 +10,8 @@ python bench.py > $out/bench_line.json 2> $out/bench.err
 tail -1 $out/bench_line.json
 # 2) kernel trace + stats of the same command
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --no-cpu-baseline > $out/trace.log 2>&1
+# the JSON line of THAT process: its HIP-event kernel time and the trace average describe the same launches
+grep '^{"metric"' $out/trace.log | tail -1 > $out/bench_line_under_rocprof.json
 f=$(ls $out/trace/*/*kernel_stats.csv | head -1)
 python3 - "$f" > $out/kernel_stats_summary.csv <<'PY'
 import csv, sys
