@@ -209,9 +209,11 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  *   dq     device bf16 [B, heads, Ho, Wo, Dq]   gradient of q, strides {b, head, y, x}
  *   dk_lr  device float [B, h, w, heads, Dq] dense, dv_lr device float [B, h, w, heads, Dv] dense: the caller
  *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
- * Served shapes: what the MFMA forward serves with ky = kx <= 9, Wo/w a multiple of 16 and
- * Dv in {32, 64, 96, 128, 192, 256}; NAF_ERR_UNSUPPORTED otherwise (naf_xna_bwd_supported tells in advance).
- * scale <= 0 selects Dq^-0.5. */
+ *   idx_y, idx_x   optional device int32 tables from naf_axis_index_table, required by the table-driven path.
+ * Two kernels, like the forward: the MFMA cell kernel (what the MFMA forward serves with ky = kx <= 9, Wo/w a
+ * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}) and a table-driven one for everything else (any ratio,
+ * head dims, rectangular windows; one wave per query, atomics per key).  naf_xna_bwd_supported returns which
+ * (NAF_XNA_MFMA / NAF_XNA_GENERIC) so that the caller knows whether to build the tables.  scale <= 0 selects Dq^-0.5. */
 typedef struct naf_xna_bwd_args {
     const void* q;
     const void* k_lr;
@@ -220,6 +222,8 @@ typedef struct naf_xna_bwd_args {
     void* dq;
     float* dk_lr;
     float* dv_lr;
+    const int32_t* idx_y;
+    const int32_t* idx_x;
     int32_t B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx;
     float scale;
     int32_t reserved;
@@ -229,7 +233,7 @@ typedef struct naf_xna_bwd_args {
     int64_t dout_stride[4];
     int64_t dq_stride[4];
 } naf_xna_bwd_args;
-/* 1 when naf_xna_bwd serves these arguments, 0 when not, negative naf_status on invalid arguments. */
+/* NAF_XNA_MFMA or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run; negative naf_status on invalid arguments. */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 

@@ -64,7 +64,7 @@ class StemConvArgs(C.Structure):
 class XnaBwdArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k_lr", C.c_void_p), ("v_lr", C.c_void_p), ("dout", C.c_void_p), ("dq", C.c_void_p),
-        ("dk_lr", C.c_void_p), ("dv_lr", C.c_void_p),
+        ("dk_lr", C.c_void_p), ("dv_lr", C.c_void_p), ("idx_y", C.c_void_p), ("idx_x", C.c_void_p),
         ("B", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
         ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
         ("scale", C.c_float), ("reserved", C.c_int32),

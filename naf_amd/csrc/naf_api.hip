@@ -204,14 +204,15 @@ static int xna_bwd_validate(const naf_xna_bwd_args* a) {
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a) {
     const int rc = xna_bwd_validate(a);
     if (rc != NAF_OK) return -rc;
-    return naf_xna_bwd_eligible(a);
+    return naf_xna_bwd_eligible(a) ? NAF_XNA_MFMA : NAF_XNA_GENERIC;
 }
 
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
     const int rc = xna_bwd_validate(a);
     if (rc != NAF_OK) return rc;
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
-    return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
+    if (naf_xna_bwd_eligible(a)) return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
+    return naf_launch_xna_generic_bwd(a, scale, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

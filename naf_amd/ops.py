@@ -304,7 +304,7 @@ def _fill_xna_bwd(q, k, v, dout, dq, dk, dv, ky, kx, scale) -> XnaBwdArgs:
 
 
 def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> bool:
-    """True when ``xna_backward`` has a kernel for these shapes (see naf_xna_bwd in include/naf_hip.h)."""
+    """True when ``xna_backward`` runs the MFMA cell kernel for these shapes (otherwise: the table-driven one)."""
     lib = _lib.load()
     ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
     a = _fill_xna_bwd(q, k_lr, v_lr, q, q, q, q, ky, kx, None)      # shape / alignment query only
@@ -312,7 +312,7 @@ def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tens
     Dv = v_lr.shape[-1]
     a.dout_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
     a.dq_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
-    return lib.naf_xna_bwd_supported(C.byref(a)) == 1
+    return lib.naf_xna_bwd_supported(C.byref(a)) == _lib.XNA_MFMA
 
 
 def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: torch.Tensor, kernel_size, *,
@@ -337,6 +337,13 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
     dk = torch.zeros((B, h, w, heads, Dq), dtype=torch.float32, device=dev)
     dv = torch.zeros((B, h, w, heads, Dv), dtype=torch.float32, device=dev)
     a = _fill_xna_bwd(q, k_lr, v_lr, dout, dq, dk, dv, ky, kx, scale)
+    sel = lib.naf_xna_bwd_supported(C.byref(a))
+    if sel < 0:
+        _lib.check(-sel, "naf_xna_bwd_supported")
+    if sel == _lib.XNA_GENERIC:
+        iy = device_index_table(Ho, h, ky, dev)
+        ix = device_index_table(Wo, w, kx, dev)
+        a.idx_y, a.idx_x = iy.data_ptr(), ix.data_ptr()
     with torch.cuda.device(dev), _Timed("xna_bwd"):
         rc = lib.naf_xna_bwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_bwd")
@@ -344,13 +351,13 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
 
 
 class XnaFunction(torch.autograd.Function):
-    """Differentiable ``xna_forward`` (MFMA path): forward = naf_xna_fwd, backward = naf_xna_bwd."""
+    """Differentiable ``xna_forward``: forward = naf_xna_fwd, backward = naf_xna_bwd (MFMA or table-driven kernels)."""
 
     @staticmethod
     def forward(ctx, q, k_lr, v_lr, kernel_size, scale, out_dtype):
         ctx.save_for_backward(q, k_lr, v_lr)
         ctx.kernel_size, ctx.scale = kernel_size, scale
-        return xna_forward(q, k_lr, v_lr, kernel_size, out_dtype=out_dtype, path="mfma", scale=scale)
+        return xna_forward(q, k_lr, v_lr, kernel_size, out_dtype=out_dtype, path="auto", scale=scale)
 
     @staticmethod
     def backward(ctx, dout):

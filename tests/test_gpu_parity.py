@@ -461,6 +461,29 @@ def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
             f"{name}: max err {float(err.max()):.3e} mean {float(err.mean()):.3e} (ref max {scale:.3e})"
 
 
+@pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
+    (1, 256, 24, 4, (5, 7), (23, 30), 3),       # non-integer ratio (F4 shapes): irregular neighbourhoods, duplicates
+    (1, 96, 3, 1, (12, 10), (12, 10), 5),       # ratio 1, one head of 96, C = 3 (denoising-like)
+    (2, 64, 16, 2, (4, 4), (16, 16), (3, 1)),   # rectangular window, Dq = 32, d = 4 (MFMA backward does not serve it)
+])
+def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_sz, ksz):
+    """naf_xna_bwd's table-driven kernel (shapes the MFMA cell kernel does not serve) vs autograd through the oracle."""
+    from naf_amd import ops
+    q = bf16r(O.hash_normal((B, Cq, *out_sz), 531))
+    k = bf16r(O.hash_normal((B, Cq, *lr), 532))
+    v = bf16r(O.hash_normal((B, C, *lr), 533))
+    dout = bf16r(O.hash_normal((B, C, *out_sz), 534))
+    rq, rk, rv = O.xna_backward(q, k, v, dout, ksz, heads)
+    q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, dout))
+    assert not ops.xna_backward_supported(q5, k5, v5, ksz)
+    dq, dk, dv = ops.xna_backward(q5, k5, v5, g5, ksz)
+    back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
+    for got, ref, name, tol in ((back(dq), rq, "dq", 1e-2), (back(dk), rk, "dk", 1e-4), (back(dv), rv, "dv", 1e-4)):
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= tol * scale + 1e-5, f"{name}: max err {err:.3e} (ref max {scale:.3e})"   # dq is rounded to bf16
+
+
 def test_xna_autograd_function(dev):
     """ops.XnaFunction: torch autograd drives naf_xna_fwd / naf_xna_bwd."""
     from naf_amd import ops
