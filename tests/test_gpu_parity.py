@@ -620,3 +620,34 @@ def test_full_size_properties(dev, name, B, C, lr, out_sz, ksz):
     ref = O.xna_tables(q_rows, bf16r(k), bf16r(v1), iy, ix, heads)
     got = o1[:, :, rows].permute(0, 1, 4, 2, 3).reshape(B, C, len(rows), out_sz).float().cpu()
     assert_close(got, ref, 6e-3, 6e-3, f"{name} sampled rows")
+
+
+def test_rccl_single_rank_sharded_forward(dev):
+    """naf_amd.dist on the real RCCL backend ("nccl" on ROCm) with a one-rank group: parameter broadcast, batch
+    sharding, result gathering and the sharded forward run through the same calls the multi-GPU bench uses."""
+    import torch.distributed as dist
+    from naf_amd import dist as nd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    port = 29500 + (os.getpid() % 400)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        p = O.make_params(seed=3)
+        m = _load_model(dev, p, kernel_size=3)
+        nd.broadcast_parameters(m, src=0)
+        sm = nd.ShardedNAF(m)
+        img = O.hash_normal((2, 3, 32, 32), 701).to(dev)
+        ft = O.hash_normal((2, 64, 4, 4), 702).to(dev)
+        out = sm(img, ft, (32, 32))
+        ref = m(img, ft, (32, 32))
+        assert torch.equal(out, ref)
+        lo, hi = nd.shard_range(2, 0, 1)
+        mine = nd.scatter_batch(img, img.shape, img.dtype, dev, src=0)
+        assert (lo, hi) == (0, 2) and torch.equal(mine, img)
+        vals = nd.gather_scalars([1.5, 2.5], dev)
+        assert vals == [[1.5, 2.5]]
+        full = nd.gather_outputs(out, 2)
+        assert torch.equal(full, ref)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
