@@ -43,7 +43,11 @@ WORKLOADS = {
     "G2-k15": (1024, 32, 512, 15),
     "G3": (1024, 64, 1024, 7),
     "G4": (768, 128, 2048, 7),
+    # the reference's own published timing point (test/test_results.json:243-256, A100-40GB, fp32):
+    # image 448^2, DINO-S features 384 x 28^2 -> 448^2, NAF() default window 9: 56.24 ms = 3.57 Mpix/s
+    "REF448": (384, 28, 448, 9),
 }
+PUBLISHED_MPIX = {"REF448": 3.57}   # BASELINE.md numbers for the exact configuration (other hardware)
 
 
 class EventTimer:
@@ -207,7 +211,10 @@ def main():
         line = {
             "metric": "upsampled Mpixels/sec (NAF forward)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": (round(value / PUBLISHED_MPIX[args.workload], 2) if (args.workload in PUBLISHED_MPIX and world == 1 and B == 1
+                                                                                  and not args.attention_only) else None),
+            "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {B}x3x{out}x{out} guidance, {B}x{C}x{lr}x{lr} features -> "
                                    f"{out}x{out}, window {ksz}, per GPU", "per_gpu_batch": B, "parallelism": f"batch-shard x{world}",
                        "scope": "attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)",

@@ -25,6 +25,18 @@ int naf_check_launch(const char* what) {
     return NAF_OK;
 }
 
+int naf_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 extern "C" {
 
 int naf_version(void) { return NAF_HIP_VERSION; }

@@ -19,6 +19,7 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // ---- error plumbing (naf_api.cpp owns the storage) ----
 void naf_set_error(const char* fmt, ...);
 int naf_check_launch(const char* what);
+int naf_cu_count();   // compute units of the current device (cached per device)
 
 #define NAF_REQUIRE(cond, ...)        \
     do {                              \

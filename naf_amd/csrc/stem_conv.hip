@@ -44,15 +44,11 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
     p.tiles_x = (a->W + TW - 1) / TW;
     // One workgroup fills a CU (all 512 registers of every SIMD, ~100 KiB LDS) and re-reads its weights
     // from L2 once, so aim for about one workgroup per CU: tall segments, a multiple of RS rows.
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-    }
+    const int ncu = naf_cu_count();
     const int64_t strips = (int64_t)a->B * p.tiles_x;
-    int64_t segs = (ncu + strips - 1) / strips;            // smallest count that gives >= ncu workgroups
+    // largest segment count that still fits ONE round of workgroups (a workgroup owns a whole CU): 266 workgroups on
+    // 256 CUs take two rounds (448^2: 0.117 ms per layer), 252 take one
+    int64_t segs = ncu / strips;
     if (segs < 1) segs = 1;
     if (segs > (a->H + 7) / 8) segs = (a->H + 7) / 8;      // keep >= 8 rows per segment
     if (segs < 1) segs = 1;

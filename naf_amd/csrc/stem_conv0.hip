@@ -197,7 +197,10 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     for (int i = 0; i < 4; ++i) p.is[i] = (int32_t)a->image_stride[i];
     for (int i = 0; i < 3; ++i) p.ys[i] = a->y_stride[i];
     // persistent-style grid: ~4 workgroups per CU in total, every wave walks many 32-pixel segments
-    int64_t nbx = (1024 + a->B - 1) / a->B;
+    // one residency round (2 workgroups of 4 waves per CU), the same number of segments for every wave
+    const int64_t slots = (int64_t)naf_cu_count() * 2 * 4;
+    const int64_t gpw = (ng * a->B + slots - 1) / slots;
+    int64_t nbx = (ng + gpw * 4 - 1) / (gpw * 4);
     const int64_t maxb = (ng + 3) / 4;
     if (nbx > maxb) nbx = maxb;
     if (nbx < 1) nbx = 1;

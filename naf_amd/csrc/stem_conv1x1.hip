@@ -354,15 +354,12 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
     const size_t lds = (size_t)(C1 * WROW + NW1 * 32 * OROW1) * 2 + 4 * C1 * sizeof(float);
     // persistent-style grid: ~4 workgroups per CU in total (2 resident), each wave walks many groups, so the
     // 32 KB weight staging and the GroupNorm atomics are paid ~1k times, not once per 16 groups
-    // one workgroup (NW1 waves, ~140 KB of LDS) per CU, all resident, every wave walks many groups
-    static const int ncu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            return prop.multiProcessorCount;
-        return 256;
-    }();
-    int64_t nbx = (((NW1 > 4) ? ncu : 4 * ncu) + a->B - 1) / a->B;
+    // One residency round: (NW1 <= 4 ? 2 : 1) workgroups per CU, all resident, and every wave gets the SAME number of
+    // 32-pixel groups (a wave with one group more than the others sets the kernel time when there are only a few).
+    const int64_t slots = (int64_t)naf_cu_count() * (NW1 <= 4 ? 2 : 1) * NW1;                 // resident waves
+    const int64_t total = (int64_t)p.groups_per_image * a->B;
+    const int64_t gpw = (total + slots - 1) / slots;                                          // groups per wave
+    int64_t nbx = (p.groups_per_image + gpw * NW1 - 1) / (gpw * NW1);
     const int64_t maxb = (p.groups_per_image + NW1 - 1) / NW1;
     if (nbx > maxb) nbx = maxb;
     if (nbx < 1) nbx = 1;
