@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
     ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
     ap.add_argument("--no-fuse-conv0", action="store_true", help="store the 1x1 branch's conv0 activation (A/B against recompute)")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a hipGraph (NAF.capture); no per-kernel "
+                    "event timing is possible inside a graph, so `roofline` is null in this mode")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +164,11 @@ def main():
 
         def step():
             return model.upsampler(q5, k5, feats, rope_tables=tabs)
+    elif args.graph:
+        graphed = model.capture(image, feats, size)
+
+        def step():
+            return graphed()
     else:
         def step():
             return model(image, feats, size)
@@ -217,7 +224,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {B}x3x{out}x{out} guidance, {B}x{C}x{lr}x{lr} features -> "
                                    f"{out}x{out}, window {ksz}, per GPU", "per_gpu_batch": B, "parallelism": f"batch-shard x{world}",
-                       "scope": "attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)",
+                       "scope": ("attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)")
+                                + (", hipGraph replay" if args.graph else ""),
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
             "roofline": roof,
             "phases_ms": {k: (round(timer.mean_ms(k), 4) if timer.mean_ms(k) else None)

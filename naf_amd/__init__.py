@@ -7,7 +7,7 @@ attention filtering forward, behind the reference's own API (valeoai/NAF: src/mo
 
 Kernels live in naf_amd/csrc (HIP, C ABI in include/naf_hip.h); build with ``python -m naf_amd.build``.
 """
-from .model import NAF, CrossAttention, ImageEncoder, RoPE  # noqa: F401
+from .model import NAF, CrossAttention, GraphedForward, ImageEncoder, RoPE  # noqa: F401
 
-__all__ = ["NAF", "CrossAttention", "ImageEncoder", "RoPE"]
+__all__ = ["NAF", "CrossAttention", "GraphedForward", "ImageEncoder", "RoPE"]
 __version__ = "0.1.0"

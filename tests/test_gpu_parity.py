@@ -651,3 +651,16 @@ def test_rccl_single_rank_sharded_forward(dev):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_forward_replays_bit_exactly(dev):
+    """NAF.capture: the hipGraph replay gives the eager result, also after new inputs are copied in."""
+    p = O.make_params(seed=5)
+    m = _load_model(dev, p, kernel_size=3)
+    img = O.hash_normal((1, 3, 64, 64), 801).to(dev)
+    ft = O.hash_normal((1, 128, 4, 4), 802).to(dev)
+    g = m.capture(img, ft, (64, 64))
+    assert torch.equal(g(), m(img, ft, (64, 64)))
+    img2 = O.hash_normal((1, 3, 64, 64), 803).to(dev)
+    ft2 = O.hash_normal((1, 128, 4, 4), 804).to(dev)
+    assert torch.equal(g(img2, ft2), m(img2, ft2, (64, 64)))
