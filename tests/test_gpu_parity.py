@@ -502,6 +502,28 @@ def test_xna_autograd_function(dev):
         assert float((got - ref).abs().max()) <= 3e-2 * scale + 1e-3, name
 
 
+def test_golden_F8_gradients_forward_train(dev, golden_dir):
+    """NAF.forward_train gradients against the REFERENCE's own autograd (golden F8, generated by importing it)."""
+    g = np.load(os.path.join(golden_dir, "F8_gradients.npz"))
+    p = O.make_params(seed=int(g["param_seed"]))
+    m = _load_model(dev, p, kernel_size=int(g["k"]))
+    for prm in m.parameters():
+        prm.requires_grad_(True)
+    img = O.hash_normal(tuple(g["shape"]), int(g["image_seed"])).to(dev)
+    ft = O.hash_normal(tuple(g["feat_shape"]), int(g["feat_seed"])).to(dev).requires_grad_(True)
+    w = O.hash_normal((1, 128, 48, 48), int(g["weight_seed"])).to(dev)
+    (m.forward_train(img, ft, (48, 48)).float() * w).sum().backward()
+    ref = torch.from_numpy(g["dfeatures"])
+    assert float((ft.grad.float().cpu() - ref).abs().max()) <= 3e-2 * float(ref.abs().max()) + 1e-3
+    named = dict(m.named_parameters())
+    for i, name in enumerate(g["names"]):
+        ref = torch.from_numpy(g[f"g{i}"])
+        got = named[str(name)].grad.float().cpu()
+        if got.dim() == 4 and got.shape[1] == 128:
+            got = got[::4, ::4]
+        assert float((got - ref).abs().max()) <= 5e-2 * float(ref.abs().max()) + 1e-3, name
+
+
 def test_forward_train_gradients_match_oracle(dev):
     """NAF.forward_train: loss gradients w.r.t. encoder parameters and features vs autograd through the oracle."""
     p = O.make_params(seed=21)

@@ -181,3 +181,25 @@ def test_xna_backward_matches_finite_differences():
             args_m = [tm if x is t else x for x in (q, k, v)]
             fd = (f(*args_p) - f(*args_m)) / (2 * eps)
             assert abs(fd - float(g[idx])) <= 1e-5 + 1e-4 * abs(fd), (name, idx, fd, float(g[idx]))
+
+
+def _f8_sample(g, name_grad):
+    return name_grad[::4, ::4] if name_grad.dim() == 4 and name_grad.shape[1] == 128 else name_grad
+
+
+def test_golden_F8_gradients(golden_dir):
+    """Autograd through the oracle == autograd through the imported reference (train-style loss), F8."""
+    g = np.load(os.path.join(golden_dir, "F8_gradients.npz"))
+    p = O.make_params(seed=int(g["param_seed"]))
+    img = O.hash_normal(tuple(g["shape"]), int(g["image_seed"]))
+    ft = O.hash_normal(tuple(g["feat_shape"]), int(g["feat_seed"])).requires_grad_(True)
+    w = O.hash_normal((1, 128, 48, 48), int(g["weight_seed"]))
+    po = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "periods" not in k) for k, v in p.items()}
+    (O.naf_forward(po, img, ft, (48, 48), kernel_size=int(g["k"])) * w).sum().backward()
+    ref = torch.from_numpy(g["dfeatures"])
+    assert float((ft.grad - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    for i, name in enumerate(g["names"]):
+        ref = torch.from_numpy(g[f"g{i}"])
+        got = _f8_sample(g, po[str(name)].grad)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), name
