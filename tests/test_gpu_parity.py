@@ -686,3 +686,23 @@ def test_captured_forward_replays_bit_exactly(dev):
     img2 = O.hash_normal((1, 3, 64, 64), 803).to(dev)
     ft2 = O.hash_normal((1, 128, 4, 4), 804).to(dev)
     assert torch.equal(g(img2, ft2), m(img2, ft2, (64, 64)))
+
+
+@pytest.mark.parametrize("img_hw,lr,C,ksz", [
+    ((50, 70), (5, 7), 32, 3),     # ratio 10: integer, but tiles straddle rows (generic tile loop, queries materialised)
+    ((50, 70), (6, 9), 24, 3),     # non-integer ratio: table-driven attention
+    ((96, 64), (6, 4), 64, 3),     # ratio 16: row tiles + rotate-on-load, odd strip / segment geometry in the stem
+    ((33, 47), (33, 47), 16, 7),   # ratio 1 (denoising-like), image sizes that are multiples of nothing
+])
+def test_full_forward_odd_shapes_match_oracle(dev, img_hw, lr, C, ksz):
+    """Whole NAF forward (fused stem, RoPE/pool, attention) on awkward geometries vs the fp32 oracle."""
+    p = O.make_params(seed=31)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *img_hw), 901)
+    ft = O.hash_normal((1, C, *lr), 902)
+    ref = O.naf_forward(p, img, ft, img_hw, kernel_size=ksz)
+    out = m(img.to(dev), ft.to(dev), img_hw).float().cpu()
+    assert out.shape == ref.shape
+    err = (out - ref).abs()
+    assert float(err.max()) <= 6e-2 + 3e-2 * float(ref.abs().max()) and float(err.mean()) <= 6e-3, \
+        f"max {float(err.max()):.3e} mean {float(err.mean()):.3e}"
