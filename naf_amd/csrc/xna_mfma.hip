@@ -1,9 +1,14 @@
 // Eligibility test + dispatcher for the MFMA cell kernel (see xna_mfma_kernel.h).
-#include "xna_mfma_kernel.h"
+#include <stdlib.h>
+
+#include "xna_slide_kernel.h"
 
 #define NAF_DECL(K) int naf_xna_mfma_launch_k##K(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s);
 NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13) NAF_DECL(15)
 #undef NAF_DECL
+int naf_xna_slide_launch_k11(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
+int naf_xna_slide_launch_k13(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
+int naf_xna_slide_launch_k15(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
@@ -73,6 +78,38 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.scale = scale;
     for (int i = 0; i < 4; ++i) {
         p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i]; p.os[i] = a->o_stride[i];
+    }
+    // Large windows on the row-tile geometry: persistent sliding-window kernel (xna_slide_kernel.h).  return_weights
+    // needs the window's row-major slot order and stays on the cell kernel.
+    static const bool no_slide = [] { const char* e = getenv("NAF_XNA_SLIDE"); return e && atoi(e) == 0; }();   // A/B knob
+    if (a->ky >= 11 && !no_slide && a->logits == nullptr && (p.dx % 16) == 0 && (int64_t)p.dy * p.dx / 16 <= 1024) {
+        XnaSlideParams sp;
+        sp.m = p;
+        const int dvt_u = [&] {   // Dv tile of the unstaged plan: the largest divisor of Dv whose window fits the LDS
+            static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
+            for (int c : cand)
+                if (a->Dv % c == 0 && xna_mfma_lds_for(a->ky, 1, c, false) <= 160 * 1024) return c;
+            return 0;
+        }();
+        sp.m.nchunk = a->Dv / dvt_u;
+        const int64_t rows = (int64_t)a->B * a->h * a->heads * sp.m.nchunk;
+        int64_t nseg = (naf_cu_count() + rows - 1) / rows;             // enough workgroups for every CU ...
+        const int64_t max_seg = (a->w + 3) / 4;                          // ... but segments of at least 4 cells
+        if (nseg > max_seg) nseg = max_seg;
+        if (nseg < 1) nseg = 1;
+        sp.seg_len = (int32_t)((a->w + nseg - 1) / nseg);
+        sp.nseg = (int32_t)((a->w + sp.seg_len - 1) / sp.seg_len);
+        const int64_t nbs = rows * sp.nseg;
+        if (nbs > 0x7fffffffLL) {
+            naf_set_error("naf_xna_fwd: grid of %lld workgroups out of range", (long long)nbs);
+            return NAF_ERR_INVALID;
+        }
+        sp.m.nblocks = (uint32_t)nbs;
+        switch (a->ky) {
+            case 11: return naf_xna_slide_launch_k11(sp, dvt_u, a->out_dtype, s);
+            case 13: return naf_xna_slide_launch_k13(sp, dvt_u, a->out_dtype, s);
+            case 15: return naf_xna_slide_launch_k15(sp, dvt_u, a->out_dtype, s);
+        }
     }
     switch (a->ky) {
         case 3: return naf_xna_mfma_launch_k3(p, pl, a->out_dtype, s);

@@ -1,0 +1,359 @@
+// Cross-scale neighbourhood attention forward for LARGE windows (11x11 ... 15x15): sliding-window cell kernel.
+//
+// Same math and MFMA mapping as xna_mfma_kernel.h (attentions.py:16-29,53-75 on the low-res grid).  What differs is
+// the work decomposition.  A 15x15 window with Dv = 256 is 155 KB of K/V in LDS: one workgroup per CU, nothing to
+// overlap its staging with, and with 8 waves x 2 tiles a 16x16 cell is exactly ONE pass, so neither the window
+// staging nor the query loads nor the stores hide behind anything (profiles: staging 31 %, query loads 35 %, stores
+// 24 % of the kernel when switched off one at a time).  Here a persistent workgroup walks a SEGMENT of consecutive
+// cells of one cell row:
+//   * the windows of neighbouring cells differ by one column of KS keys, so only that column is loaded per cell
+//     (15x less staging); the LDS window is a ring over columns: low-res column x lives in column slot x % KS.  The
+//     MFMA contraction order over keys is a free permutation (the same slot order is used for K and V), no masks.
+//   * the new column travels global -> registers while the current cell is computed and is written to LDS between
+//     two barriers; the queries of the next cell are prefetched during the current one; the current cell's stores
+//     drain during the next one.
+// Row-tile geometry only (Wo/w a multiple of 16), two tiles per wave (every K / V^T fragment read feeds two MFMAs),
+// stores as 16-byte pieces.  Rotate-on-load (rope_tab_*) is supported; return_weights is not (the library falls
+// back to xna_mfma_kernel, whose slot order is the window's row-major order).
+#pragma once
+#include <type_traits>
+
+#include "xna_mfma_kernel.h"
+
+struct XnaSlideParams {
+    XnaMfmaParams m;
+    int32_t nseg;      // segments per cell row
+    int32_t seg_len;   // cells per segment
+};
+
+template <int KS, int DVT, typename OutT, int NW, bool ROPE>
+__global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams sp) {
+    const XnaMfmaParams& p = sp.m;
+    constexpr int NT = NW * 64, TPW = 2;
+    using G = XnaGeom<KS, 1>;
+    constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW;
+    constexpr int VROW = XnaVRow<DVT>::VROW;
+    constexpr int CT = DVT / 16, VCH = DVT / 8;
+    constexpr int DCH = KS * (8 + VCH);                 // 16-byte chunks of one new window column (K and V rows)
+    constexpr int NDL = (DCH + NT - 1) / NT;            // ... per thread
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + NSLOT * KROW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, grp = lane >> 4;
+
+    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    const int chunk = L % p.nchunk;
+    L /= p.nchunk;
+    const int head = L % p.heads;
+    L /= p.heads;
+    const int seg = L % sp.nseg;
+    L /= sp.nseg;
+    const int cy0 = L % p.h;
+    const int b = L / p.h;
+    const int cx_lo = seg * sp.seg_len, cx_hi = min(p.w, cx_lo + sp.seg_len);
+    const int y0 = min(max(cy0 - KS / 2, 0), p.h - KS);
+    auto win_x0 = [&](int cx) __attribute__((always_inline)) { return min(max(cx - KS / 2, 0), p.w - KS); };
+
+    const int tpr = p.dx >> 4, ntile = p.dy * tpr;      // row tiles per cell
+    const uint32_t tmagic = (1u << 20) / (uint32_t)tpr + 1u;
+    const bf16_t* qbb = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)(cy0 * p.dy) * p.qs[2];
+    OutT* obb = reinterpret_cast<OutT*>(p.out) + b * p.os[0] + head * p.os[1] + chunk * DVT + (int64_t)(cy0 * p.dy) * p.os[2];
+    const uint32_t q_lane = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u;
+    const uint32_t o_lane = (uint32_t)(col * (int)p.os[3]) * (uint32_t)sizeof(OutT);
+
+    // global tile index g = (cell - cx_lo) * ntile + t walks the segment; a wave handles tiles g, g+1 per pass
+    const int gtot = (cx_hi - cx_lo) * ntile;
+    auto tile_xy = [&](int g, int& cx, int& ty, int& tx0) __attribute__((always_inline)) {
+        const int gc = min(g, gtot - 1);
+        const int ci = gc / ntile, t = gc - ci * ntile;
+        cx = cx_lo + ci;
+        ty = (int)(((uint32_t)t * tmagic) >> 20);
+        tx0 = (t - ty * tpr) * 16;
+    };
+    auto q_ptr = [&](int g) __attribute__((always_inline)) {
+        int cx, ty, tx0;
+        tile_xy(g, cx, ty, tx0);
+        return reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(qbb + (int64_t)ty * p.qs[2] + (int64_t)(cx * p.dx + tx0) * p.qs[3]) + q_lane);
+    };
+    auto rope_fetch = [&](int g, f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        int cx, ty, tx0;
+        tile_xy(g, cx, ty, tx0);
+        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx * p.dx + tx0 + col) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
+        cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
+        cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
+        cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
+        cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
+    };
+    auto rope_apply = [&](bf16x8_t (&qv)[2], const f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float o1, o2;
+            naf_rope_rotate((float)qv[0][i], (float)qv[1][i], cs[i >> 2][i & 3], cs[2 + (i >> 2)][i & 3], o1, o2);
+            qv[0][i] = (bf16_t)o1;
+            qv[1][i] = (bf16_t)o2;
+        }
+    };
+
+    // queries of this wave's first pair of tiles: in flight during the window staging
+    bf16x8_t qf[TPW][2];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const bf16_t* qp = q_ptr(wave * TPW + u);
+        qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+        qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+    }
+
+    // ---- full window of the segment's first cell; low-res column x -> column slot x % KS ----
+    const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
+    const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
+    {
+        const int x0 = win_x0(cx_lo);
+        for (int i = tid; i < NSLOT * 8; i += NT) {
+            const int key = i >> 3, c = i & 7;
+            const int ry = key / KS, xc = x0 + (key - ry * KS);
+            *reinterpret_cast<u32x4_t*>(Ks + (ry * KS + xc % KS) * KROW + c * 8) =
+                *reinterpret_cast<const u32x4_t*>(kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)xc * p.ks[3] + c * 8);
+        }
+        for (int i = tid; i < NSLOT * VCH; i += NT) {
+            const int key = i / VCH, c = i - key * VCH;
+            const int ry = key / KS, xc = x0 + (key - ry * KS);
+            *reinterpret_cast<u32x4_t*>(Vs + (ry * KS + xc % KS) * VROW + c * 8) =
+                *reinterpret_cast<const u32x4_t*>(vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)xc * p.vs[3] + c * 8);
+        }
+    }
+    if constexpr (ROPE) {
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            f32x4_t cs0[4];
+            rope_fetch(wave * TPW + u, cs0);
+            rope_apply(qf[u], cs0);
+        }
+    }
+    // everything loaded so far has landed before the loop is entered (keeps the loop's vmcnt waits exact)
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) asm volatile("; xna slide first tiles landed" ::"v"(qf[u][0]), "v"(qf[u][1]));
+    __syncthreads();
+
+    auto ka_of = [&](int mt) __attribute__((always_inline)) {
+        const int row = (mt * 16 + 15 < NSLOT) ? mt * 16 + col : min(mt * 16 + col, NSLOT - 1);
+        return Ks + row * KROW + grp * 8;
+    };
+    auto va_of = [&](int blk) __attribute__((always_inline)) {
+        const int r = blk * 16 + grp * 4 + (col >> 2);
+        const int row = (blk * 16 + 15 < NSLOT) ? r : min(r, NSLOT - 1);
+        return Vs + row * VROW + (col & 3) * 4;
+    };
+
+    const int pass_tiles = NW * TPW;
+    const int npass = (ntile + pass_tiles - 1) / pass_tiles;
+    for (int cx = cx_lo; cx < cx_hi; ++cx) {
+        // ---- the next cell's new window column: global -> registers now, LDS after this cell's passes ----
+        // (always one column, branch-free: when the window does not move -- image border, last cell of the segment --
+        //  the column that is already there is loaded and rewritten)
+        u32x4_t dl[NDL];
+        int dl_lds[NDL];
+        {
+            const int xn = win_x0(min(cx + 1, cx_hi - 1)) + KS - 1;      // the column that enters replaces column xn - KS (same slot)
+#pragma unroll
+            for (int n = 0; n < NDL; ++n) {
+                const int i = n * NT + tid;
+                const int ic = min(i, DCH - 1);
+                const int ry = ic / (8 + VCH), c = ic - ry * (8 + VCH);
+                const int slot = ry * KS + xn % KS;
+                const bf16_t* src = (c < 8) ? kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)xn * p.ks[3] + c * 8
+                                            : vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)xn * p.vs[3] + (c - 8) * 8;
+                dl[n] = *reinterpret_cast<const u32x4_t*>(src);
+                dl_lds[n] = (i < DCH) ? ((c < 8) ? slot * KROW + c * 8 : NSLOT * KROW + slot * VROW + (c - 8) * 8) : -1;
+            }
+        }
+
+        for (int ps = 0; ps < npass; ++ps) {
+            const int tloc = ps * pass_tiles + wave * TPW;                 // this wave's first tile inside the cell
+            const int g = (cx - cx_lo) * ntile + tloc;                     // ... and in the segment
+            // next pair of tiles of this wave (next pass, or the first pass of the next cell)
+            const int gnext = (ps + 1 < npass) ? g + pass_tiles : (cx + 1 - cx_lo) * ntile + wave * TPW;
+            bf16x8_t qn[TPW][2];
+            f32x4_t csn[TPW][4];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const bf16_t* qp = q_ptr(gnext + u);
+                qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+                if constexpr (ROPE) rope_fetch(gnext + u, csn[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- S^T = K . Q^T, softmax (fp32), P normalised then bf16 ----
+            f32x4_t s[TPW][MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
+                }
+            }
+            bf16x8_t pf[TPW][KST];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mt * 16 + 15 >= NSLOT) s[u][mt][r] = ((mt * 16 + r + grp * 4) < NSLOT) ? s[u][mt][r] : -INFINITY;
+                        m = fmaxf(m, s[u][mt][r]);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float sum = 0.f;
+                const float mc = m * p.scale_log2e;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[u][mt][r], p.scale_log2e, -mc));
+                        s[u][mt][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) s[u][mt] *= inv;
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
+            }
+
+            // ---- O^T = V^T . P^T and stores (tile u valid when it lies inside the cell) ----
+            OutT* opv[TPW];
+            bool okv[TPW];
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int t = min(tloc + u, ntile - 1);
+                const int ty = (int)(((uint32_t)t * tmagic) >> 20), tx0 = (t - ty * tpr) * 16;
+                okv[u] = tloc + u < ntile;
+                opv[u] = reinterpret_cast<OutT*>(reinterpret_cast<char*>(obb + (int64_t)ty * p.os[2] + (int64_t)(cx * p.dx + tx0) * p.os[3]) + o_lane);
+            }
+            auto pv_tile = [&](int ct, f32x4_t (&acc)[TPW]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
+                    bf16x8_t a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[u][ks], acc[u], 0, 0, 0);
+                }
+            };
+            constexpr bool kWide = sizeof(OutT) == 2;
+            constexpr int CTP = kWide ? (CT & ~1) : 0;
+            if constexpr (kWide) {
+#pragma unroll
+                for (int ct = 0; ct < CTP; ct += 2) {
+                    f32x4_t a[TPW], bq[TPW];
+                    pv_tile(ct, a);
+                    pv_tile(ct + 1, bq);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        bf16x4_t ab, bb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ab[i] = (bf16_t)a[u][i];
+                            bb[i] = (bf16_t)bq[u][i];
+                        }
+                        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                        if (okv[u]) *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int ct = CTP; ct < CT; ++ct) {
+                f32x4_t acc[TPW];
+                pv_tile(ct, acc);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+                    if (okv[u]) xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
+            }
+
+            // consume the prefetch below the stores (exact vmcnt waits: the stores stay in flight)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                qf[u][0] = qn[u][0];
+                qf[u][1] = qn[u][1];
+                if constexpr (ROPE) rope_apply(qf[u], csn[u]);
+            }
+        }
+
+        // ---- slide the window: every wave is done with the leaving column ----
+        if (cx + 1 < cx_hi) {
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NDL; ++n)
+                if (dl_lds[n] >= 0) *reinterpret_cast<u32x4_t*>(Ks + dl_lds[n]) = dl[n];
+            __syncthreads();
+        }
+    }
+    // drain the (unused) prefetch past the last tile here (see xna_mfma_kernel.h on hipcc's waitcnt pass)
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) asm volatile("; xna slide loop drained" ::"v"(qf[u][0]), "v"(qf[u][1]));
+}
+
+template <int KS, int DVT, typename OutT, int NW, bool ROPE>
+static int xna_slide_launch_one(const XnaSlideParams& sp, hipStream_t s) {
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, 1, DVT, false, NW>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = xna_slide_kernel<KS, DVT, OutT, NW, ROPE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+            return NAF_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(sp.m.nblocks), dim3(NW * 64), lds, s, sp);
+    return naf_check_launch("xna_slide_kernel");
+}
+
+// Dv tiles as the cell kernel plans them for unstaged stores (largest divisor of Dv that fits the LDS)
+template <int KS>
+static int xna_slide_launch_ks(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s) {
+#define NAF_SLIDE_CASE(D)                                                                              \
+    if constexpr (xna_mfma_lds_for(KS, 1, D, false) <= 160 * 1024) {                                   \
+        if (dvt == D) {                                                                                \
+            constexpr int NWV = xna_mfma_lds_for(KS, 1, D, false) > 80 * 1024 ? 8 : 4;                 \
+            if (sp.m.tab_y != nullptr) {                                                               \
+                if (out_dtype == NAF_BF16) return xna_slide_launch_one<KS, D, bf16_t, NWV, true>(sp, s); \
+                return xna_slide_launch_one<KS, D, float, NWV, true>(sp, s);                           \
+            }                                                                                          \
+            if (out_dtype == NAF_BF16) return xna_slide_launch_one<KS, D, bf16_t, NWV, false>(sp, s);  \
+            return xna_slide_launch_one<KS, D, float, NWV, false>(sp, s);                              \
+        }                                                                                              \
+    }
+    NAF_SLIDE_CASE(16)
+    NAF_SLIDE_CASE(32)
+    NAF_SLIDE_CASE(48)
+    NAF_SLIDE_CASE(64)
+    NAF_SLIDE_CASE(96)
+    NAF_SLIDE_CASE(128)
+    NAF_SLIDE_CASE(192)
+    NAF_SLIDE_CASE(256)
+#undef NAF_SLIDE_CASE
+    naf_set_error("naf_xna_fwd: no sliding-window instantiation for window %d, Dv tile %d", KS, dvt);
+    return NAF_ERR_UNSUPPORTED;
+}

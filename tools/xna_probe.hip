@@ -182,6 +182,21 @@ int main(int argc, char** argv) {
         run_pattern<1>(p, reps, "pattern: 384 B contiguous pieces", bytes);
         run_pattern<0>(p, reps, "pattern: 16 px x 64 B pieces (again)", bytes);
     }
+    if (PROBE_KS >= 11) {
+        // large windows: the library's configuration is unstaged, 8 waves, 2 tiles per wave
+        run<0, false, 1, 8, 2>(p, reps, "full kernel (8 waves, 2 tiles/wave)", bytes);
+        run<1, false, 1, 8, 2>(p, reps, "no output stores", bytes);
+        run<2, false, 1, 8, 2>(p, reps, "no PV mfma / V reads", bytes);
+        run<4, false, 1, 8, 2>(p, reps, "no Q loads", bytes);
+        run<8, false, 1, 8, 2>(p, reps, "no K/V staging loads", bytes);
+        run<16, false, 1, 8, 2>(p, reps, "no QK mfma", bytes);
+        run<2 | 16, false, 1, 8, 2>(p, reps, "no mfma at all (loads+softmax+stores)", bytes);
+        run<1 | 4 | 8, false, 1, 8, 2>(p, reps, "compute only, no staging", bytes);
+        run<1 | 2 | 4 | 8 | 16, false, 1, 8, 2>(p, reps, "softmax only", bytes);
+        run<0, false, 1, 8, 1>(p, reps, "8 waves, 1 tile per wave", bytes);
+        run<0, false, 1, 4, 2>(p, reps, "4 waves, 2 tiles per wave", bytes);
+        return 0;
+    }
     run<0>(p, reps, "full kernel", bytes);
     run<1>(p, reps, "no output stores", bytes);
     run<2>(p, reps, "no PV mfma / V reads", bytes);
