@@ -183,33 +183,31 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 const bf16_t* qp = q_ptr(gnext + u);
                 qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
                 qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-                if constexpr (ROPE) rope_fetch(gnext + u, csn[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
 
-            // ---- S^T = K . Q^T, softmax (fp32), P normalised then bf16 ----
-            f32x4_t s[TPW][MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
-                }
-            }
+            // ---- S^T = K . Q^T, softmax (fp32), P normalised then bf16: one tile at a time, so that only 64 score
+            // registers are live (the K fragments are read twice; they are 1/8 of the V^T traffic) ----
             bf16x8_t pf[TPW][KST];
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
+                f32x4_t s[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    s[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
+                        s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[mt], 0, 0, 0);
+                    }
+                }
                 float m = -INFINITY;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (mt * 16 + 15 >= NSLOT) s[u][mt][r] = ((mt * 16 + r + grp * 4) < NSLOT) ? s[u][mt][r] : -INFINITY;
-                        m = fmaxf(m, s[u][mt][r]);
+                        if (mt * 16 + 15 >= NSLOT) s[mt][r] = ((mt * 16 + r + grp * 4) < NSLOT) ? s[mt][r] : -INFINITY;
+                        m = fmaxf(m, s[mt][r]);
                     }
                 m = fmaxf(m, __shfl_xor(m, 16));
                 m = fmaxf(m, __shfl_xor(m, 32));
@@ -219,19 +217,29 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[u][mt][r], p.scale_log2e, -mc));
-                        s[u][mt][r] = e;
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2e, -mc));
+                        s[mt][r] = e;
                         sum += e;
                     }
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
                 const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) s[u][mt] *= inv;
+                for (int mt = 0; mt < MT; ++mt) s[mt] *= inv;
 #pragma unroll
                 for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
+                    for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[2 * ks + (j >> 2)][j & 3];
+                __builtin_amdgcn_sched_barrier(0);   // keep the two tiles' score registers from overlapping
+            }
+
+            // RoPE table rows of the next tiles: fetched HERE, when the 128 score registers are dead (fetched with the
+            // queries they made the 15x15 / Dv 256 variant spill), still ahead of this pass's stores
+            if constexpr (ROPE) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) rope_fetch(gnext + u, csn[u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 
             // ---- O^T = V^T . P^T and stores (tile u valid when it lies inside the cell) ----
