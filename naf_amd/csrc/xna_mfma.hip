@@ -6,6 +6,8 @@
 #define NAF_DECL(K) int naf_xna_mfma_launch_k##K(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int out_dtype, hipStream_t s);
 NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13) NAF_DECL(15)
 #undef NAF_DECL
+int naf_xna_slide_launch_k7(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
+int naf_xna_slide_launch_k9(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
 int naf_xna_slide_launch_k11(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
 int naf_xna_slide_launch_k13(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
 int naf_xna_slide_launch_k15(const XnaSlideParams& sp, int dvt, int out_dtype, hipStream_t s);
@@ -79,10 +81,11 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     for (int i = 0; i < 4; ++i) {
         p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i]; p.os[i] = a->o_stride[i];
     }
-    // Large windows on the row-tile geometry: persistent sliding-window kernel (xna_slide_kernel.h).  return_weights
-    // needs the window's row-major slot order and stays on the cell kernel.
+    // Whenever the plan has no staged stores (windows of 11x11 and up, fp32 output, windows + staging tiles that would
+    // leave fewer than 3 workgroups per CU) and the geometry has row tiles: persistent sliding-window kernel
+    // (xna_slide_kernel.h).  return_weights needs the window's row-major slot order and stays on the cell kernel.
     static const bool no_slide = [] { const char* e = getenv("NAF_XNA_SLIDE"); return e && atoi(e) == 0; }();   // A/B knob
-    if (a->ky >= 11 && !no_slide && a->logits == nullptr && (p.dx % 16) == 0 && (int64_t)p.dy * p.dx / 16 <= 1024) {
+    if (a->ky >= 7 && !pl.staged && !no_slide && a->logits == nullptr && (p.dx % 16) == 0 && (int64_t)p.dy * p.dx / 16 <= 1024) {
         XnaSlideParams sp;
         sp.m = p;
         const int dvt_u = [&] {   // Dv tile of the unstaged plan: the largest divisor of Dv whose window fits the LDS
@@ -106,6 +109,8 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
         }
         sp.m.nblocks = (uint32_t)nbs;
         switch (a->ky) {
+            case 7: return naf_xna_slide_launch_k7(sp, dvt_u, a->out_dtype, s);
+            case 9: return naf_xna_slide_launch_k9(sp, dvt_u, a->out_dtype, s);
             case 11: return naf_xna_slide_launch_k11(sp, dvt_u, a->out_dtype, s);
             case 13: return naf_xna_slide_launch_k13(sp, dvt_u, a->out_dtype, s);
             case 15: return naf_xna_slide_launch_k15(sp, dvt_u, a->out_dtype, s);

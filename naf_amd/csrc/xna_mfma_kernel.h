@@ -619,14 +619,12 @@ inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
         for (int cb = xna_mfma_cb(ks); cb >= 1; --cb) {
             for (int st = can_stage ? 1 : 0; st >= 0; --st) {
                 const size_t lds = xna_mfma_lds_for(ks, cb, c, st != 0);
-                // Staged stores win whenever >= 3 workgroups stay resident per CU, and at 2 when the unstaged
-                // kernel would keep >= 4 (k7, Dv 256: 0.57 vs 0.67 ms); they lose at 1 resident workgroup (k9,
-                // Dv 256: 0.94 vs 0.69 ms) and tie at 2 vs 3 (k9, Dv 192).  tools/xna_stage_sweep.py, G1 grid.
+                // Staged whole-row stores pay off while >= 3 workgroups stay resident per CU; below that the
+                // unstaged plan is taken, which the launcher serves with the sliding-window kernel on the row-tile
+                // geometry (tools/xna_stage_sweep.py, tools/f32out_probe.py: k7 Dv 256 staged 0.58 ms, sliding 0.55 ms;
+                // k9 Dv 256 cell 0.67 ms, sliding 0.58 ms).
                 if (st && force == 0) continue;
-                if (st && force != 1) {
-                    const int wg_st = (int)(160 * 1024 / lds), wg_un = (int)(160 * 1024 / xna_mfma_lds_for(ks, cb, c, false));
-                    if (!(wg_st >= 3 || (wg_st == 2 && wg_un >= 4))) continue;
-                }
+                if (st && force != 1 && (int)(160 * 1024 / lds) < 3) continue;
                 if (lds <= 160 * 1024) {
                     pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->tpw = tpw; pl->lds = lds;
                     return true;
