@@ -706,3 +706,21 @@ def test_full_forward_odd_shapes_match_oracle(dev, img_hw, lr, C, ksz):
     err = (out - ref).abs()
     assert float(err.max()) <= 6e-2 + 3e-2 * float(ref.abs().max()) and float(err.mean()) <= 6e-3, \
         f"max {float(err.max()):.3e} mean {float(err.mean()):.3e}"
+
+
+@pytest.mark.parametrize("B,C,lr,out_sz,ksz,out_dtype", [
+    (1, 192, (9, 9), (144, 144), 9, torch.float32),        # window = whole grid: the ring never slides
+    (2, 256, (12, 20), (192, 320), 7, torch.float32),      # fp32 output -> sliding kernel, several segments per row
+    (1, 192, (11, 13), (176, 416), 11, torch.bfloat16),    # 11x11, dx = 32 (two row tiles per cell row), Dv = 48 (odd tile count)
+    (1, 1024, (15, 17), (240, 272), 15, torch.bfloat16),   # 15x15, Dv = 256: 155 KB window, 8 waves
+])
+def test_sliding_window_kernel_matches_oracle(dev, B, C, lr, out_sz, ksz, out_dtype):
+    """xna_slide_kernel (plans without staged stores): ring-of-columns window, per-cell column refresh, segment borders."""
+    heads = 4
+    q = bf16r(O.hash_normal((B, 256, *out_sz), 951))
+    k = bf16r(O.hash_normal((B, 256, *lr), 952))
+    v = bf16r(O.hash_normal((B, C, *lr), 953))
+    ref = O.xna_lowres(q, k, v, ksz, heads)
+    out = run_xna(dev, q, k, v, ksz, heads, out_dtype=out_dtype, path="mfma")
+    tol = 6e-3 if out_dtype == torch.float32 else 1.2e-2
+    assert_close(out, ref, tol, tol, f"slide k={ksz}")
