@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
     ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
     ap.add_argument("--no-fuse-conv0", action="store_true", help="store the 1x1 branch's conv0 activation (A/B against recompute)")
+    ap.add_argument("--multi-call", action="store_true", help="one foreign call per kernel (per-kernel phase timers) instead of "
+                    "naf_forward's single call")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a hipGraph (NAF.capture); no per-kernel "
                     "event timing is possible inside a graph, so `roofline` is null in this mode")
     args = ap.parse_args()
@@ -147,6 +149,7 @@ def main():
     torch.manual_seed(0)                                        # same random-init weights on every rank...
     model = NAF(kernel_size=ksz).to(dev).eval()
     model.fuse_rope = not args.no_fuse_rope
+    model.single_call = not args.multi_call
     model.image_encoder.fuse_conv0 = not args.no_fuse_conv0
     if world > 1:
         nd.broadcast_parameters(model, src=0)                   # ...and made identical by one RCCL broadcast

@@ -237,6 +237,58 @@ typedef struct naf_xna_bwd_args {
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
+/* ---- whole forward in one call ----------------------------------------------------------------------
+ * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
+ * encoder branches with img_layers blocks, 4 RoPE heads = 4 attention heads, image size == output size, integer
+ * ratio with Wo/w a multiple of 16): every launch of the path above -- conv stem, key pooling, value packing,
+ * attention with rotate-on-load -- is issued from one host call on the caller's stream, so a C/C++ host needs
+ * nothing else and a Python host pays one foreign call per forward instead of fourteen.
+ *   image     device [B, 3, H, W] f32/bf16, strides {b, c, y, x}
+ *   features  device [B, C, h, w] f32/bf16, strides {b, c, y, x}
+ *   out       device out_dtype, dense channels-last [B, H, W, C] (logical [B, C, H, W] view for the caller)
+ *   branch[i] parameters of encoder / sem_encoder (naf.py:26-27): conv0 weight f32 [128][3][k0][k0] + bias, then
+ *             per block layer l < nlayer: GroupNorm weight / bias f32 [128], conv weight packed bf16
+ *             [k*k][128][128] (= weight.permute(2,3,0,1)) and bias f32 [128]
+ *   tab_y / tab_x  RoPE tables from naf_rope_tables for (H, W)
+ *   workspace device scratch of naf_forward_workspace_bytes() bytes (activations, GroupNorm sums, keys, packed
+ *             values); the library still owns no memory
+ *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
+ *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
+ * Shapes outside the list above return NAF_ERR_UNSUPPORTED (compose the individual entry points instead). */
+#define NAF_MAX_STEM_LAYERS 8
+typedef struct naf_stem_branch {
+    const float* conv0_weight;
+    const float* conv0_bias;
+    int32_t conv0_ksize; /* 1 or 3 */
+    int32_t ksize;       /* block convolutions: 1 or 3 */
+    const float* gn_weight[NAF_MAX_STEM_LAYERS];
+    const float* gn_bias[NAF_MAX_STEM_LAYERS];
+    const void* conv_weight_packed[NAF_MAX_STEM_LAYERS];
+    const float* conv_bias[NAF_MAX_STEM_LAYERS];
+} naf_stem_branch;
+typedef struct naf_forward_args {
+    const void* image;
+    const void* features;
+    void* out;
+    const float* tab_y;
+    const float* tab_x;
+    void* workspace;
+    size_t workspace_bytes;
+    void* events[2];
+    naf_stem_branch branch[2];
+    int32_t nlayer; /* GroupNorm/SiLU/conv layers per branch = 2 * img_layers */
+    int32_t image_dtype, feat_dtype, out_dtype; /* naf_dtype */
+    int32_t B, H, W, h, w, C, heads, ksize;
+    float gn_eps;
+    float scale; /* <= 0: Dq^-0.5 */
+    int64_t image_stride[4];
+    int64_t feat_stride[4];
+} naf_forward_args;
+size_t naf_forward_workspace_bytes(const naf_forward_args* a);
+/* 1 when naf_forward serves these arguments, 0 when not (then NAF_ERR_UNSUPPORTED), negative naf_status if invalid. */
+int naf_forward_supported(const naf_forward_args* a);
+int naf_forward(const naf_forward_args* a, naf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

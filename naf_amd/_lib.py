@@ -72,6 +72,29 @@ class XnaBwdArgs(C.Structure):
     ]
 
 
+MAX_STEM_LAYERS = 8
+
+
+class StemBranch(C.Structure):
+    _fields_ = [
+        ("conv0_weight", C.c_void_p), ("conv0_bias", C.c_void_p), ("conv0_ksize", C.c_int32), ("ksize", C.c_int32),
+        ("gn_weight", C.c_void_p * MAX_STEM_LAYERS), ("gn_bias", C.c_void_p * MAX_STEM_LAYERS),
+        ("conv_weight_packed", C.c_void_p * MAX_STEM_LAYERS), ("conv_bias", C.c_void_p * MAX_STEM_LAYERS),
+    ]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("image", C.c_void_p), ("features", C.c_void_p), ("out", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("events", C.c_void_p * 2),
+        ("branch", StemBranch * 2),
+        ("nlayer", C.c_int32), ("image_dtype", C.c_int32), ("feat_dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("C", C.c_int32),
+        ("heads", C.c_int32), ("ksize", C.c_int32), ("gn_eps", C.c_float), ("scale", C.c_float),
+        ("image_stride", I64x4), ("feat_stride", I64x4),
+    ]
+
+
 # symbol -> (restype, argtypes); must list every function include/naf_hip.h declares
 SIGNATURES = {
     "naf_version": (C.c_int, []),
@@ -88,6 +111,9 @@ SIGNATURES = {
     "naf_xna_fwd": (C.c_int, [C.POINTER(XnaArgs), C.c_void_p]),
     "naf_xna_bwd_supported": (C.c_int, [C.POINTER(XnaBwdArgs)]),
     "naf_xna_bwd": (C.c_int, [C.POINTER(XnaBwdArgs), C.c_void_p]),
+    "naf_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ForwardArgs)]),
+    "naf_forward_supported": (C.c_int, [C.POINTER(ForwardArgs)]),
+    "naf_forward": (C.c_int, [C.POINTER(ForwardArgs), C.c_void_p]),
 }
 
 _lib = None

@@ -227,4 +227,157 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
     return naf_launch_xna_generic_bwd(a, scale, static_cast<hipStream_t>(stream));
 }
 
+// ---- whole forward in one call ---------------------------------------------------------------------------
+namespace {
+struct FwdLayout {
+    size_t stats, buf0, buf1, cat, keys, vp, total;
+};
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+FwdLayout fwd_layout(const naf_forward_args* a) {
+    FwdLayout L;
+    const size_t px = (size_t)a->B * a->H * a->W;
+    size_t off = 0;
+    L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * a->B * 16 * sizeof(double));
+    L.buf0 = off;  off = align256(off + px * 128 * 2);
+    L.buf1 = off;  off = align256(off + px * 128 * 2);
+    L.cat = off;   off = align256(off + px * 256 * 2);
+    L.keys = off;  off = align256(off + (size_t)a->B * a->h * a->w * 256 * 2);
+    L.vp = off;    off = align256(off + (size_t)a->B * a->h * a->w * a->C * 2);
+    L.total = off;
+    return L;
+}
+int fwd_validate(const naf_forward_args* a) {
+    NAF_REQUIRE(a != nullptr, "naf_forward: args is NULL");
+    NAF_REQUIRE(a->image && a->features && a->out && a->tab_y && a->tab_x, "naf_forward: NULL tensor pointer");
+    NAF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->h > 0 && a->w > 0 && a->C > 0 && a->heads > 0, "naf_forward: non-positive size");
+    NAF_REQUIRE(a->nlayer >= 1 && a->nlayer <= NAF_MAX_STEM_LAYERS, "naf_forward: %d block layers (1..%d)", a->nlayer, NAF_MAX_STEM_LAYERS);
+    NAF_REQUIRE(a->C % a->heads == 0, "naf_forward: %d feature channels not divisible by %d heads", a->C, a->heads);
+    for (int br = 0; br < 2; ++br) {
+        const naf_stem_branch& b = a->branch[br];
+        NAF_REQUIRE(b.conv0_weight && b.conv0_bias, "naf_forward: branch %d: NULL conv0 parameters", br);
+        NAF_REQUIRE((b.conv0_ksize == 1 || b.conv0_ksize == 3) && (b.ksize == 1 || b.ksize == 3), "naf_forward: branch %d: kernel sizes", br);
+        for (int l = 0; l < a->nlayer; ++l)
+            NAF_REQUIRE(b.gn_weight[l] && b.gn_bias[l] && b.conv_weight_packed[l] && b.conv_bias[l], "naf_forward: branch %d layer %d: NULL parameter", br, l);
+    }
+    return NAF_OK;
+}
+// the arguments of the attention call this forward would make (for eligibility and for the launch)
+void fwd_xna_args(const naf_forward_args* a, const FwdLayout& L, naf_xna_args* x) {
+    char* ws = static_cast<char*>(a->workspace);
+    const int Dv = a->C / a->heads;
+    *x = naf_xna_args{};
+    x->q = ws ? ws + L.cat : reinterpret_cast<const void*>(0x100);
+    x->k_lr = ws ? ws + L.keys : reinterpret_cast<const void*>(0x100);
+    x->v_lr = ws ? ws + L.vp : reinterpret_cast<const void*>(0x100);
+    x->out = a->out;
+    x->rope_tab_y = a->tab_y; x->rope_tab_x = a->tab_x;
+    x->B = a->B; x->heads = a->heads; x->Ho = a->H; x->Wo = a->W; x->h = a->h; x->w = a->w;
+    x->Dq = 256 / a->heads; x->Dv = Dv; x->ky = a->ksize; x->kx = a->ksize;
+    x->out_dtype = a->out_dtype; x->path = NAF_XNA_MFMA; x->scale = a->scale;
+    const int64_t Dq = x->Dq;
+    const int64_t qs[4] = {(int64_t)a->H * a->W * 256, Dq, (int64_t)a->W * 256, 256};
+    const int64_t ks[4] = {(int64_t)a->h * a->w * 256, Dq, (int64_t)a->w * 256, 256};
+    const int64_t vs[4] = {(int64_t)a->h * a->w * a->C, Dv, (int64_t)a->w * a->C, a->C};
+    const int64_t os[4] = {(int64_t)a->H * a->W * a->C, Dv, (int64_t)a->W * a->C, a->C};
+    for (int i = 0; i < 4; ++i) { x->q_stride[i] = qs[i]; x->k_stride[i] = ks[i]; x->v_stride[i] = vs[i]; x->o_stride[i] = os[i]; }
+}
+}  // namespace
+
+size_t naf_forward_workspace_bytes(const naf_forward_args* a) {
+    if (a == nullptr || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->h <= 0 || a->w <= 0 || a->C <= 0 || a->nlayer < 0) return 0;
+    return fwd_layout(a).total;
+}
+
+int naf_forward_supported(const naf_forward_args* a) {
+    const int rc = fwd_validate(a);
+    if (rc != NAF_OK) return -rc;
+    if (a->heads != 4 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
+    if (a->H < 2 || a->W < 2) return 0;
+    naf_xna_args x;
+    fwd_xna_args(a, fwd_layout(a), &x);
+    if (reinterpret_cast<uintptr_t>(a->out) % 16) return 0;
+    if (xna_validate(&x) != NAF_OK) return 0;
+    return (naf_xna_mfma_eligible(&x, nullptr, nullptr) && naf_xna_mfma_rope_ok(&x)) ? 1 : 0;
+}
+
+int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
+    const int sup = naf_forward_supported(a);
+    if (sup < 0) return -sup;
+    if (sup == 0) {
+        naf_set_error("naf_forward: unsupported configuration (needs 4 heads, integer ratio with Wo/w %% 16 == 0, window <= 15 "
+                      "fitting the grid, Dv %% 16 == 0); compose the individual entry points instead");
+        return NAF_ERR_UNSUPPORTED;
+    }
+    const FwdLayout L = fwd_layout(a);
+    NAF_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= L.total, "naf_forward: workspace of %zu bytes needed, %zu given", L.total, a->workspace_bytes);
+    NAF_REQUIRE(reinterpret_cast<uintptr_t>(a->workspace) % 256 == 0, "naf_forward: workspace must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(a->workspace);
+    double* stats = reinterpret_cast<double*>(ws + L.stats);
+    const size_t stat_stride = (size_t)a->B * 16;   // doubles per (branch, stage)
+    if (hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
+        naf_set_error("naf_forward: hipMemsetAsync failed");
+        return NAF_ERR_LAUNCH;
+    }
+    void* bufs[2] = {ws + L.buf0, ws + L.buf1};
+    char* cat = ws + L.cat;
+    const int64_t dense[3] = {(int64_t)a->H * a->W * 128, (int64_t)a->W * 128, 128};
+    const int64_t cat_st[3] = {(int64_t)a->H * a->W * 256, (int64_t)a->W * 256, 256};
+    for (int br = 0; br < 2; ++br) {
+        const naf_stem_branch& b = a->branch[br];
+        double* st = stats + (size_t)br * (a->nlayer + 1) * stat_stride;
+        naf_stem_conv0_args c0{};
+        c0.image = a->image; c0.weight = b.conv0_weight; c0.bias = b.conv0_bias; c0.stats_out = st;
+        c0.image_dtype = a->image_dtype; c0.ksize = b.conv0_ksize; c0.B = a->B; c0.H = a->H; c0.W = a->W;
+        for (int i = 0; i < 4; ++i) c0.image_stride[i] = a->image_stride[i];
+        // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
+        const bool recompute = b.conv0_ksize == 1 && b.ksize == 1;
+        c0.y = recompute ? nullptr : bufs[0];
+        for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
+        int rc = naf_stem_conv0_fwd(&c0, stream);
+        if (rc != NAF_OK) return rc;
+        const void* cur = bufs[0];
+        for (int l = 0; l < a->nlayer; ++l) {
+            const bool last = l == a->nlayer - 1;
+            naf_stem_conv_args c{};
+            c.x = (recompute && l == 0) ? nullptr : cur;
+            c.first = (recompute && l == 0) ? &c0 : nullptr;
+            c.y = last ? static_cast<void*>(cat + (size_t)br * 128 * 2) : bufs[(l + 1) & 1];
+            c.w_packed = b.conv_weight_packed[l]; c.bias = b.conv_bias[l];
+            c.gn_weight = b.gn_weight[l]; c.gn_bias = b.gn_bias[l];
+            c.stats_in = st + (size_t)l * stat_stride;
+            c.stats_out = last ? nullptr : st + (size_t)(l + 1) * stat_stride;
+            c.ksize = b.ksize; c.B = a->B; c.H = a->H; c.W = a->W; c.eps = a->gn_eps;
+            for (int i = 0; i < 3; ++i) { c.x_stride[i] = dense[i]; c.y_stride[i] = last ? cat_st[i] : dense[i]; }
+            rc = naf_stem_conv_fwd(&c, stream);
+            if (rc != NAF_OK) return rc;
+            cur = c.y;
+        }
+    }
+    // keys: pooled RoPE'd guidance (queries are rotated on load by the attention kernel)
+    naf_rope_pool_args rp{};
+    rp.x = cat; rp.q = nullptr; rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
+    rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = a->heads; rp.Ho = a->H; rp.Wo = a->W; rp.h = a->h; rp.w = a->w;
+    const int64_t xs[4] = {(int64_t)a->H * a->W * 256, 1, (int64_t)a->W * 256, 256};
+    const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / a->heads, (int64_t)a->w * 256, 256};
+    for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = 0; rp.k_stride[i] = kst[i]; }
+    int rc = naf_rope_pool_fwd(&rp, stream);
+    if (rc != NAF_OK) return rc;
+    rc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, stream);
+    if (rc != NAF_OK) return rc;
+    naf_xna_args x;
+    fwd_xna_args(a, L, &x);
+    if (a->events[0] && hipEventRecord(static_cast<hipEvent_t>(a->events[0]), s) != hipSuccess) {
+        naf_set_error("naf_forward: hipEventRecord failed");
+        return NAF_ERR_LAUNCH;
+    }
+    rc = naf_xna_fwd(&x, stream);
+    if (rc != NAF_OK) return rc;
+    if (a->events[1] && hipEventRecord(static_cast<hipEvent_t>(a->events[1]), s) != hipSuccess) {
+        naf_set_error("naf_forward: hipEventRecord failed");
+        return NAF_ERR_LAUNCH;
+    }
+    return NAF_OK;
+}
+
 }  // extern "C"

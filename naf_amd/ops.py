@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import XnaArgs, XnaBwdArgs, RopePoolArgs, StemConv0Args, StemConvArgs, I64x3, I64x4
+from ._lib import XnaArgs, XnaBwdArgs, RopePoolArgs, StemConv0Args, StemConvArgs, ForwardArgs, I64x3, I64x4
 
 _DT = {torch.bfloat16: _lib.NAF_BF16, torch.float32: _lib.NAF_F32}
 
@@ -402,3 +402,54 @@ def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logi
     if sel < 0:
         _lib.check(-sel, "naf_xna_select")
     return {1: "mfma", 2: "generic"}[sel]
+
+
+# ------------------------------------------------------------------------------------------------
+class ForwardPlan:
+    """Argument block of ``naf_forward`` (the whole forward in ONE foreign call) for fixed parameters and shapes.
+    Built once per (parameter versions, shapes); ``run`` only swaps the image / features / output pointers."""
+
+    def __init__(self, branches, nlayer: int, gn_eps: float, tabs, image: torch.Tensor, features: torch.Tensor,
+                 heads: int, ksize: int, out_dtype: torch.dtype, scale: Optional[float]):
+        lib = _lib.load()
+        B, _, H, W = image.shape
+        _, Cc, h, w = features.shape
+        a = ForwardArgs()
+        a.tab_y, a.tab_x = tabs[0].data_ptr(), tabs[1].data_ptr()
+        a.nlayer = nlayer
+        a.image_dtype, a.feat_dtype, a.out_dtype = _DT[image.dtype], _DT[features.dtype], _DT[out_dtype]
+        a.B, a.H, a.W, a.h, a.w, a.C, a.heads, a.ksize = B, H, W, h, w, Cc, heads, ksize
+        a.gn_eps = float(gn_eps)
+        a.scale = float(scale) if scale else 0.0
+        self._keep = [tabs]
+        for br, (w0, b0, k0, kb, layers) in enumerate(branches):
+            sb = a.branch[br]
+            sb.conv0_weight, sb.conv0_bias, sb.conv0_ksize, sb.ksize = w0.data_ptr(), b0.data_ptr(), k0, kb
+            self._keep += [w0, b0]
+            for l, (gw, gb, wp, cb) in enumerate(layers):
+                sb.gn_weight[l], sb.gn_bias[l] = gw.data_ptr(), gb.data_ptr()
+                sb.conv_weight_packed[l], sb.conv_bias[l] = wp.data_ptr(), cb.data_ptr()
+                self._keep += [gw, gb, wp, cb]
+        a.image_stride = _strides4(image, (0, 1, 2, 3))
+        a.feat_stride = _strides4(features, (0, 1, 2, 3))
+        # shape / alignment query with placeholder pointers (nothing is dereferenced)
+        a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), image.data_ptr() & ~0xFF
+        self.supported = lib.naf_forward_supported(C.byref(a)) == 1
+        self.args, self.lib = a, lib
+        self.out_dtype, self.shape_out = out_dtype, (B, H, W, Cc)
+        self.ws_bytes = int(lib.naf_forward_workspace_bytes(C.byref(a))) if self.supported else 0
+        self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype)
+
+    def run(self, image: torch.Tensor, features: torch.Tensor, events=None) -> torch.Tensor:
+        a = self.args
+        dev = image.device
+        ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+        out = torch.empty(self.shape_out, dtype=self.out_dtype, device=dev)
+        a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), out.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes
+        a.events[0] = events[0].cuda_event if events else None
+        a.events[1] = events[1].cuda_event if events else None
+        with torch.cuda.device(dev):
+            rc = self.lib.naf_forward(C.byref(a), _stream(image))
+        _lib.check(rc, "naf_forward")
+        return out.permute(0, 3, 1, 2)

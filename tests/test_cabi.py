@@ -38,15 +38,16 @@ def test_struct_layout_matches_header(built_lib):
     """sizeof of the ctypes mirrors == the C structs (checked through a tiny C probe compiled with gcc)."""
     import subprocess, tempfile
     from naf_amd import _lib
-    src = ('#include "naf_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(naf_rope_pool_args), '
-           'sizeof(naf_xna_args), sizeof(naf_stem_conv0_args), sizeof(naf_stem_conv_args), sizeof(naf_xna_bwd_args));return 0;}\n')
+    src = ('#include "naf_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(naf_rope_pool_args), '
+           'sizeof(naf_xna_args), sizeof(naf_stem_conv0_args), sizeof(naf_stem_conv_args), sizeof(naf_xna_bwd_args), '
+           'sizeof(naf_forward_args));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
-        a, b, c, e, f = map(int, subprocess.check_output([os.path.join(d, "p")]).split())
+        a, b, c, e, f, g = map(int, subprocess.check_output([os.path.join(d, "p")]).split())
     assert a == C.sizeof(_lib.RopePoolArgs) and b == C.sizeof(_lib.XnaArgs)
     assert c == C.sizeof(_lib.StemConv0Args) and e == C.sizeof(_lib.StemConvArgs)
-    assert f == C.sizeof(_lib.XnaBwdArgs)
+    assert f == C.sizeof(_lib.XnaBwdArgs) and g == C.sizeof(_lib.ForwardArgs)
 
 
 @pytest.mark.parametrize("L_in", [1, 2, 3, 5, 7, 14, 28, 32, 64])

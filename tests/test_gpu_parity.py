@@ -724,3 +724,22 @@ def test_sliding_window_kernel_matches_oracle(dev, B, C, lr, out_sz, ksz, out_dt
     out = run_xna(dev, q, k, v, ksz, heads, out_dtype=out_dtype, path="mfma")
     tol = 6e-3 if out_dtype == torch.float32 else 1.2e-2
     assert_close(out, ref, tol, tol, f"slide k={ksz}")
+
+
+@pytest.mark.parametrize("feat_dtype", [torch.bfloat16, torch.float32])
+def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
+    """naf_forward (the whole forward in one foreign call) == the same kernels launched one by one, bit for bit."""
+    p = O.make_params(seed=41)
+    m = _load_model(dev, p, kernel_size=5)
+    img = O.hash_normal((2, 3, 96, 128), 961).to(dev)
+    ft = O.hash_normal((2, 128, 6, 8), 962).to(dev).to(feat_dtype)
+    assert m._forward_plan(img, ft, (96, 128)) is not None
+    a = m(img, ft, (96, 128))
+    m.single_call = False
+    b = m(img, ft, (96, 128))
+    m.single_call = True
+    assert a.dtype == b.dtype and torch.equal(a, b)
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
+    # shapes it does not serve fall back to the composed path transparently
+    assert m._forward_plan(img, ft, (48, 64)) is None
