@@ -43,6 +43,7 @@ struct RopePoolParams {
     int32_t B, Cq, heads, Dh, Ho, Wo, h, w;
     int32_t tpp;     // threads per pixel (power of two dividing 256)
     int32_t nchunk;  // pair-chunks per pixel = Cq / (2 * VEC)
+    int32_t tab_lds; // 1: the cell's table rows are staged in LDS (vector path)
     int64_t xs[4], qs[4], ks[4];
 };
 
@@ -103,6 +104,20 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
     const int wy = ye - ys, wx = xe - xs;
     const int npix = wy * wx;
 
+    // vector path: the (wy + wx) table rows this cell needs go to LDS once (4 KB for a 16x16 cell); reading them from
+    // global for every pixel made the table loads 2/3 of the kernel's load instructions (0.154 vs 0.133 ms without)
+    float* tl = red + (256 / p.tpp) * p.Cq;
+    const int TS = 2 * (p.Dh >> 2) + 4;   // padded row: cos[quarter] | sin[quarter]
+    if (p.tab_lds) {
+        const int q4 = (p.Dh >> 2) >> 1;  // 16-byte pieces per row = 2 * quarter / 4
+        for (int i = tid; i < (wy + wx) * q4; i += 256) {
+            const int r = i / q4, c = i - r * q4;
+            const float* src = (r < wy) ? p.tab_y + (int64_t)(ys + r) * 2 * (p.Dh >> 2) : p.tab_x + (int64_t)(xs + r - wy) * 2 * (p.Dh >> 2);
+            *reinterpret_cast<f32x4_t*>(tl + r * TS + c * 4) = *reinterpret_cast<const f32x4_t*>(src + c * 4);
+        }
+        __syncthreads();
+    }
+
     const int chunk = tid & (p.tpp - 1);
     const int plane = tid / p.tpp;
     const int nplanes = 256 / p.tpp;
@@ -132,10 +147,20 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
             if constexpr (VEC == 8) {
                 // Dh % 32 == 0: the 8 angle indices t0..t0+7 are all row angles or all column angles ->
                 // four 16-byte table loads instead of sixteen scalar ones
-                const float* tb = (t0 < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + t0)
-                                                 : (p.tab_x + (int64_t)x * 2 * quarter + (t0 - quarter));
-                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(tb), c1v = *reinterpret_cast<const f32x4_t*>(tb + 4);
-                const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(tb + quarter), s1v = *reinterpret_cast<const f32x4_t*>(tb + quarter + 4);
+                f32x4_t c0, c1v, s0, s1v;
+                if (p.tab_lds) {   // uniform: LDS copy (ds_read_b128), typed pointer so that no flat load is emitted
+                    NAF_LDS const float* tb = (NAF_LDS const float*)((t0 < quarter) ? tl + py * TS + t0 : tl + (wy + px) * TS + (t0 - quarter));
+                    c0 = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb);
+                    c1v = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + 4);
+                    s0 = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + quarter);
+                    s1v = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + quarter + 4);
+                } else {
+                    const float* tb = (t0 < quarter) ? (p.tab_y + (int64_t)y * 2 * quarter + t0) : (p.tab_x + (int64_t)x * 2 * quarter + (t0 - quarter));
+                    c0 = *reinterpret_cast<const f32x4_t*>(tb);
+                    c1v = *reinterpret_cast<const f32x4_t*>(tb + 4);
+                    s0 = *reinterpret_cast<const f32x4_t*>(tb + quarter);
+                    s1v = *reinterpret_cast<const f32x4_t*>(tb + quarter + 4);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     cs[i] = c0[i];
@@ -212,7 +237,16 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
         return NAF_ERR_UNSUPPORTED;
     }
     p.tpp = tpp;
-    const size_t lds = (size_t)(256 / tpp) * a->Cq * sizeof(float);
+    size_t lds = (size_t)(256 / tpp) * a->Cq * sizeof(float);
+    p.tab_lds = 0;
+    if (vec) {
+        const int wy_max = (a->Ho + a->h - 1) / a->h + 1, wx_max = (a->Wo + a->w - 1) / a->w + 1;
+        const size_t tl = (size_t)(wy_max + wx_max) * (2 * (p.Dh / 4) + 4) * sizeof(float);
+        if (lds + tl <= 48 * 1024) {
+            lds += tl;
+            p.tab_lds = 1;
+        }
+    }
     if (lds > 64 * 1024) {
         naf_set_error("naf_rope_pool_fwd: reduction scratch %zu B exceeds 64 KiB (Cq=%d)", lds, a->Cq);
         return NAF_ERR_UNSUPPORTED;
