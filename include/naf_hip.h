@@ -45,9 +45,12 @@ enum naf_status {
 };
 
 enum naf_xna_path {
-    NAF_XNA_AUTO = 0,    /* pick: MFMA cell kernel when eligible, else table-driven kernel */
+    NAF_XNA_AUTO = 0,    /* pick: MFMA cell kernel, else table-driven MFMA kernel, else generic kernel */
     NAF_XNA_MFMA = 1,    /* integer ratio Ho = dy*h, Wo = dx*w; one workgroup per (cell, head) */
-    NAF_XNA_GENERIC = 2  /* any sizes; needs idx_y / idx_x */
+    NAF_XNA_GENERIC = 2, /* any sizes, head dims, rectangular windows; needs idx_y / idx_x (any tables) */
+    NAF_XNA_UNION = 3    /* any ratio >= 1 on the matrix cores (Dq = 64, Dv % 16 == 0, square window <= 15); needs
+                            idx_y / idx_x and they MUST be the canonical tables of naf_axis_index_table: the library
+                            sizes its LDS windows from the same rule.  Other tables: NAF_XNA_GENERIC. */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -163,8 +166,10 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
  *   logits optional device float [B, heads, Ho, Wo, ky*kx] dense: scaled pre-softmax scores, i.e. what
  *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.  Both paths
  *          produce them (the MFMA kernel writes them from its S^T accumulators).
- *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the
- *          generic path, ignored by the MFMA path (closed form, integer ratio).
+ *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the two
+ *          table-driven paths (NAF_XNA_UNION, NAF_XNA_GENERIC), ignored by the cell kernels (closed form,
+ *          integer ratio).  AUTO may pick NAF_XNA_UNION, so callers that pass tables of their own making must
+ *          ask for NAF_XNA_GENERIC.
  *   rope_tab_y / rope_tab_x  optional device float [Ho][2][Dq/4] / [Wo][2][Dq/4] from naf_rope_tables.  When
  *          both are given, `q` holds the UN-rotated guidance and the kernel applies RoPE (rope.py:15-34,139-153,
  *          same arithmetic and bf16 rounding as naf_rope_pool_fwd) to every query as it is loaded, so the
@@ -193,9 +198,13 @@ typedef struct naf_xna_args {
     int64_t o_stride[4];
 } naf_xna_args;
 
-/* Which kernel naf_xna_fwd would run for these arguments (NAF_XNA_MFMA or NAF_XNA_GENERIC), or a
- * negative naf_status on invalid arguments.  Lets the caller skip building index tables. */
+/* Which kernel naf_xna_fwd would run for these arguments (NAF_XNA_MFMA, NAF_XNA_UNION or NAF_XNA_GENERIC), or a
+ * negative naf_status on invalid arguments.  Lets the caller skip building index tables (MFMA needs none). */
 int naf_xna_select(const naf_xna_args* a);
+/* Diagnostics: the workgroup plan of the NAF_XNA_UNION path for these arguments, out = {slots per window row
+ * (16/32), output rows per workgroup, output pixels per workgroup, staged low-res rows, staged low-res columns,
+ * value channels per pass, LDS bytes}.  Returns 1 when that path can serve the request, 0 otherwise. */
+int naf_xna_union_plan(const naf_xna_args* a, int32_t out[7]);
 /* Scratch bytes the call needs (currently always 0; kept so callers need not change later). */
 size_t naf_workspace_bytes(const naf_xna_args* a);
 int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the HIP library is dlopen'e
 LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
 NAF_BF16, NAF_F32 = 0, 1
-XNA_AUTO, XNA_MFMA, XNA_GENERIC = 0, 1, 2
+XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION = 0, 1, 2, 3
 
 I64x4 = C.c_int64 * 4
 
@@ -107,6 +107,7 @@ SIGNATURES = {
     "naf_pack_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int64), C.c_void_p]),
     "naf_xna_select": (C.c_int, [C.POINTER(XnaArgs)]),
+    "naf_xna_union_plan": (C.c_int, [C.POINTER(XnaArgs), C.POINTER(C.c_int32)]),
     "naf_workspace_bytes": (C.c_size_t, [C.POINTER(XnaArgs)]),
     "naf_xna_fwd": (C.c_int, [C.POINTER(XnaArgs), C.c_void_p]),
     "naf_xna_bwd_supported": (C.c_int, [C.POINTER(XnaBwdArgs)]),

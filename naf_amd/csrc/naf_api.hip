@@ -156,7 +156,7 @@ static int xna_validate(const naf_xna_args* a) {
     NAF_REQUIRE((int64_t)a->ky * (a->Ho / a->h) <= a->Ho && (int64_t)a->kx * (a->Wo / a->w) <= a->Wo,
                 "naf_xna_fwd: kernel_size * dilation exceeds the output extent (k=%dx%d, dilation=%dx%d, out=%dx%d)",
                 a->ky, a->kx, a->Ho / a->h, a->Wo / a->w, a->Ho, a->Wo);
-    NAF_REQUIRE(a->path == NAF_XNA_AUTO || a->path == NAF_XNA_MFMA || a->path == NAF_XNA_GENERIC, "naf_xna_fwd: path %d", a->path);
+    NAF_REQUIRE(a->path == NAF_XNA_AUTO || a->path == NAF_XNA_MFMA || a->path == NAF_XNA_GENERIC || a->path == NAF_XNA_UNION, "naf_xna_fwd: path %d", a->path);
     NAF_REQUIRE((a->rope_tab_y == nullptr) == (a->rope_tab_x == nullptr), "naf_xna_fwd: rope_tab_y and rope_tab_x must be given together");
     return NAF_OK;
 }
@@ -175,6 +175,13 @@ int naf_xna_select(const naf_xna_args* a) {
         return NAF_XNA_MFMA;
     }
     if (a->path == NAF_XNA_GENERIC) return NAF_XNA_GENERIC;
+    if (a->path == NAF_XNA_UNION) {
+        if (!naf_xna_union_eligible(a)) {
+            naf_set_error("naf_xna_select: table-driven MFMA path requested but the arguments are not eligible");
+            return -NAF_ERR_UNSUPPORTED;
+        }
+        return NAF_XNA_UNION;
+    }
     if (a->path == NAF_XNA_MFMA) {
         if (!ok) {
             naf_set_error("naf_xna_select: MFMA path requested but the arguments are not eligible");
@@ -182,8 +189,14 @@ int naf_xna_select(const naf_xna_args* a) {
         }
         return NAF_XNA_MFMA;
     }
-    // AUTO: tiny cells leave the 16-query MFMA tiles mostly empty -> table-driven kernel
-    if (ok && (int64_t)(a->Ho / a->h) * (a->Wo / a->w) >= 8) return NAF_XNA_MFMA;
+    // AUTO: the cell kernels for integer ratios whose cells hold at least four 16-query tiles; smaller cells,
+    // non-integer ratios and ratio 1 go to the table-driven MFMA kernel (one staged window per BLOCK of queries,
+    // measured faster below 8x8 cells), the rest (odd head dims, return_weights off the cell path) to the generic one
+    static const bool no_union = [] { const char* e = getenv("NAF_XNA_UNION"); return e && atoi(e) == 0; }();   // A/B knob
+    const int64_t cell_px = (int64_t)(a->Ho / a->h) * (a->Wo / a->w);
+    if (ok && (cell_px >= 64 || a->logits != nullptr || no_union) && cell_px >= 8) return NAF_XNA_MFMA;
+    if (!no_union && a->logits == nullptr && naf_xna_union_eligible(a)) return NAF_XNA_UNION;
+    if (ok && cell_px >= 8) return NAF_XNA_MFMA;
     return NAF_XNA_GENERIC;
 }
 
@@ -197,6 +210,7 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream) {
     if (sel < 0) return -sel;
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
     if (sel == NAF_XNA_MFMA) return naf_launch_xna_mfma(a, scale, static_cast<hipStream_t>(stream));
+    if (sel == NAF_XNA_UNION) return naf_launch_xna_union(a, scale, static_cast<hipStream_t>(stream));
     return naf_launch_xna_generic(a, scale, static_cast<hipStream_t>(stream));
 }
 

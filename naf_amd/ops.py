@@ -39,7 +39,8 @@ class _Timed:
         if KERNEL_TIMER is not None:
             KERNEL_TIMER.stop(self.name)
         return False
-_PATH = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "generic": _lib.XNA_GENERIC}
+_PATH = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "generic": _lib.XNA_GENERIC, "union": _lib.XNA_UNION}
+_PATH_NAME = {_lib.XNA_MFMA: "mfma", _lib.XNA_GENERIC: "generic", _lib.XNA_UNION: "union"}
 
 
 def _gpu(t: torch.Tensor, name: str) -> None:
@@ -280,11 +281,11 @@ def xna_forward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_
     sel = lib.naf_xna_select(C.byref(a))
     if sel < 0:
         _lib.check(-sel, "naf_xna_select")
-    if sel == _lib.XNA_GENERIC:
+    if sel != _lib.XNA_MFMA:   # the table-driven kernels (MFMA "union" and generic) read the canonical index tables
         iy = device_index_table(Ho, h, ky, dev)
         ix = device_index_table(Wo, w, kx, dev)
         a.idx_y, a.idx_x = iy.data_ptr(), ix.data_ptr()
-    with torch.cuda.device(dev), _Timed("xna_mfma" if sel == _lib.XNA_MFMA else "xna_generic"):
+    with torch.cuda.device(dev), _Timed("xna_" + _PATH_NAME[sel]):
         rc = lib.naf_xna_fwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_fwd")
     return (out, logits) if return_logits else out
@@ -401,7 +402,7 @@ def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logi
     sel = lib.naf_xna_select(C.byref(a))
     if sel < 0:
         _lib.check(-sel, "naf_xna_select")
-    return {1: "mfma", 2: "generic"}[sel]
+    return _PATH_NAME[sel]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -278,6 +278,56 @@ def test_xna_generic_matches_oracle(dev, case):
     assert_close(lg, ref_lg, 2e-5, 2e-5, f"generic logits {case}")
 
 
+UNION_CASES = [
+    # (B, heads, (Ho, Wo), (h, w), ksz, C): the table-driven MFMA kernel (non-integer ratios, ratio 1, small cells)
+    (1, 4, (64, 64), (28, 28), 9, 384),        # notebook case 28 -> 64 (ratio 2.29, repeated taps)
+    (1, 4, (128, 128), (28, 28), 9, 384),      # 28 -> 128 (ratio 4.57)
+    (1, 4, (100, 150), (37, 37), 9, 768),      # ratio 2.7 x 4.05, Wo not a multiple of 16
+    (2, 4, (23, 30), (5, 7), 3, 64),           # F4 sizes
+    (1, 4, (23, 30), (5, 7), 5, 64),
+    (1, 4, (40, 48), (40, 48), 7, 384),        # ratio 1: plain neighbourhood attention
+    (1, 4, (33, 47), (33, 47), 15, 64),        # ratio 1, largest window, ragged tiles
+    (1, 4, (32, 32), (16, 16), 7, 768),        # 2x2 cells
+    (1, 4, (36, 60), (12, 20), 5, 1024),       # 3x3 cells, Dv = 256
+    (1, 4, (64, 64), (16, 16), 7, 128),        # 4x4 cells
+    (1, 4, (96, 80), (12, 10), 7, 192),        # 8x8 cells
+    (1, 4, (70, 84), (5, 6), 5, 256),          # 14x14 cells (patch 14)
+    (1, 4, (300, 40), (20, 17), 11, 64),       # ratio 15 x 2.35, kernel 11
+    (1, 2, (50, 50), (21, 21), 13, 2048),      # Dv = 1024: four channel chunks
+]
+
+
+@pytest.mark.parametrize("case", UNION_CASES)
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_xna_union_matches_oracle(dev, case, out_dtype):
+    """The MFMA kernel that follows the index tables (repeated taps carry multiplicities) against the oracle's
+    dilated hi-res formulation.  Tolerance as for the cell kernel (P is rounded to bf16 before the PV product)."""
+    from naf_amd import ops
+    B, heads, (Ho, Wo), (h, w), ksz, C = case
+    seed = 7 * Ho + Wo + ksz
+    q = bf16r(O.hash_normal((B, 64 * heads, Ho, Wo), seed + 1))
+    k = bf16r(O.hash_normal((B, 64 * heads, h, w), seed + 2))
+    v = bf16r(O.hash_normal((B, C, h, w), seed + 3))
+    ref = O.xna(q, k, v, ksz, heads)
+    q5, k5 = to5(q, heads).to(dev), to5(k, heads).to(dev)
+    v5 = ops.pack_values(v.to(dev)).view(B, h, w, heads, C // heads).permute(0, 3, 1, 2, 4)
+    assert ops.xna_select(q5, k5, v5, ksz, path="union") == "union"
+    out = run_xna(dev, q, k, v, ksz, heads, out_dtype=out_dtype, path="union")
+    tol = 6e-3 if out_dtype == torch.float32 else 1.2e-2
+    assert_close(out, ref, tol, tol, f"union {case} {out_dtype}")
+
+
+def test_union_and_generic_agree_on_a_large_problem(dev):
+    """Two independent table-driven kernels, non-integer ratio, more workgroups than CUs."""
+    heads, C, ksz = 4, 384, 9
+    q = bf16r(O.hash_normal((1, 256, 200, 333), 61))
+    k = bf16r(O.hash_normal((1, 256, 37, 41), 62))
+    v = bf16r(O.hash_normal((1, C, 37, 41), 63))
+    a = run_xna(dev, q, k, v, ksz, heads, path="union")
+    b = run_xna(dev, q, k, v, ksz, heads, path="generic")
+    assert_close(a, b, 6e-3, 6e-3, "union vs generic")
+
+
 def test_generic_and_mfma_agree(dev):
     """Two independent kernels on an integer-ratio problem."""
     h, w, d, ksz, heads, C = 10, 9, 8, 7, 4, 192
