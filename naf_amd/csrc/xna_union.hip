@@ -7,6 +7,7 @@
 //     workgroup stages costs few LDS bytes per query while two workgroups still fit a CU where possible,
 //   * the exact bounds of that rectangle.
 // Plans are cached per geometry (a plan costs ~0.1 ms of host time).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <map>
@@ -63,15 +64,19 @@ UnionPlan make_plan(int Ho, int h, int Wo, int w, int k, int Dv, int64_t groups)
     double best_cost = 1e30;
     static const int rys[] = {1, 2, 4, 8, 16, 32, 64};
     static const int segs[] = {16, 32, 64, 128, 256, 512};
+    // experiments: NAF_UNION_PLAN="ry,seg,dvt" pins the plan (0 = free)
+    int pin[3] = {0, 0, 0};
+    if (const char* e = getenv("NAF_UNION_PLAN")) sscanf(e, "%d,%d,%d", &pin[0], &pin[1], &pin[2]);
     for (int dvt = 256; dvt >= 16; dvt -= 16) {
-        if (Dv % dvt) continue;
+        if (Dv % dvt || (pin[2] && dvt != pin[2])) continue;
         const int nchunk = Dv / dvt;
         if (nchunk > 1 && dvt < 64 && best.ok) break;   // many thin channel chunks: every one restages K and redoes QK
         for (int ry : rys) {
-            if (ry > Ho && ry != 1) continue;
+            if ((ry > Ho && ry != 1) || (pin[0] && ry != pin[0])) continue;
             const int hub = span_max(ty, Ho, k, ry);
             for (int sg : segs) {
                 const int seg = sg < wo16 ? sg : wo16;
+                if (pin[1] && sg != pin[1]) continue;
                 const int wub = span_max(tx, Wo, k, seg);
                 const size_t lds = xna_union_lds(k, dvt, ry, seg, hub, wub);
                 if (lds > 160 * 1024) continue;
@@ -79,12 +84,12 @@ UnionPlan make_plan(int Ho, int h, int Wo, int w, int k, int Dv, int64_t groups)
                 // cost: staged bytes per query (all channel chunks) plus the repeated QK work of extra chunks; fewer
                 // resident workgroups, idle waves and an under-filled GPU cost extra
                 const double nq = (double)(ry < Ho ? ry : Ho) * (seg < Wo ? seg : Wo);
-                double cost = (double)nchunk * (double)lds / nq + 40.0 * (nchunk - 1);
+                double cost = (double)nchunk * ((double)lds + 16384.0) / nq + 96.0 * (nchunk - 1);   // 16 KB ~ a workgroup's fixed prologue; an extra chunk re-reads Q and redoes QK
                 const int resident = (int)(160 * 1024 / lds);
                 if (resident < 2) cost *= 1.6;
                 else if (resident < 3) cost *= 1.15;
                 const double tiles = nq / 16.0;
-                if (tiles < 16.0) cost *= 1.0 + (16.0 - tiles) / 16.0;   // two tiles per wave at least
+                if (tiles < 24.0) cost *= 1.0 + (24.0 - tiles) / 24.0;   // two tiles per wave at least
                 if (nblk < 2 * (int64_t)ncu) cost *= (double)(2 * ncu) / (double)(nblk > 0 ? nblk : 1);
                 cost += 8.0;   // plan-independent per-query traffic keeps tiny differences from mattering
                 if (cost < best_cost) {
@@ -103,6 +108,7 @@ const UnionPlan& plan_for(const naf_xna_args* a) {
     static std::map<Key, UnionPlan> cache;
     const Key key(a->Ho, a->h, a->Wo, a->w, a->ky, a->Dv, (int64_t)a->B * a->heads);
     std::lock_guard<std::mutex> lock(mu);
+    if (getenv("NAF_UNION_PLAN")) cache.erase(key);   // experiments: the pinned plan may change between calls
     auto it = cache.find(key);
     if (it == cache.end()) {
         if (cache.size() > 256) cache.clear();

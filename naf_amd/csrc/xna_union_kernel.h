@@ -315,15 +315,11 @@ __global__ __launch_bounds__(NW * 64) void xna_union_kernel(const XnaUnionParams
 }
 
 // Waves per workgroup: the staged rectangle usually leaves room for one or two workgroups per CU, so the waves that
-// hide each other's latencies have to come from inside the workgroup (8 = two per SIMD; the 15x15 / 13x13 windows
-// with 32 slots per row need more than 256 registers and run 4).
+// hide each other's latencies have to come from inside the workgroup: 12 (three per SIMD, <= 170 registers) with 16
+// slots per window row, 8 with 32 slots, 4 for the 13x13 / 15x15 windows with 32 slots (> 256 registers).
 template <int KS, int WT>
 constexpr int xna_union_waves() {
-#ifdef NAF_UNION_NW   // experiments only
-    return (WT == 32 && KS >= 13) ? 4 : NAF_UNION_NW;
-#else
-    return (WT == 32 && KS >= 13) ? 4 : 8;
-#endif
+    return WT == 16 ? 12 : (KS >= 13 ? 4 : 8);
 }
 
 template <int KS, typename OutT, int WT>
