@@ -81,6 +81,59 @@ class RoPE(nn.Module):
         return self._tables
 
 
+class _GroupNormTrain(torch.autograd.Function):
+    """GroupNorm for the training stem.  ATen's ROCm forward computes the statistics with one workgroup per
+    (sample, group) -- 8 workgroups at batch 1, 2.1 ms per layer at 448^2 (profiles/r01_train_step.txt).  Here the
+    moments are a per-channel reduction over the channels-last rows ([HW, C]: C outputs, parallel over HW) folded
+    into groups on [B, C] values; the normalisation is one fused multiply-add; the backward is ATen's own
+    native_group_norm_backward (0.25 ms), fed with the saved mean / rstd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        B, C, H, W = x.shape
+        xv = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        var_c, mean_c = torch.var_mean(xv, dim=1, unbiased=False)                 # [B, C]
+        mean = mean_c.view(B, groups, -1).mean(-1)                                 # [B, G]
+        ex2 = (var_c + mean_c * mean_c).view(B, groups, -1).mean(-1)
+        rstd = torch.rsqrt((ex2 - mean * mean).clamp_min(0.0) + eps)
+        scale = (rstd.unsqueeze(-1) * weight.view(groups, -1)).reshape(B, C)
+        shift = bias.unsqueeze(0) - (mean.unsqueeze(-1) * scale.view(B, groups, -1)).reshape(B, C)
+        ctx.save_for_backward(x, mean, rstd, weight)
+        ctx.groups = groups
+        return torch.addcmul(shift.view(B, C, 1, 1), x, scale.view(B, C, 1, 1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        # ATen's kernel indexes dense NCHW memory (autograd hands it grad.contiguous() as well)
+        dx, dw, db = torch.ops.aten.native_group_norm_backward(dy.contiguous(), x.contiguous(), mean, rstd, weight, B, C, H * W,
+                                                               ctx.groups, [True, True, True])
+        return dx.contiguous(memory_format=torch.channels_last), dw, db, None, None
+
+
+class _ReflectPad(torch.autograd.Function):
+    """F.pad(mode="reflect") whose backward folds the border strips back with slice adds (ATen's
+    reflection_pad2d_backward is a scalar atomic kernel: 0.85 ms per layer at 448^2 on gfx950)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = pad
+        return F.pad(x, (pad, pad, pad, pad), mode="reflect")
+
+    @staticmethod
+    def backward(ctx, g):
+        p = ctx.pad
+        H, W = g.shape[-2] - 2 * p, g.shape[-1] - 2 * p
+        gx = g[..., :, p:p + W].clone()                                   # columns first: [.., H + 2p, W]
+        gx[..., :, 1:p + 1] += g[..., :, :p].flip(-1)                     # left strip mirrors columns 1..p
+        gx[..., :, W - 1 - p:W - 1] += g[..., :, p + W:].flip(-1)         # right strip mirrors columns W-1-p..W-2
+        out = gx[..., p:p + H, :].clone()
+        out[..., 1:p + 1, :] += gx[..., :p, :].flip(-2)
+        out[..., H - 1 - p:H - 1, :] += gx[..., p + H:, :].flip(-2)
+        return out, None
+
+
 class ImageEncoder(nn.Module):
     """Guidance encoder (naf.py:11-52).  At the default width (dim 256 -> 128 hidden channels) both
     conv branches run through the library's fused HIP stem (naf_stem_conv0_fwd / naf_stem_conv_fwd:
@@ -113,6 +166,28 @@ class ImageEncoder(nn.Module):
             x = self._conv(x, blk.conv1, dt)
             x = F.silu(F.group_norm(x, blk.norm2.num_groups, blk.norm2.weight.to(dt), blk.norm2.bias.to(dt), blk.norm2.eps))
             x = self._conv(x, blk.conv2, dt)
+        return x
+
+    # ---- differentiable torch stem of forward_train ---------------------------------------------------
+    # Same math as _branch (convolutions.py:52-92) with the three ops whose ATen ROCm kernels dominate a training
+    # step at batch 1 replaced by equivalent compositions (profiles/r01_train_step.txt): GroupNorm statistics
+    # (ATen launches one workgroup per (sample, group) = 8 workgroups: 2.1 ms per layer at 448^2), the reflect-pad
+    # backward (0.85 ms per layer) and -- in forward_train -- the adaptive-average-pool backward (atomics, 2.6 ms).
+    @staticmethod
+    def _group_norm_train(x, norm: nn.GroupNorm):
+        return _GroupNormTrain.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+
+    def _conv_train(self, x, conv: nn.Conv2d):
+        pad = conv.kernel_size[0] // 2
+        if pad:
+            x = _ReflectPad.apply(x, pad)
+        return F.conv2d(x, conv.weight, conv.bias)
+
+    def _branch_train(self, x, seq: nn.Sequential):
+        x = self._conv_train(x, seq[0])
+        for blk in list(seq)[1:]:
+            x = self._conv_train(F.silu(self._group_norm_train(x, blk.norm1)), blk.conv1)
+            x = self._conv_train(F.silu(self._group_norm_train(x, blk.norm2)), blk.conv2)
         return x
 
     # ---- fused HIP stem (default width: 128 hidden channels, GroupNorm(8)) -------------------------
@@ -373,7 +448,7 @@ class NAF(nn.Module):
                               mode="bilinear", align_corners=False)
         if enc.use_encoder:
             x = x.float().contiguous(memory_format=torch.channels_last)
-            x = torch.cat([enc._branch(x, enc.encoder, torch.float32), enc._branch(x, enc.sem_encoder, torch.float32)], dim=1)
+            x = torch.cat([enc._branch_train(x, enc.encoder), enc._branch_train(x, enc.sem_encoder)], dim=1)
         if x.shape[-2:] != (ho, wo):
             x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
@@ -386,7 +461,10 @@ class NAF(nn.Module):
         x1, x2 = xh[..., : D // 2], xh[..., D // 2:]
         xr = torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
         xr = xr.permute(0, 1, 4, 2, 3).reshape(B, Cq, ho, wo)
-        k = F.adaptive_avg_pool2d(xr, output_size=(h, w))                      # naf.py:63-69 (pooled AFTER RoPE)
+        if ho % h == 0 and wo % w == 0:                                        # naf.py:63-69 (pooled AFTER RoPE); box mean as a
+            k = xr.reshape(B, Cq, h, ho // h, w, wo // w).mean(dim=(3, 5))    # reshape: its backward is a broadcast, not atomics
+        else:
+            k = F.adaptive_avg_pool2d(xr, output_size=(h, w))
         Dq, C = Cq // heads, features.shape[1]
         to5 = lambda t, d: t.reshape(B, heads, d, *t.shape[-2:]).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
         q5, k5, v5 = to5(xr, Dq), to5(k, Dq), to5(features, C // heads)
