@@ -62,6 +62,9 @@ const char* naf_last_error(void);
  * upsampling of K/V (attentions.py:48-61 + NATTEN get_window_start, dilation = L_out / L_in).
  * out_host[L_out * k] (HOST memory).  Errors like NATTEN: k even, k*dilation > L_out, L_out < L_in. */
 int naf_axis_index_table(int32_t* out_host, int32_t L_out, int32_t L_in, int32_t k);
+/* The same table computed on the device (out_dev: device int32 [L_out * k]), bit-identical to the host one:
+ * for hosts that stay off the CPU path (naf_forward builds its tables this way; capturable in a hipGraph). */
+int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, int32_t k, naf_stream_t stream);
 
 /* ---- guidance conv stem ----------------------------------------------------------------------------
  * Replaces the reference's encoder() branches (convolutions.py:6-92, built at naf.py:26-27 with
@@ -248,10 +251,13 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------
  * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
- * encoder branches with img_layers blocks, 4 RoPE heads = 4 attention heads, image size == output size, integer
- * ratio with Wo/w a multiple of 16): every launch of the path above -- conv stem, key pooling, value packing,
- * attention with rotate-on-load -- is issued from one host call on the caller's stream, so a C/C++ host needs
- * nothing else and a Python host pays one foreign call per forward instead of fourteen.
+ * encoder branches with img_layers blocks, RoPE heads = attention heads, image size == output size): every launch
+ * of the path above -- conv stem, key pooling, value packing, attention -- is issued from one host call on the
+ * caller's stream, so a C/C++ host needs nothing else and a Python host pays one foreign call per forward instead
+ * of fourteen.  Any geometry naf_xna_fwd accepts is served: with an integer ratio and Wo/w a multiple of 16 the
+ * queries are rotated on load (no query buffer); otherwise they are materialised in the workspace, and when the
+ * attention runs on a table-driven kernel the index tables are built in the workspace by
+ * naf_axis_index_table_device.  The call is capturable in a hipGraph (no host-side copies, no allocation).
  *   image     device [B, 3, H, W] f32/bf16, strides {b, c, y, x}
  *   features  device [B, C, h, w] f32/bf16, strides {b, c, y, x}
  *   out       device out_dtype, dense channels-last [B, H, W, C] (logical [B, C, H, W] view for the caller)
@@ -260,10 +266,11 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  *             [k*k][128][128] (= weight.permute(2,3,0,1)) and bias f32 [128]
  *   tab_y / tab_x  RoPE tables from naf_rope_tables for (H, W)
  *   workspace device scratch of naf_forward_workspace_bytes() bytes (activations, GroupNorm sums, keys, packed
- *             values); the library still owns no memory
+ *             values, queries / index tables where needed); the library still owns no memory
  *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
- * Shapes outside the list above return NAF_ERR_UNSUPPORTED (compose the individual entry points instead). */
+ * Configurations outside the list (other widths, return_weights, image size != output size) return
+ * NAF_ERR_UNSUPPORTED: compose the individual entry points instead. */
 #define NAF_MAX_STEM_LAYERS 8
 typedef struct naf_stem_branch {
     const float* conv0_weight;

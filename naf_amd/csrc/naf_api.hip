@@ -42,42 +42,31 @@ extern "C" {
 int naf_version(void) { return NAF_HIP_VERSION; }
 const char* naf_last_error(void) { return g_err; }
 
-// NATTEN <= 0.17 get_window_start (published algorithm; NATTEN is not vendored by the reference).
-static int window_start(int i, int L, int k, int dil) {
-    const int r = k / 2;
-    if (dil <= 1) return (i - r > 0 ? i - r : 0) + (i + r >= L ? (L - i - r - 1) : 0);
-    const int ni = i - r * dil;
-    if (ni < 0) return i % dil;
-    if (i + r * dil >= L) {
-        const int m = i % dil, a = (L / dil) * dil, b = L - a;
-        return (m < b) ? (L - b + m - 2 * r * dil) : (a + m - k * dil);
-    }
-    return ni;
-}
-
-int naf_axis_index_table(int32_t* out, int32_t L_out, int32_t L_in, int32_t k) {
+static int axis_table_validate(const void* out, int32_t L_out, int32_t L_in, int32_t k) {
     NAF_REQUIRE(out != nullptr, "naf_axis_index_table: out is NULL");
     NAF_REQUIRE(L_out > 0 && L_in > 0 && k > 0, "naf_axis_index_table: sizes must be positive (L_out=%d L_in=%d k=%d)", L_out, L_in, k);
     NAF_REQUIRE((k & 1) == 1, "naf_axis_index_table: kernel size must be odd, got %d", k);
     NAF_REQUIRE(L_out >= L_in, "naf_axis_index_table: output extent %d smaller than feature extent %d (dilation 0)", L_out, L_in);
     const int dil = L_out / L_in;
     NAF_REQUIRE((int64_t)k * dil <= L_out, "naf_axis_index_table: kernel_size * dilation = %d * %d exceeds extent %d", k, dil, L_out);
+    return NAF_OK;
+}
+
+int naf_axis_index_table(int32_t* out, int32_t L_out, int32_t L_in, int32_t k) {
+    const int rc = axis_table_validate(out, L_out, L_in, k);
+    if (rc != NAF_OK) return rc;
+    const int dil = L_out / L_in;
     for (int i = 0; i < L_out; ++i) {
-        const int s = window_start(i, L_out, k, dil);
-        for (int t = 0; t < k; ++t) {
-            const int pos = s + t * dil;  // position on the (virtual) nearest-exact upsampled grid
-            // F.interpolate(mode="nearest-exact") source index in ATen's device arithmetic
-            // (UpSample.cuh nearest_neighbor_exact_compute_source_index): all-fp32
-            // floorf((pos + 0.5f) * (float(in) / float(out))), clamped to in-1.  At exact ties ATen's
-            // CPU build may differ by one (FMA contraction); see DESIGN.md.
-            const float scale = (float)L_in / (float)L_out;
-            volatile float prod = ((float)pos + 0.5f) * scale;  // volatile: no FMA/extended precision
-            int src = (int)floorf(prod);
-            if (src > L_in - 1) src = L_in - 1;
-            out[(int64_t)i * k + t] = src;
-        }
+        const int s = naf_window_start(i, L_out, k, dil);
+        for (int t = 0; t < k; ++t) out[(int64_t)i * k + t] = naf_nearest_exact_src(s + t * dil, L_in, L_out);
     }
     return NAF_OK;
+}
+
+int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, int32_t k, naf_stream_t stream) {
+    const int rc = axis_table_validate(out_dev, L_out, L_in, k);
+    if (rc != NAF_OK) return rc;
+    return naf_launch_axis_table(out_dev, L_out, L_in, k, static_cast<hipStream_t>(stream));
 }
 
 int naf_rope_tables(float* tab_y, float* tab_x, const float* periods, int32_t n_periods, int32_t Ho, int32_t Wo,
@@ -244,8 +233,10 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
 // ---- whole forward in one call ---------------------------------------------------------------------------
 namespace {
 struct FwdLayout {
-    size_t stats, buf0, buf1, cat, keys, vp, total;
+    size_t stats, buf0, buf1, cat, keys, vp, q, idx_y, idx_x, total;
+    bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
 };
+bool fwd_rope_fusable(const naf_forward_args* a);
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 FwdLayout fwd_layout(const naf_forward_args* a) {
     FwdLayout L;
@@ -257,6 +248,10 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.cat = off;   off = align256(off + px * 256 * 2);
     L.keys = off;  off = align256(off + (size_t)a->B * a->h * a->w * 256 * 2);
     L.vp = off;    off = align256(off + (size_t)a->B * a->h * a->w * a->C * 2);
+    L.fused = fwd_rope_fusable(a);
+    L.q = off;     off = align256(off + (L.fused ? 0 : px * 256 * 2));
+    L.idx_y = off; off = align256(off + (size_t)a->H * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
+    L.idx_x = off; off = align256(off + (size_t)a->W * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
     L.total = off;
     return L;
 }
@@ -275,25 +270,45 @@ int fwd_validate(const naf_forward_args* a) {
     }
     return NAF_OK;
 }
-// the arguments of the attention call this forward would make (for eligibility and for the launch)
-void fwd_xna_args(const naf_forward_args* a, const FwdLayout& L, naf_xna_args* x) {
+// the arguments of the attention call this forward would make (for eligibility and for the launch): fused =
+// rotate-on-load on the MFMA cell kernels, otherwise materialised queries and whatever kernel AUTO selects
+void fwd_xna_args(const naf_forward_args* a, const FwdLayout* L, bool fused, naf_xna_args* x) {
     char* ws = static_cast<char*>(a->workspace);
+    const bool real = ws != nullptr && L != nullptr;
+    const void* fake = reinterpret_cast<const void*>(0x100);
     const int Dv = a->C / a->heads;
     *x = naf_xna_args{};
-    x->q = ws ? ws + L.cat : reinterpret_cast<const void*>(0x100);
-    x->k_lr = ws ? ws + L.keys : reinterpret_cast<const void*>(0x100);
-    x->v_lr = ws ? ws + L.vp : reinterpret_cast<const void*>(0x100);
+    x->q = real ? ws + (fused ? L->cat : L->q) : fake;
+    x->k_lr = real ? ws + L->keys : fake;
+    x->v_lr = real ? ws + L->vp : fake;
     x->out = a->out;
-    x->rope_tab_y = a->tab_y; x->rope_tab_x = a->tab_x;
+    if (fused) {
+        x->rope_tab_y = a->tab_y; x->rope_tab_x = a->tab_x;
+        x->path = NAF_XNA_MFMA;
+    } else {
+        x->path = NAF_XNA_AUTO;
+        x->idx_y = real ? reinterpret_cast<const int32_t*>(ws + L->idx_y) : static_cast<const int32_t*>(fake);
+        x->idx_x = real ? reinterpret_cast<const int32_t*>(ws + L->idx_x) : static_cast<const int32_t*>(fake);
+    }
     x->B = a->B; x->heads = a->heads; x->Ho = a->H; x->Wo = a->W; x->h = a->h; x->w = a->w;
     x->Dq = 256 / a->heads; x->Dv = Dv; x->ky = a->ksize; x->kx = a->ksize;
-    x->out_dtype = a->out_dtype; x->path = NAF_XNA_MFMA; x->scale = a->scale;
+    x->out_dtype = a->out_dtype; x->scale = a->scale;
     const int64_t Dq = x->Dq;
     const int64_t qs[4] = {(int64_t)a->H * a->W * 256, Dq, (int64_t)a->W * 256, 256};
     const int64_t ks[4] = {(int64_t)a->h * a->w * 256, Dq, (int64_t)a->w * 256, 256};
     const int64_t vs[4] = {(int64_t)a->h * a->w * a->C, Dv, (int64_t)a->w * a->C, a->C};
     const int64_t os[4] = {(int64_t)a->H * a->W * a->C, Dv, (int64_t)a->W * a->C, a->C};
     for (int i = 0; i < 4; ++i) { x->q_stride[i] = qs[i]; x->k_stride[i] = ks[i]; x->v_stride[i] = vs[i]; x->o_stride[i] = os[i]; }
+}
+bool fwd_rope_fusable(const naf_forward_args* a) {
+    if (a->heads <= 0 || a->C <= 0 || a->C % a->heads || 256 % a->heads) return false;
+    naf_forward_args g = *a;   // geometry only: eligibility must not depend on whether a workspace was passed yet
+    g.workspace = nullptr;
+    g.out = reinterpret_cast<void*>(0x100);
+    g.tab_y = g.tab_x = reinterpret_cast<const float*>(0x100);
+    naf_xna_args x;
+    fwd_xna_args(&g, nullptr, true, &x);
+    return xna_validate(&x) == NAF_OK && naf_xna_mfma_eligible(&x, nullptr, nullptr) && naf_xna_mfma_rope_ok(&x);
 }
 }  // namespace
 
@@ -305,21 +320,23 @@ size_t naf_forward_workspace_bytes(const naf_forward_args* a) {
 int naf_forward_supported(const naf_forward_args* a) {
     const int rc = fwd_validate(a);
     if (rc != NAF_OK) return -rc;
-    if (a->heads != 4 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
-    if (a->H < 2 || a->W < 2) return 0;
-    naf_xna_args x;
-    fwd_xna_args(a, fwd_layout(a), &x);
+    if (256 % (4 * a->heads) != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
+    if (a->H < 2 || a->W < 2 || a->H < a->h || a->W < a->w) return 0;
     if (reinterpret_cast<uintptr_t>(a->out) % 16) return 0;
-    if (xna_validate(&x) != NAF_OK) return 0;
-    return (naf_xna_mfma_eligible(&x, nullptr, nullptr) && naf_xna_mfma_rope_ok(&x)) ? 1 : 0;
+    if (fwd_rope_fusable(a)) return 1;
+    naf_forward_args g = *a;
+    g.workspace = nullptr;
+    naf_xna_args x;
+    fwd_xna_args(&g, nullptr, false, &x);
+    return naf_xna_select(&x) > 0 ? 1 : 0;   // any geometry NATTEN accepts: cell, table-driven MFMA or generic kernel
 }
 
 int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     const int sup = naf_forward_supported(a);
     if (sup < 0) return -sup;
     if (sup == 0) {
-        naf_set_error("naf_forward: unsupported configuration (needs 4 heads, integer ratio with Wo/w %% 16 == 0, window <= 15 "
-                      "fitting the grid, Dv %% 16 == 0); compose the individual entry points instead");
+        naf_set_error("naf_forward: unsupported configuration (needs a head count dividing 64, output >= feature grid, kernel_size * "
+                      "floor(ratio) <= output extent, 16-byte aligned output); compose the individual entry points instead");
         return NAF_ERR_UNSUPPORTED;
     }
     const FwdLayout L = fwd_layout(a);
@@ -368,19 +385,26 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
             cur = c.y;
         }
     }
-    // keys: pooled RoPE'd guidance (queries are rotated on load by the attention kernel)
+    // keys: pooled RoPE'd guidance; queries: rotated on load by the attention kernel where the geometry allows it
+    // (row tiles), otherwise written here
     naf_rope_pool_args rp{};
-    rp.x = cat; rp.q = nullptr; rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
+    rp.x = cat; rp.q = L.fused ? nullptr : static_cast<void*>(ws + L.q); rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
     rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = a->heads; rp.Ho = a->H; rp.Wo = a->W; rp.h = a->h; rp.w = a->w;
     const int64_t xs[4] = {(int64_t)a->H * a->W * 256, 1, (int64_t)a->W * 256, 256};
     const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / a->heads, (int64_t)a->w * 256, 256};
-    for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = 0; rp.k_stride[i] = kst[i]; }
+    const int64_t qst[4] = {(int64_t)a->H * a->W * 256, 256 / a->heads, (int64_t)a->W * 256, 256};
+    for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = L.fused ? 0 : qst[i]; rp.k_stride[i] = kst[i]; }
     int rc = naf_rope_pool_fwd(&rp, stream);
     if (rc != NAF_OK) return rc;
     rc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, stream);
     if (rc != NAF_OK) return rc;
     naf_xna_args x;
-    fwd_xna_args(a, L, &x);
+    fwd_xna_args(a, &L, L.fused, &x);
+    if (!L.fused && naf_xna_select(&x) != NAF_XNA_MFMA) {   // table-driven kernels: the index tables, built on the device
+        rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_y), a->H, a->h, a->ksize, stream);
+        if (rc == NAF_OK) rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_x), a->W, a->w, a->ksize, stream);
+        if (rc != NAF_OK) return rc;
+    }
     if (a->events[0] && hipEventRecord(static_cast<hipEvent_t>(a->events[0]), s) != hipSuccess) {
         naf_set_error("naf_forward: hipEventRecord failed");
         return NAF_ERR_LAUNCH;

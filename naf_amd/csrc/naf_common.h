@@ -48,6 +48,37 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);         
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s);              // stem_conv.hip
 int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s);           // stem_conv1x1.hip
 
+int naf_launch_axis_table(int32_t* out_dev, int L_out, int L_in, int k, hipStream_t s);  // axis_table.hip
+
+// ---- the per-axis neighbourhood rule, one definition for the host table and the device table ----
+// NATTEN <= 0.17 get_window_start (published algorithm; NATTEN is not vendored by the reference).
+__host__ __device__ inline int naf_window_start(int i, int L, int k, int dil) {
+    const int r = k / 2;
+    if (dil <= 1) return (i - r > 0 ? i - r : 0) + (i + r >= L ? (L - i - r - 1) : 0);
+    const int ni = i - r * dil;
+    if (ni < 0) return i % dil;
+    if (i + r * dil >= L) {
+        const int m = i % dil, a = (L / dil) * dil, b = L - a;
+        return (m < b) ? (L - b + m - 2 * r * dil) : (a + m - k * dil);
+    }
+    return ni;
+}
+// F.interpolate(mode="nearest-exact") source index of position `pos` on the (virtual) upsampled grid, in ATen's
+// device arithmetic (UpSample.cuh nearest_neighbor_exact_compute_source_index): all-fp32
+// floorf((pos + 0.5f) * (float(in) / float(out))), clamped to in-1, every operation rounded on its own (no FMA
+// contraction, correctly rounded division) so that host and device agree bit for bit.  At exact ties ATen's CPU
+// build may differ by one; see DESIGN.md.
+__host__ __device__ inline int naf_nearest_exact_src(int pos, int L_in, int L_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float prod = __fmul_rn((float)pos + 0.5f, __fdiv_rn((float)L_in, (float)L_out));
+#else
+    const float scale = (float)L_in / (float)L_out;
+    volatile float prod = ((float)pos + 0.5f) * scale;
+#endif
+    int src = (int)floorf(prod);
+    return src > L_in - 1 ? L_in - 1 : src;
+}
+
 // ---- device helpers ----
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 

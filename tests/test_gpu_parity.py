@@ -793,3 +793,58 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
     # shapes it does not serve fall back to the composed path transparently
     assert m._forward_plan(img, ft, (48, 64)) is None
+
+
+@pytest.mark.parametrize("hw,lr,C,ksz,path", [
+    ((70, 84), (5, 6), 128, 5, "mfma"),        # 14x14 cells: cell kernel, queries materialised (tiles straddle rows)
+    ((64, 64), (28, 28), 128, 9, "union"),     # non-integer ratio: index tables built on the device
+    ((40, 48), (20, 24), 256, 7, "union"),     # 2x2 cells
+    ((45, 45), (45, 45), 64, 3, "union"),      # ratio 1
+    ((23, 30), (5, 7), 24, 3, "generic"),      # Dv = 6: generic kernel
+])
+def test_single_call_forward_other_geometries(dev, hw, lr, C, ksz, path):
+    """naf_forward beyond the rotate-on-load shapes: same kernels, same bits as the composed path; the index tables it
+    builds on the device are those of the host function."""
+    from naf_amd import ops
+    p = O.make_params(seed=43)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *hw), 971).to(dev)
+    ft = O.hash_normal((1, C, *lr), 972).to(dev)
+    assert m._forward_plan(img, ft, hw) is not None
+    a = m(img, ft, hw)
+    class Names:                       # ops.KERNEL_TIMER protocol: which launches the composed path makes
+        enabled = False
+
+        def __init__(self):
+            self.seen = set()
+
+        def start(self, name):
+            self.seen.add(name)
+
+        def stop(self, name):
+            pass
+
+    m.single_call = False
+    ops.KERNEL_TIMER = rec = Names()
+    try:
+        b = m(img, ft, hw)
+    finally:
+        ops.KERNEL_TIMER = None
+    m.single_call = True
+    assert ("xna_" + path) in rec.seen, sorted(rec.seen)
+    assert torch.equal(a, b)
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), hw, kernel_size=ksz)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"single-call forward vs oracle {hw} {lr}")
+
+
+@pytest.mark.parametrize("L_out,L_in,k", [(64, 28, 9), (512, 37, 9), (518, 37, 15), (23, 5, 3), (30, 7, 5), (256, 256, 15),
+                                          (1024, 64, 7), (333, 41, 7), (100, 99, 11)])
+def test_device_index_table_equals_host_table(dev, L_out, L_in, k):
+    import ctypes as C
+    from naf_amd import ops, _lib
+    host = ops.axis_index_table(L_out, L_in, k)
+    d = torch.empty((L_out, k), dtype=torch.int32, device=dev)
+    rc = _lib.load().naf_axis_index_table_device(C.cast(d.data_ptr(), C.POINTER(C.c_int32)), L_out, L_in, k,
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert torch.equal(d.cpu(), host)
