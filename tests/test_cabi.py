@@ -77,6 +77,63 @@ def test_axis_index_table_errors_mirror_natten(built_lib):
         ops.axis_index_table(4, 8, 3)
 
 
+def _xna_args(h, w, Ho, Wo, Cc, k, heads=4, B=1, Dq=64, path=0, logits=False):
+    from naf_amd._lib import XnaArgs, I64x4
+    a = XnaArgs()
+    Dv = Cc // heads
+    a.q = a.k_lr = a.v_lr = a.out = 0x1000           # host logic only: never dereferenced
+    a.logits = 0x1000 if logits else None
+    a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, Dv, k, k
+    a.out_dtype, a.path, a.scale = 0, path, 0.0
+    a.q_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
+    a.k_stride = I64x4(h * w * heads * Dq, Dq, w * heads * Dq, heads * Dq)
+    a.v_stride = I64x4(h * w * heads * Dv, Dv, w * heads * Dv, heads * Dv)
+    a.o_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    return a
+
+
+@pytest.mark.parametrize("geom", [(28, 28, 64, 64, 384, 9), (37, 37, 512, 512, 768, 9), (5, 7, 23, 30, 64, 3),
+                                  (64, 64, 256, 256, 768, 7), (128, 128, 256, 256, 768, 7), (48, 40, 48, 40, 384, 7),
+                                  (33, 47, 33, 47, 64, 15), (21, 21, 50, 50, 2048, 13), (20, 17, 300, 40, 64, 11)])
+def test_union_planner_covers_every_window(built_lib, geom):
+    """Host logic of the table-driven MFMA path: the planned LDS rectangle must contain the taps of every query of
+    every workgroup, a tile's taps must fit its slots, and the plan must fit the 160 KB LDS."""
+    from naf_amd import _lib, ops
+    h, w, Ho, Wo, Cc, k = geom
+    lib = _lib.load()
+    a = _xna_args(*geom, path=_lib.XNA_UNION)
+    out = (C.c_int32 * 7)()
+    assert lib.naf_xna_union_plan(C.byref(a), out) == 1
+    wt, ry, seg, hub, wub, dvt, lds = list(out)
+    assert wt in (16, 32) and seg % 16 == 0 and ry >= 1 and (Cc // 4) % dvt == 0 and dvt % 16 == 0 and lds <= 160 * 1024
+    ty, tx = ops.axis_index_table(Ho, h, k).numpy(), ops.axis_index_table(Wo, w, k).numpy()
+
+    def span(t, blk):
+        return max(int(t[i:i + blk, -1].max() - t[i:i + blk, 0].min() + 1) for i in range(0, t.shape[0], blk))
+
+    assert span(tx, 16) <= wt
+    assert span(ty, ry) == hub and span(tx, seg) == wub
+    assert lds >= (hub * wub + 32) * (72 + dvt + 16) * 2
+    assert lib.naf_xna_select(C.byref(a)) == _lib.XNA_UNION
+
+
+def test_xna_auto_policy(built_lib):
+    """AUTO: cell kernels for integer ratios with 10x10+ cells, the table-driven MFMA kernel for smaller cells,
+    non-integer ratios and ratio 1, the generic kernel for other head dims / channel counts / return_weights."""
+    from naf_amd import _lib
+    lib = _lib.load()
+    sel = lambda *g, **kw: lib.naf_xna_select(C.byref(_xna_args(*g, **kw)))
+    assert sel(64, 64, 1024, 1024, 768, 7) == _lib.XNA_MFMA
+    assert sel(37, 37, 518, 518, 768, 9) == _lib.XNA_MFMA            # 14x14 cells
+    assert sel(64, 64, 512, 512, 768, 7) == _lib.XNA_UNION           # 8x8 cells
+    assert sel(28, 28, 64, 64, 384, 9) == _lib.XNA_UNION             # ratio 2.29
+    assert sel(40, 40, 40, 40, 384, 7) == _lib.XNA_UNION             # ratio 1
+    assert sel(28, 28, 64, 64, 384, 9, logits=True) == _lib.XNA_GENERIC
+    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=96) == _lib.XNA_GENERIC     # denoising-like
+    assert sel(8, 8, 32, 32, 128, 7, logits=True) == _lib.XNA_MFMA   # return_weights stays on the cell kernel
+    assert sel(28, 28, 64, 64, 384, 9, path=_lib.XNA_MFMA) == -2     # NAF_ERR_UNSUPPORTED
+
+
 def test_module_mirrors_reference_interface():
     from naf_amd import NAF
     m = NAF()
