@@ -332,7 +332,11 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = mt * 16 + grp * 4 + r;
+#ifdef NAF_BWD_NO_ATOMICS   // experiments only: how much of the kernel is the atomic traffic
+            if (key < NSLOT && p.scale > 1e30f) {
+#else
             if (key < NSLOT) {
+#endif
                 const int ry = key / KS, rx = key - ry * KS;
                 const int64_t cell = (int64_t)(y0 + ry) * p.w + (x0 + rx);
                 atomicAdd(dkb + cell * p.heads * 64 + wave * 16 + col, accK[mt][r]);
