@@ -59,7 +59,7 @@ struct StemGeom {
 
 // ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue
 // (bias, sums, LDS tile), 4 no LDS B-fragment reads (MFMA on stale registers), 8 no row stores, 16 no global loads,
-// 32 no per-step barrier, 64 no per-slot scheduling pins
+// 32 no per-step barrier, 64 no per-slot scheduling pins, 128 cycle counters per step, 256 phase timestamps
 template <int KS, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams p) {
     static_assert(KS == 3, "the 1x1 layers have their own kernel (stem_conv1x1.hip)");
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n32 = lane & 31, half = lane >> 5;
 
+    long long ph[6] = {0, 0, 0, 0, 0, 0};   // probe only (ABL & 256): 100 MHz timestamps of the kernel's phases
+    if constexpr ((ABL & 256) != 0) ph[0] = (long long)__builtin_amdgcn_s_memrealtime();
     int bid = blockIdx.x;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
         for (int n = 0; n < NLD; ++n) commit_one(k, n);
     }
     __syncthreads();
+    if constexpr ((ABL & 256) != 0) ph[1] = (long long)__builtin_amdgcn_s_memrealtime();
     // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
     // (after the prologue: loaded earlier, the compiler spilled ~70 of these registers around the prologue's
     //  GroupNorm/SiLU code and reloaded them -- 38 MB of scratch traffic per launch)
@@ -200,6 +203,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
                 wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((ABL & 256) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ph[2] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 #pragma unroll
     for (int n = 0; n < NLD; ++n) issue_one(PRE, n);
 
@@ -322,6 +329,13 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
         for (int n = 0; n < NST; ++n) store_one(nstep - 1, n, T{});
     }
 
+    if constexpr ((ABL & 256) != 0) {
+        ph[3] = (long long)__builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ph[4] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (tid == 0)
+            for (int i = 0; i < 5; ++i) p.stats_out[1024 + blockIdx.x * 8 + i] = (double)ph[i];
+    }
     if constexpr ((ABL & 128) != 0) {
         if (lane == 0 && blockIdx.x < 8) {
             for (int i = 0; i < 3; ++i) p.stats_out[16 + (blockIdx.x * 4 + wave) * 4 + i] = (double)tmacc[i];

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     uint32_t st = 777u;
     for (auto& v : hx) { st = st * 1664525u + 1013904223u; union { float f; uint32_t u; } c; c.f = ((st >> 8) & 0xffff) / 32768.0f - 1.f; v = (uint16_t)(c.u >> 16); }
     bf16_t *x, *y, *w; float *vec; double* stats;
-    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4)); CK(hipMalloc(&stats, 4096 * 8)); CK(hipMemset(stats, 0, 4096 * 8));
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4)); CK(hipMalloc(&stats, 8192 * 8)); CK(hipMemset(stats, 0, 8192 * 8));
     CK(hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w, hx.data(), 9 * 128 * 128 * 2, hipMemcpyHostToDevice));
     std::vector<float> hv(3 * 128, 0.5f);
@@ -74,6 +74,22 @@ int main(int argc, char** argv) {
             for (int w = 0; w < 8; ++w)
                 printf("   wg %d wave %d: per step  mfma-block %.0f  epilogue(g1) %.0f  barrier %.0f cycles (%d steps, counter ticks)\n", w / 4, w % 4,
                        t[w * 4] / t[w * 4 + 3] / 3, t[w * 4 + 1] / t[w * 4 + 3] / 3, t[w * 4 + 2] / t[w * 4 + 3] / 3, (int)t[w * 4 + 3]);
+        }
+        {
+            run<3, 256>(p, nb, 1, "full + phase timestamps", px * 2 * 1152 * 128, by);
+            std::vector<double> t(nb * 8);
+            CK(hipMemcpy(t.data(), stats + 16 + 1024, (size_t)nb * 8 * 8, hipMemcpyDeviceToHost));
+            double t0 = 1e300, tend = 0, sum[5] = {0, 0, 0, 0, 0}, last_start = 0;
+            for (int g = 0; g < nb; ++g) { t0 = t[g * 8] < t0 ? t[g * 8] : t0; tend = t[g * 8 + 4] > tend ? t[g * 8 + 4] : tend; last_start = t[g * 8] > last_start ? t[g * 8] : last_start; }
+            for (int g = 0; g < nb; ++g) {
+                sum[0] += t[g * 8] - t0;
+                for (int i = 1; i < 5; ++i) sum[i] += t[g * 8 + i] - t[g * 8 + i - 1];
+            }
+            printf("   phases (100 MHz ticks -> us, mean over %d workgroups): start skew %.2f (last start %.2f)  stats+prologue %.2f  weights %.2f  steps %.2f  drain %.2f | first start -> last end %.2f us\n",
+                   nb, sum[0] / nb / 100, (last_start - t0) / 100, sum[1] / nb / 100, sum[2] / nb / 100, sum[3] / nb / 100, sum[4] / nb / 100, (tend - t0) / 100);
+            double emin = 1e300;
+            for (int g = 0; g < nb; ++g) emin = t[g * 8 + 4] < emin ? t[g * 8 + 4] : emin;
+            printf("   first workgroup ends %.2f us after the first start, last %.2f us\n", (emin - t0) / 100, (tend - t0) / 100);
         }
         run<3, 59 + 64>(p, nb, reps, "LDS reads + MFMA, no slot pins", px * 2 * 1152 * 128, by);
         run<3, 64>(p, nb, reps, "full, no slot pins", px * 2 * 1152 * 128, by);
