@@ -136,7 +136,12 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
 
     const T* xb = reinterpret_cast<const T*>(p.x) + b * p.xs[0];
     if (active) {
-#pragma unroll 4
+        // NOT unrolled: 75 VGPRs = 6 waves per SIMD; unrolled by 4 the loop needs 132 (3 waves) and the keys-only pass
+        // of G1 takes 0.145 instead of 0.110 ms -- resident waves hide the HBM latency better than loads in flight per wave
+#ifndef NAF_ROPE_UNROLL
+#define NAF_ROPE_UNROLL 1
+#endif
+#pragma unroll NAF_ROPE_UNROLL
         for (int pi = plane; pi < npix; pi += nplanes) {
             const int py = pi / wx, px = pi - py * wx;
             const int y = ys + py, x = xs + px;
