@@ -95,54 +95,37 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
     float sv[KSTEP], nx[KSTEP];
     int g = blockIdx.x * 4 + wave;
     load_taps(g, sv);
-    // The first segment's taps land BEFORE the loop: otherwise the loop header inherits "loads in flight, nothing
-    // younger" from this path and every iteration's wait for its taps also waits for the previous segment's stores.
-    // (KS = 1 only: with the 14 tap registers of the 3x3 kernel the pinned order costs more in register pressure than
-    //  the exact waits win -- 0.138 vs 0.130 ms; the 1x1 kernel gains 0.062 -> 0.060 ms)
     if constexpr (KS == 1) {
+        // The first segment's taps land BEFORE the loop: otherwise the loop header inherits "loads in flight, nothing
+        // younger" from this path and every iteration's wait for its taps also waits for the previous segment's stores.
         float t0 = sv[0], t1 = sv[KSTEP - 1];
         asm volatile("; conv0 first taps landed" : "+v"(t0), "+v"(t1));
         sv[0] = t0;
         sv[KSTEP - 1] = t1;
     }
-    for (; g < p.ngroups; g += gstride) {
-        load_taps(g + gstride, nx);   // next segment's taps load while this one's MFMAs run
-        if constexpr (KS == 1) __builtin_amdgcn_sched_barrier(0);
-        const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
 
-        // two oc-tiles at a time (two interleaved accumulator chains keep the matrix pipe fed and only 32
-        // accumulator registers live): MFMAs, then bias, GroupNorm partial sums, bf16 -> the wave's LDS tile
-        const float vmask = (x0 + n32 < p.W) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
-            f32x16_t acc[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KSTEP; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[2 * mp + q][ks], sv[ks], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = 2 * mp + q;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(&biasv[32 * m + 8 * j + 4 * half]);
-                    const f32x2_t v0 = f32x2_t{acc[q][j * 4], acc[q][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
-                    const f32x2_t v1 = f32x2_t{acc[q][j * 4 + 2], acc[q][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
-                    bf16x4_t o;
-                    o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
-                    const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
-                    s1p[m * 2 + (j >> 1)] += w0 + w1;
-                    s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
-                    if (p.y != nullptr) *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
-                }
-            }
-        }
-        // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
-        // (uniform 64-bit base of the segment + one 32-bit lane offset: no per-lane 64-bit address registers)
+    // bias, GroupNorm partial sums, bf16 -> the wave's LDS tile for rows 8j + 4*half .. +3 of oc-tile m
+    auto epi = [&](const f32x16_t& a, int m, int j, float vmask) __attribute__((always_inline)) {
+#if defined(NAF_CONV0_ABL) && (NAF_CONV0_ABL & 1)   // experiments only: no epilogue
+        asm volatile("" ::"v"(a[j * 4]), "v"(a[j * 4 + 1]), "v"(a[j * 4 + 2]), "v"(a[j * 4 + 3]));
+        return;
+#endif
+        const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(&biasv[32 * m + 8 * j + 4 * half]);
+        const f32x2_t v0 = f32x2_t{a[j * 4], a[j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
+        const f32x2_t v1 = f32x2_t{a[j * 4 + 2], a[j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+        bf16x4_t o;
+        o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
+        const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
+        s1p[m * 2 + (j >> 1)] += w0 + w1;
+        s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
+        if (p.y != nullptr) *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
+    };
+    // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
+    // (uniform 64-bit base of the segment + one 32-bit lane offset: no per-lane 64-bit address registers)
+    auto store_rows = [&](int y, int x0) __attribute__((always_inline)) {
+#if defined(NAF_CONV0_ABL) && (NAF_CONV0_ABL & 2)   // experiments only: no row stores
+        return;
+#endif
         char* yr = reinterpret_cast<char*>(yb + (int64_t)y * p.ys[1] + (int64_t)x0 * p.ys[2]);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -152,9 +135,85 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
                 *reinterpret_cast<u32x4_t*>(yr + (int64_t)it * 8 * p.ys[2] + st_lane) = v;
             }
         }
-        if constexpr (KS == 1) __builtin_amdgcn_sched_barrier(0);   // consume the prefetch below the stores (exact vmcnt: the stores stay in flight)
+    };
+
+    if constexpr (KS == 3) {
+        // One wave issues in order and a dependent MFMA chain (64+ cycles per link) blocks the issue port, so the
+        // epilogue of one pair of oc-tiles only overlaps matrix work if it sits BETWEEN the MFMAs of the next pair in
+        // program order: half-step A = MFMAs of (segment, tiles 2,3) with the epilogue of (segment, tiles 0,1) spread
+        // through them, half-step B = MFMAs of (next segment, tiles 0,1) with the epilogue of (segment, tiles 2,3).
+        // (was: MFMAs, then epilogue, per pair -- the matrix pipe idled through 1600 cycles of VALU per segment)
+        auto mfma_with_epi = [&](const float (&taps)[KSTEP], int mp, f32x16_t (&out)[2], const f32x16_t (&done)[2], int mdone, float vmask)
+                                 __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEP; ++ks) sv[ks] = nx[ks];
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[q][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KSTEP; ++ks) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#if defined(NAF_CONV0_ABL) && (NAF_CONV0_ABL & 4)   // experiments only: no MFMAs
+                    out[q][0] += wr[2 * mp + q][ks] * taps[ks];
+#else
+                    out[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[2 * mp + q][ks], taps[ks], out[q], 0, 0, 0);
+#endif
+                }
+                if (ks >= 1 && ks <= 8) {   // 8 epilogue slices behind k-steps 1..8
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int c = ks - 1;
+                    epi(done[c >> 2], mdone + (c >> 2), c & 3, vmask);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        f32x16_t accA[2], accB[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[q][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) accA[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[q][ks], sv[ks], accA[q], 0, 0, 0);
+        for (; g < p.ngroups; g += gstride) {
+            load_taps(g + gstride, nx);   // needed by half-step B, a whole half-step of MFMAs away
+            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
+            const float vmask = (x0 + n32 < p.W) ? 1.0f : 0.0f;
+            mfma_with_epi(sv, 1, accB, accA, 0, vmask);
+            mfma_with_epi(nx, 0, accA, accB, 2, vmask);
+            store_rows(y, x0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEP; ++ks) sv[ks] = nx[ks];
+        }
+    } else {
+        for (; g < p.ngroups; g += gstride) {
+            load_taps(g + gstride, nx);   // next segment's taps load while this one's MFMAs run
+            __builtin_amdgcn_sched_barrier(0);
+            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
+            // two oc-tiles at a time (two interleaved accumulator chains, 32 accumulator registers live)
+            const float vmask = (x0 + n32 < p.W) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+                f32x16_t acc[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[2 * mp + q][ks], sv[ks], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) epi(acc[q], 2 * mp + q, j, vmask);
+            }
+            store_rows(y, x0);
+            __builtin_amdgcn_sched_barrier(0);   // consume the prefetch below the stores (exact vmcnt: the stores stay in flight)
+#pragma unroll
+            for (int ks = 0; ks < KSTEP; ++ks) sv[ks] = nx[ks];
+        }
     }
 
 #pragma unroll
