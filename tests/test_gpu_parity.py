@@ -725,17 +725,20 @@ def test_rccl_single_rank_sharded_forward(dev):
         dist.destroy_process_group()
 
 
-def test_captured_forward_replays_bit_exactly(dev):
+@pytest.mark.parametrize("hw,lr,C,ksz", [((64, 64), (4, 4), 128, 3),      # rotate-on-load shape
+                                          ((64, 64), (28, 28), 128, 9),    # non-integer ratio: tables built on the device, inside the graph
+                                          ((42, 56), (3, 4), 64, 3)])      # 14x14 cells: materialised queries
+def test_captured_forward_replays_bit_exactly(dev, hw, lr, C, ksz):
     """NAF.capture: the hipGraph replay gives the eager result, also after new inputs are copied in."""
     p = O.make_params(seed=5)
-    m = _load_model(dev, p, kernel_size=3)
-    img = O.hash_normal((1, 3, 64, 64), 801).to(dev)
-    ft = O.hash_normal((1, 128, 4, 4), 802).to(dev)
-    g = m.capture(img, ft, (64, 64))
-    assert torch.equal(g(), m(img, ft, (64, 64)))
-    img2 = O.hash_normal((1, 3, 64, 64), 803).to(dev)
-    ft2 = O.hash_normal((1, 128, 4, 4), 804).to(dev)
-    assert torch.equal(g(img2, ft2), m(img2, ft2, (64, 64)))
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *hw), 801).to(dev)
+    ft = O.hash_normal((1, C, *lr), 802).to(dev)
+    g = m.capture(img, ft, hw)
+    assert torch.equal(g(), m(img, ft, hw))
+    img2 = O.hash_normal((1, 3, *hw), 803).to(dev)
+    ft2 = O.hash_normal((1, C, *lr), 804).to(dev)
+    assert torch.equal(g(img2, ft2), m(img2, ft2, hw))
 
 
 @pytest.mark.parametrize("img_hw,lr,C,ksz", [
