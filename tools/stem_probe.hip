@@ -90,6 +90,25 @@ int main(int argc, char** argv) {
             double emin = 1e300;
             for (int g = 0; g < nb; ++g) emin = t[g * 8 + 4] < emin ? t[g * 8 + 4] : emin;
             printf("   first workgroup ends %.2f us after the first start, last %.2f us\n", (emin - t0) / 100, (tend - t0) / 100);
+            {   // who is slow?  mean end time by XCD (block id % 8), by segment (row band) and by strip column
+                double xs[8] = {0}, xn[8] = {0};
+                for (int g = 0; g < nb; ++g) { xs[g & 7] += t[g * 8 + 4] - t0; xn[g & 7] += 1; }
+                printf("   mean end by XCD:");
+                for (int i = 0; i < 8; ++i) printf(" %.1f", xs[i] / xn[i] / 100);
+                printf("\n   mean end by segment:");
+                for (int sgi = 0; sgi < p.segs_y; ++sgi) {
+                    double a = 0; int n = 0;
+                    for (int g = 0; g < nb; ++g) if ((g / p.tiles_x) % p.segs_y == sgi) { a += t[g * 8 + 4] - t0; ++n; }
+                    printf(" %.1f", a / n / 100);
+                }
+                printf("\n   mean end by strip:");
+                for (int tx = 0; tx < p.tiles_x; ++tx) {
+                    double a = 0; int n = 0;
+                    for (int g = 0; g < nb; ++g) if (g % p.tiles_x == tx) { a += t[g * 8 + 4] - t0; ++n; }
+                    printf(" %.0f", a / n / 100);
+                }
+                printf("\n");
+            }
         }
         run<3, 59 + 64>(p, nb, reps, "LDS reads + MFMA, no slot pins", px * 2 * 1152 * 128, by);
         run<3, 64>(p, nb, reps, "full, no slot pins", px * 2 * 1152 * 128, by);
