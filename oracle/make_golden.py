@@ -184,6 +184,20 @@ save("F8_gradients", param_seed=8, image_seed=801, feat_seed=802, weight_seed=80
      **{f"g{i}": (g_ref[n][::4, ::4] if g_ref[n].dim() == 4 and g_ref[n].shape[1] == 128 else g_ref[n]) for i, n in enumerate(keep)})
 # (the two 128x128 conv-weight gradients are stored as [::4, ::4] samples: 32 x 32 x k x k)
 
+# ---- F9: non-integer ratios end to end (notebooks/inference.ipynb cell 19: 28^2 -> 64^2; a rectangular 2.7 x 4.05 case):
+#      nearest-exact K/V upsampling + dilation floor(ratio) inside the reference's CrossAttention, repeated taps ---------
+p9 = O.make_params(dim=256, heads_rope=4, seed=9)
+m9 = ref_model(p9, kernel_size=9)
+f9 = {}
+for tag, hw, lr9, C9, iseed in (("a", (64, 64), (28, 28), 64, 901), ("b", (100, 150), (37, 37), 128, 903)):
+    img9 = O.hash_normal((1, 3, *hw), seed=iseed)
+    ft9 = O.hash_normal((1, C9, *lr9), seed=iseed + 1)
+    o_ref = m9(img9, ft9, hw)
+    report[f"F9{tag} non-integer ratio"] = maxdiff(o_ref, O.naf_forward(p9, img9, ft9, hw, kernel_size=9))
+    f9[f"{tag}_sample"] = (o_ref[:, :, 1::2, ::2] if tag == "a" else o_ref[:, ::4, 1::2, ::3]).contiguous()   # strided samples
+    f9[f"{tag}_shape"] = np.array([*hw, *lr9, C9, iseed])
+save("F9_noninteger_ratio", param_seed=9, k=9, **f9)
+
 print("\noracle vs imported reference (max abs diff, fp32):")
 worst = 0.0
 for k_, v_ in report.items():
@@ -197,4 +211,4 @@ with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
     f.write("oracle/naf_oracle.py vs imported reference + natten shim (max abs diff, fp32)\n")
     for k_, v_ in report.items():
         f.write(f"{k_:28s} {v_:.3e}\n")
-print("OK: oracle pinned to the imported reference (<= 1e-5) on F1-F8")
+print("OK: oracle pinned to the imported reference (<= 1e-5) on F1-F9")

@@ -399,6 +399,29 @@ def test_golden_F5_full_forward_P1(dev, golden_dir):
     assert_close(out_b.float().cpu()[:, :, oy::st, ox::st], ref, 8e-2, 4e-2, "F5 bf16 I/O")
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_F9_noninteger_ratio(dev, golden_dir, tag):
+    """Whole forward at non-integer ratios against the REFERENCE's output (notebook geometry 28^2 -> 64^2; 37^2 ->
+    100x150): the table-driven MFMA kernel with the index tables naf_forward builds on the device."""
+    from naf_amd import ops
+    g = _g(golden_dir, "F9_noninteger_ratio")
+    p = O.make_params(seed=int(g["param_seed"]))
+    m = _load_model(dev, p, kernel_size=int(g["k"]))
+    H, W, h, w, C, iseed = (int(v) for v in g[f"{tag}_shape"])
+    img = O.hash_normal((1, 3, H, W), iseed).to(dev)
+    ft = O.hash_normal((1, C, h, w), iseed + 1).to(dev)
+    assert m._forward_plan(img, ft, (H, W)) is not None
+    q5 = torch.empty(1, 4, H, W, 64, dtype=torch.bfloat16, device=dev)
+    k5 = torch.empty(1, 4, h, w, 64, dtype=torch.bfloat16, device=dev)
+    v5 = torch.empty(1, h, w, 4, C // 4, dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
+    assert ops.xna_select(q5, k5, v5, int(g["k"])) == "union"
+    out = m(img, ft, (H, W)).float().cpu()
+    got = out[:, :, 1::2, ::2] if tag == "a" else out[:, ::4, 1::2, ::3]
+    ref = torch.from_numpy(g[f"{tag}_sample"])
+    assert_close(got, ref, 6e-2, 3e-2, f"F9{tag} strided sample vs reference")
+    assert _forward_stats(got, ref)[1] <= 6e-3
+
+
 def test_golden_F6_denoise_like(dev, golden_dir):
     g = _g(golden_dir, "F6_denoise_d1")
     p = O.make_params(dim=int(g["dim"]), heads_rope=1, seed=int(g["param_seed"]))

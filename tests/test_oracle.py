@@ -63,6 +63,17 @@ def test_golden_F4_nonmultiple(golden_dir):
         assert np.abs(lg.numpy() - g[f"logits_k{kk}"]).max() <= TOL
 
 
+def test_golden_F9_noninteger_ratio(golden_dir):
+    """Notebook geometry 28^2 -> 64^2 and a rectangular 37^2 -> 100x150 case, whole forward, window 9."""
+    g = _load(golden_dir, "F9_noninteger_ratio")
+    p = O.make_params(seed=int(g["param_seed"]))
+    for tag in ("a", "b"):
+        H, W, h, w, C, iseed = (int(v) for v in g[f"{tag}_shape"])
+        out = O.naf_forward(p, O.hash_normal((1, 3, H, W), iseed), O.hash_normal((1, C, h, w), iseed + 1), (H, W), kernel_size=int(g["k"]))
+        got = out[:, :, 1::2, ::2] if tag == "a" else out[:, ::4, 1::2, ::3]
+        assert np.abs(got.numpy() - g[f"{tag}_sample"]).max() <= TOL
+
+
 def test_golden_F5_full_P1(golden_dir):
     """BASELINE configs[0]: 1x3x224x224 image, 1x384x14x14 features -> 224x224, window 7."""
     g = _load(golden_dir, "F5_full_P1")
