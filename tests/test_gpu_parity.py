@@ -328,6 +328,64 @@ def test_union_and_generic_agree_on_a_large_problem(dev):
     assert_close(a, b, 6e-3, 6e-3, "union vs generic")
 
 
+def test_union_fuzz_against_generic(dev):
+    """Seeded random geometries (ratios 1 .. 20 per axis, every window size, ragged widths, several channel counts):
+    the table-driven MFMA kernel against the independent scalar table kernel on the same bf16 inputs."""
+    from naf_amd import ops
+    rng = np.random.RandomState(1234)
+    done = 0
+    for _ in range(400):
+        ksz = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        h, w = int(rng.randint(ksz, 40)), int(rng.randint(ksz, 40))
+        ry, rx = rng.uniform(1.0, 20.0) ** rng.uniform(0.3, 1.0), rng.uniform(1.0, 20.0) ** rng.uniform(0.3, 1.0)
+        Ho, Wo = max(h, int(h * ry)), max(w, int(w * rx))
+        if Ho * Wo > 160 * 160 or ksz * (Ho // h) > Ho or ksz * (Wo // w) > Wo:
+            continue
+        heads = int(rng.choice([1, 2, 4]))
+        C = heads * int(rng.choice([16, 32, 48, 96, 192, 256, 512]))
+        q = torch.randn(1, heads, Ho, Wo, 64, device=dev).to(torch.bfloat16)
+        k = torch.randn(1, heads, h, w, 64, device=dev).to(torch.bfloat16)
+        v = torch.randn(1, h, w, heads, C // heads, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        a = ops.xna_forward(q, k, v, ksz, out_dtype=torch.float32, path="union")
+        b = ops.xna_forward(q, k, v, ksz, out_dtype=torch.float32, path="generic")
+        err = (a - b).abs().max().item()
+        assert torch.isfinite(a).all() and err <= 6e-3 + 6e-3 * b.abs().max().item(), (h, w, Ho, Wo, ksz, C, heads, err)
+        done += 1
+        if done >= 60:
+            break
+    assert done >= 40
+
+
+def test_cell_kernels_fuzz_against_generic(dev):
+    """Seeded random integer-ratio geometries (cells 2x4 .. 20x32, all windows, Dv 16 .. 256, bf16 / fp32 output): the cell
+    and sliding-window kernels against the scalar table kernel."""
+    from naf_amd import ops
+    rng = np.random.RandomState(4321)
+    done = 0
+    for _ in range(400):
+        ksz = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        h, w = int(rng.randint(ksz, 24)), int(rng.randint(ksz, 24))
+        dy, dx = int(rng.randint(1, 21)), int(rng.choice([2, 4, 5, 8, 14, 16, 16, 16, 32]))
+        Ho, Wo = h * dy, w * dx
+        if dy * dx < 8 or Ho * Wo > 200 * 200:
+            continue
+        heads = int(rng.choice([1, 2, 4]))
+        C = heads * int(rng.choice([16, 32, 64, 96, 128, 192, 256]))
+        od = torch.float32 if rng.rand() < 0.5 else torch.bfloat16
+        q = torch.randn(1, heads, Ho, Wo, 64, device=dev).to(torch.bfloat16)
+        k = torch.randn(1, heads, h, w, 64, device=dev).to(torch.bfloat16)
+        v = torch.randn(1, h, w, heads, C // heads, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        a = ops.xna_forward(q, k, v, ksz, out_dtype=od, path="mfma").float()
+        b = ops.xna_forward(q, k, v, ksz, out_dtype=torch.float32, path="generic")
+        tol = 6e-3 if od == torch.float32 else 1.2e-2
+        err = (a - b).abs().max().item()
+        assert torch.isfinite(a).all() and err <= tol + tol * b.abs().max().item(), (h, w, dy, dx, ksz, C, heads, od, err)
+        done += 1
+        if done >= 60:
+            break
+    assert done >= 40
+
+
 def test_generic_and_mfma_agree(dev):
     """Two independent kernels on an integer-ratio problem."""
     h, w, d, ksz, heads, C = 10, 9, 8, 7, 4, 192
