@@ -172,6 +172,45 @@ def test_stem_conv_layer(dev, ks, shape):
     assert torch.allclose(st_out[..., 1].cpu(), (gr * gr).sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
 
 
+def test_stem_layers_fuzz_small_and_odd_sizes(dev):
+    """Seeded random image sizes from 2x2 up (narrower than a 32-pixel strip, shorter than a step, odd, batched): conv0
+    and the GroupNorm -> SiLU -> conv layers of both kernel sizes against torch fp32, as in the two tests above."""
+    import torch.nn.functional as F
+    from naf_amd import ops
+    rng = np.random.RandomState(77)
+    sizes = [(2, 2), (2, 33), (3, 3), (5, 64), (33, 2), (64, 31)] + [(int(rng.randint(2, 80)), int(rng.randint(2, 100))) for _ in range(10)]
+    for n, (H, W) in enumerate(sizes):
+        B = 1 + n % 2
+        for ks in (1, 3):
+            img = O.hash_normal((B, 3, H, W), 600 + n)
+            w0 = O.hash_normal((128, 3, ks, ks), 62, 0.3)
+            b0 = O.hash_normal((128,), 63, 0.1)
+            ref0 = F.conv2d(F.pad(img, (1,) * 4, mode="reflect") if ks == 3 else img, w0, b0)
+            y0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+            st0 = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+            ops.stem_conv0(img.to(dev), w0.to(dev), b0.to(dev), y0, st0)
+            assert_close(y0.float().cpu().permute(0, 3, 1, 2), ref0, 1e-5, 2 ** -8, f"conv0 k={ks} {B}x{H}x{W}")
+            g0 = ref0.double().view(B, 8, 16, H, W)
+            assert torch.allclose(st0[..., 0].cpu(), g0.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+            # the layer on top of it
+            x = bf16r(ref0)
+            w = bf16r(O.hash_normal((128, 128, ks, ks), 72, 1.0 / (11.3 * ks)))
+            bias = O.hash_normal((128,), 73, 0.1)
+            gw, gb = 1.0 + O.hash_normal((128,), 74, 0.1), O.hash_normal((128,), 75, 0.1)
+            a = bf16r(F.silu(F.group_norm(x, 8, gw, gb, 1e-5)))
+            ref = F.conv2d(F.pad(a, (1,) * 4, mode="reflect") if ks == 3 else a, w, bias)
+            gx = x.double().view(B, 8, 16, H, W)
+            st_in = torch.stack([gx.sum(dim=(2, 3, 4)), (gx * gx).sum(dim=(2, 3, 4))], dim=-1).to(dev)
+            st_out = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+            y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+            wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
+            ops.stem_conv(y0, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
+            got = y.float().cpu().permute(0, 3, 1, 2)
+            assert_close(got, ref, 3e-2, 1.5e-2, f"stem conv k={ks} {B}x{H}x{W}")
+            gr = ref.double().view(B, 8, 16, H, W)
+            assert torch.allclose(st_out[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+
+
 @pytest.mark.parametrize("shape", [(1, 20, 24), (2, 45, 67), (1, 160, 64)])
 def test_stem_whole_matches_oracle(dev, shape):
     """Both branches, all 5 layers each, against the fp32 oracle conv stem (convolutions.py:67-92)."""
