@@ -48,9 +48,12 @@ enum naf_xna_path {
     NAF_XNA_AUTO = 0,    /* pick: MFMA cell kernel, else table-driven MFMA kernel, else generic kernel */
     NAF_XNA_MFMA = 1,    /* integer ratio Ho = dy*h, Wo = dx*w; one workgroup per (cell, head) */
     NAF_XNA_GENERIC = 2, /* any sizes, head dims, rectangular windows; needs idx_y / idx_x (any tables) */
-    NAF_XNA_UNION = 3    /* any ratio >= 1 on the matrix cores (Dq = 64, Dv % 16 == 0, square window <= 15); needs
+    NAF_XNA_UNION = 3,   /* any ratio >= 1 on the matrix cores (Dq = 64, Dv % 16 == 0, square window <= 15); needs
                             idx_y / idx_x and they MUST be the canonical tables of naf_axis_index_table: the library
                             sizes its LDS windows from the same rule.  Other tables: NAF_XNA_GENERIC. */
+    NAF_XNA_ROWS = 4     /* row-streaming matrix-core kernel for the head shapes the others do not take: Dq any of
+                            {64, 96, 128, 192, 256, 384, 512}, Dv <= 64 (the denoising call: one head, C = 3), square
+                            window <= 15, any ratio >= 1; needs the canonical idx_y / idx_x like NAF_XNA_UNION */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -170,8 +173,8 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
  *          the reference's return_weights=True hands back (attentions.py:27-28); NULL to skip.  Both paths
  *          produce them (the MFMA kernel writes them from its S^T accumulators).
  *   idx_y  optional device int32 [Ho][ky], idx_x [Wo][kx] from naf_axis_index_table; required by the two
- *          table-driven paths (NAF_XNA_UNION, NAF_XNA_GENERIC), ignored by the cell kernels (closed form,
- *          integer ratio).  AUTO may pick NAF_XNA_UNION, so callers that pass tables of their own making must
+ *          table-driven paths (NAF_XNA_UNION, NAF_XNA_ROWS, NAF_XNA_GENERIC), ignored by the cell kernels (closed
+ *          form, integer ratio).  AUTO may pick NAF_XNA_UNION / NAF_XNA_ROWS, so callers that pass tables of their own making must
  *          ask for NAF_XNA_GENERIC.
  *   rope_tab_y / rope_tab_x  optional device float [Ho][2][Dq/4] / [Wo][2][Dq/4] from naf_rope_tables.  When
  *          both are given, `q` holds the UN-rotated guidance and the kernel applies RoPE (rope.py:15-34,139-153,
@@ -201,7 +204,7 @@ typedef struct naf_xna_args {
     int64_t o_stride[4];
 } naf_xna_args;
 
-/* Which kernel naf_xna_fwd would run for these arguments (NAF_XNA_MFMA, NAF_XNA_UNION or NAF_XNA_GENERIC), or a
+/* Which kernel naf_xna_fwd would run for these arguments (NAF_XNA_MFMA, NAF_XNA_UNION, NAF_XNA_ROWS or NAF_XNA_GENERIC), or a
  * negative naf_status on invalid arguments.  Lets the caller skip building index tables (MFMA needs none). */
 int naf_xna_select(const naf_xna_args* a);
 /* Diagnostics: the workgroup plan of the NAF_XNA_UNION path for these arguments, out = {slots per window row

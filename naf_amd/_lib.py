@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the HIP library is dlopen'e
 LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
 NAF_BF16, NAF_F32 = 0, 1
-XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION = 0, 1, 2, 3
+XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION, XNA_ROWS = 0, 1, 2, 3, 4
 
 I64x4 = C.c_int64 * 4
 

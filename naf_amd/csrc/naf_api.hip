@@ -145,7 +145,7 @@ static int xna_validate(const naf_xna_args* a) {
     NAF_REQUIRE((int64_t)a->ky * (a->Ho / a->h) <= a->Ho && (int64_t)a->kx * (a->Wo / a->w) <= a->Wo,
                 "naf_xna_fwd: kernel_size * dilation exceeds the output extent (k=%dx%d, dilation=%dx%d, out=%dx%d)",
                 a->ky, a->kx, a->Ho / a->h, a->Wo / a->w, a->Ho, a->Wo);
-    NAF_REQUIRE(a->path == NAF_XNA_AUTO || a->path == NAF_XNA_MFMA || a->path == NAF_XNA_GENERIC || a->path == NAF_XNA_UNION, "naf_xna_fwd: path %d", a->path);
+    NAF_REQUIRE(a->path == NAF_XNA_AUTO || a->path == NAF_XNA_MFMA || a->path == NAF_XNA_GENERIC || a->path == NAF_XNA_UNION || a->path == NAF_XNA_ROWS, "naf_xna_fwd: path %d", a->path);
     NAF_REQUIRE((a->rope_tab_y == nullptr) == (a->rope_tab_x == nullptr), "naf_xna_fwd: rope_tab_y and rope_tab_x must be given together");
     return NAF_OK;
 }
@@ -171,6 +171,13 @@ int naf_xna_select(const naf_xna_args* a) {
         }
         return NAF_XNA_UNION;
     }
+    if (a->path == NAF_XNA_ROWS) {
+        if (!naf_xna_rows_eligible(a)) {
+            naf_set_error("naf_xna_select: row-streaming MFMA path requested but the arguments are not eligible");
+            return -NAF_ERR_UNSUPPORTED;
+        }
+        return NAF_XNA_ROWS;
+    }
     if (a->path == NAF_XNA_MFMA) {
         if (!ok) {
             naf_set_error("naf_xna_select: MFMA path requested but the arguments are not eligible");
@@ -186,6 +193,7 @@ int naf_xna_select(const naf_xna_args* a) {
     if (ok && (cell_px >= 100 || a->logits != nullptr || no_union) && cell_px >= 8) return NAF_XNA_MFMA;
     if (!no_union && a->logits == nullptr && naf_xna_union_eligible(a)) return NAF_XNA_UNION;
     if (ok && cell_px >= 8) return NAF_XNA_MFMA;
+    if (!no_union && a->logits == nullptr && naf_xna_rows_eligible(a)) return NAF_XNA_ROWS;   // other head dims, few value channels
     return NAF_XNA_GENERIC;
 }
 
@@ -200,6 +208,7 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream) {
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
     if (sel == NAF_XNA_MFMA) return naf_launch_xna_mfma(a, scale, static_cast<hipStream_t>(stream));
     if (sel == NAF_XNA_UNION) return naf_launch_xna_union(a, scale, static_cast<hipStream_t>(stream));
+    if (sel == NAF_XNA_ROWS) return naf_launch_xna_rows(a, scale, static_cast<hipStream_t>(stream));
     return naf_launch_xna_generic(a, scale, static_cast<hipStream_t>(stream));
 }
 

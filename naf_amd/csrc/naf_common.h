@@ -36,6 +36,8 @@ int naf_xna_mfma_rope_ok(const naf_xna_args* a);                                
 int naf_launch_xna_generic(const naf_xna_args* a, float scale, hipStream_t s);   // xna_generic.hip
 int naf_launch_xna_union(const naf_xna_args* a, float scale, hipStream_t s);     // xna_union.hip
 int naf_xna_union_eligible(const naf_xna_args* a);                               // xna_union.hip
+int naf_launch_xna_rows(const naf_xna_args* a, float scale, hipStream_t s);      // xna_rows.hip
+int naf_xna_rows_eligible(const naf_xna_args* a);                                // xna_rows.hip
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);   // xna_bwd.hip
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a);                             // xna_bwd.hip
 int naf_launch_xna_generic_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);  // xna_generic.hip

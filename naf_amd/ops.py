@@ -39,8 +39,8 @@ class _Timed:
         if KERNEL_TIMER is not None:
             KERNEL_TIMER.stop(self.name)
         return False
-_PATH = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "generic": _lib.XNA_GENERIC, "union": _lib.XNA_UNION}
-_PATH_NAME = {_lib.XNA_MFMA: "mfma", _lib.XNA_GENERIC: "generic", _lib.XNA_UNION: "union"}
+_PATH = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "generic": _lib.XNA_GENERIC, "union": _lib.XNA_UNION, "rows": _lib.XNA_ROWS}
+_PATH_NAME = {_lib.XNA_MFMA: "mfma", _lib.XNA_GENERIC: "generic", _lib.XNA_UNION: "union", _lib.XNA_ROWS: "rows"}
 
 
 def _gpu(t: torch.Tensor, name: str) -> None:

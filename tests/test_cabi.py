@@ -119,7 +119,8 @@ def test_union_planner_covers_every_window(built_lib, geom):
 
 def test_xna_auto_policy(built_lib):
     """AUTO: cell kernels for integer ratios with 10x10+ cells, the table-driven MFMA kernel for smaller cells,
-    non-integer ratios and ratio 1, the generic kernel for other head dims / channel counts / return_weights."""
+    non-integer ratios and ratio 1, the row-streaming MFMA kernel for other head dims / few value channels, the generic
+    kernel for what is left (odd head dims, return_weights off the cell path)."""
     from naf_amd import _lib
     lib = _lib.load()
     sel = lambda *g, **kw: lib.naf_xna_select(C.byref(_xna_args(*g, **kw)))
@@ -129,7 +130,9 @@ def test_xna_auto_policy(built_lib):
     assert sel(28, 28, 64, 64, 384, 9) == _lib.XNA_UNION             # ratio 2.29
     assert sel(40, 40, 40, 40, 384, 7) == _lib.XNA_UNION             # ratio 1
     assert sel(28, 28, 64, 64, 384, 9, logits=True) == _lib.XNA_GENERIC
-    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=96) == _lib.XNA_GENERIC     # denoising-like
+    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=96) == _lib.XNA_ROWS        # denoising-like: one head of 96, C = 3
+    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=80) == _lib.XNA_GENERIC     # head dim without an instantiation
+    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=96, logits=True) == _lib.XNA_GENERIC
     assert sel(8, 8, 32, 32, 128, 7, logits=True) == _lib.XNA_MFMA   # return_weights stays on the cell kernel
     assert sel(28, 28, 64, 64, 384, 9, path=_lib.XNA_MFMA) == -2     # NAF_ERR_UNSUPPORTED
 

@@ -367,6 +367,63 @@ def test_union_and_generic_agree_on_a_large_problem(dev):
     assert_close(a, b, 6e-3, 6e-3, "union vs generic")
 
 
+ROWS_CASES = [
+    # (B, heads, Dq, (Ho, Wo), (h, w), ksz, C): the row-streaming MFMA kernel (other head dims, few value channels)
+    (2, 1, 64, (24, 20), (24, 20), 5, 3),        # F6 geometry: denoising-like, ratio 1, C = 3
+    (1, 1, 96, (33, 47), (33, 47), 15, 3),       # denoising.py:213 defaults: one head of 96, window 15
+    (1, 1, 512, (20, 40), (20, 40), 15, 3),      # dim 512
+    (1, 2, 128, (64, 64), (28, 28), 9, 10),      # non-integer ratio, Dv = 5
+    (1, 4, 64, (23, 30), (5, 7), 3, 24),         # F4 sizes, Dv = 6
+    (1, 1, 192, (50, 70), (10, 14), 7, 64),      # 5x5 cells, Dv = 64 (four channel tiles)
+    (1, 2, 256, (40, 33), (20, 11), 7, 34),      # Dv = 17: a full and a one-channel tile
+    (1, 1, 384, (18, 18), (18, 18), 13, 48),
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES)
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_xna_rows_matches_oracle(dev, case, out_dtype):
+    from naf_amd import ops
+    B, heads, Dq, (Ho, Wo), (h, w), ksz, C = case
+    seed = 11 * Ho + Wo + ksz + Dq
+    q = bf16r(O.hash_normal((B, Dq * heads, Ho, Wo), seed + 1) * (64.0 / Dq) ** 0.25)
+    k = bf16r(O.hash_normal((B, Dq * heads, h, w), seed + 2) * (64.0 / Dq) ** 0.25)
+    v = bf16r(O.hash_normal((B, C, h, w), seed + 3))
+    ref = O.xna(q, k, v, ksz, heads)
+    q5, k5 = to5(q, heads).to(dev), to5(k, heads).to(dev)
+    v5 = ops.pack_values(v.to(dev)).view(B, h, w, heads, C // heads).permute(0, 3, 1, 2, 4)
+    assert ops.xna_select(q5, k5, v5, ksz) == "rows"                  # what AUTO picks for these shapes
+    out = run_xna(dev, q, k, v, ksz, heads, out_dtype=out_dtype, path="rows")
+    tol = 6e-3 if out_dtype == torch.float32 else 1.2e-2
+    assert_close(out, ref, tol, tol, f"rows {case} {out_dtype}")
+
+
+def test_rows_fuzz_against_generic(dev):
+    from naf_amd import ops
+    rng = np.random.RandomState(99)
+    done = 0
+    for _ in range(300):
+        ksz = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15]))
+        h, w = int(rng.randint(max(ksz, 2), 36)), int(rng.randint(max(ksz, 2), 36))
+        ry, rx = rng.uniform(1.0, 12.0) ** rng.uniform(0.0, 1.0), rng.uniform(1.0, 12.0) ** rng.uniform(0.0, 1.0)
+        Ho, Wo = max(h, int(h * ry)), max(w, int(w * rx))
+        if Ho * Wo > 120 * 120 or ksz * (Ho // h) > Ho or ksz * (Wo // w) > Wo:
+            continue
+        heads, Dq = int(rng.choice([1, 2])), int(rng.choice([64, 96, 128, 192, 256, 384, 512]))
+        Dv = int(rng.randint(1, 65))
+        q = (torch.randn(1, heads, Ho, Wo, Dq, device=dev) * (64.0 / Dq) ** 0.25).to(torch.bfloat16)
+        k = (torch.randn(1, heads, h, w, Dq, device=dev) * (64.0 / Dq) ** 0.25).to(torch.bfloat16)
+        v = torch.randn(1, h, w, heads, Dv, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        a = ops.xna_forward(q, k, v, ksz, out_dtype=torch.float32, path="rows")
+        b = ops.xna_forward(q, k, v, ksz, out_dtype=torch.float32, path="generic")
+        err = (a - b).abs().max().item()
+        assert torch.isfinite(a).all() and err <= 6e-3 + 6e-3 * b.abs().max().item(), (h, w, Ho, Wo, ksz, Dq, Dv, heads, err)
+        done += 1
+        if done >= 50:
+            break
+    assert done >= 35
+
+
 def test_union_fuzz_against_generic(dev):
     """Seeded random geometries (ratios 1 .. 20 per axis, every window size, ragged widths, several channel counts):
     the table-driven MFMA kernel against the independent scalar table kernel on the same bf16 inputs."""
