@@ -980,7 +980,7 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     ((64, 64), (28, 28), 128, 9, "union"),     # non-integer ratio: index tables built on the device
     ((40, 48), (20, 24), 256, 7, "union"),     # 2x2 cells
     ((45, 45), (45, 45), 64, 3, "union"),      # ratio 1
-    ((23, 30), (5, 7), 24, 3, "generic"),      # Dv = 6: generic kernel
+    ((23, 30), (5, 7), 24, 3, "rows"),         # Dv = 6: row-streaming kernel
 ])
 def test_single_call_forward_other_geometries(dev, hw, lr, C, ksz, path):
     """naf_forward beyond the rotate-on-load shapes: same kernels, same bits as the composed path; the index tables it
