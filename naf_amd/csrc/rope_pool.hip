@@ -44,6 +44,8 @@ struct RopePoolParams {
     int32_t tpp;     // threads per pixel (power of two dividing 256)
     int32_t nchunk;  // pair-chunks per pixel = Cq / (2 * VEC)
     int32_t tab_lds; // 1: the cell's table rows are staged in LDS (vector path)
+    int32_t ppc;     // planes (pixels in flight) per cell; 256 / tpp / ppc cells per workgroup
+    int32_t ncells;  // B * h * w
     int64_t xs[4], qs[4], ks[4];
 };
 
@@ -91,12 +93,15 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [256 / tpp][Cq]
     const int tid = threadIdx.x;
-    int L = blockIdx.x;
+    // small cells (ratio 1: ONE pixel per cell) share a workgroup: plane -> (cell of the workgroup, pixel lane of the cell)
+    const int cpw = (256 / p.tpp) / p.ppc;                     // cells per workgroup
+    const int cell_l = (tid / p.tpp) / p.ppc;                  // this thread's cell inside the workgroup
+    const bool cell_ok = (int64_t)blockIdx.x * cpw + cell_l < p.ncells;
+    int L = (int)min((int64_t)blockIdx.x * cpw + cell_l, (int64_t)p.ncells - 1);
     const int cx = L % p.w;
     L /= p.w;
     const int cy = L % p.h;
     const int b = L / p.h;
-
     // adaptive_avg_pool2d window (naf.py:68) and the owned (query-writing) range
     const int ys = (int)(((int64_t)cy * p.Ho) / p.h), ye = (int)((((int64_t)cy + 1) * p.Ho + p.h - 1) / p.h);
     const int xs = (int)(((int64_t)cx * p.Wo) / p.w), xe = (int)((((int64_t)cx + 1) * p.Wo + p.w - 1) / p.w);
@@ -119,8 +124,9 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
     }
 
     const int chunk = tid & (p.tpp - 1);
-    const int plane = tid / p.tpp;
-    const int nplanes = 256 / p.tpp;
+    const int plane_all = tid / p.tpp;                          // row of the reduction scratch
+    const int plane = plane_all % p.ppc;                        // pixel lane inside the cell
+    const int nplanes = p.ppc;
     const bool active = chunk < p.nchunk;
 
     const int half = p.Dh >> 1, quarter = p.Dh >> 2;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
                 acc1[i] += o1[i];
                 acc2[i] += o2[i];
             }
-            if (p.q != nullptr && y < yo && x < xo) {   // q == NULL: keys only (queries are rotated on load by naf_xna_fwd)
+            if (p.q != nullptr && cell_ok && y < yo && x < xo) {   // q == NULL: keys only (queries are rotated on load by naf_xna_fwd)
                 bf16_t* qp = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)y * p.qs[2] + (int64_t)x * p.qs[3] + t0;
                 store_bf16<VEC>(qp, o1);
                 store_bf16<VEC>(qp + half, o2);
@@ -198,17 +204,23 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            red[plane * p.Cq + c1 + i] = acc1[i];
-            red[plane * p.Cq + c1 + half + i] = acc2[i];
+            red[plane_all * p.Cq + c1 + i] = acc1[i];
+            red[plane_all * p.Cq + c1 + half + i] = acc2[i];
         }
     }
     __syncthreads();
-    const float invn = 1.0f / (float)npix;
-    for (int c = tid; c < p.Cq; c += 256) {
+    // key = mean over the cell's planes; thread -> (cell of the workgroup, channel)
+    for (int e = tid; e < cpw * p.Cq; e += 256) {
+        const int cl = e / p.Cq, c = e - cl * p.Cq;
+        const int64_t Lc = (int64_t)blockIdx.x * cpw + cl;
+        if (Lc >= p.ncells) continue;
+        const int ccx = (int)(Lc % p.w), ccy = (int)((Lc / p.w) % p.h), cb = (int)(Lc / ((int64_t)p.w * p.h));
+        const int cys = (int)(((int64_t)ccy * p.Ho) / p.h), cye = (int)((((int64_t)ccy + 1) * p.Ho + p.h - 1) / p.h);
+        const int cxs = (int)(((int64_t)ccx * p.Wo) / p.w), cxe = (int)((((int64_t)ccx + 1) * p.Wo + p.w - 1) / p.w);
         float s = 0.f;
-        for (int pl = 0; pl < nplanes; ++pl) s += red[pl * p.Cq + c];
+        for (int pl = 0; pl < p.ppc; ++pl) s += red[(cl * p.ppc + pl) * p.Cq + c];
         const int hd = c / p.Dh, d = c - hd * p.Dh;
-        p.k[b * p.ks[0] + hd * p.ks[1] + (int64_t)cy * p.ks[2] + (int64_t)cx * p.ks[3] + d] = (bf16_t)(s * invn);
+        p.k[cb * p.ks[0] + hd * p.ks[1] + (int64_t)ccy * p.ks[2] + (int64_t)ccx * p.ks[3] + d] = (bf16_t)(s * (1.0f / (float)((cye - cys) * (cxe - cxs))));
     }
 }
 
@@ -242,9 +254,16 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
         return NAF_ERR_UNSUPPORTED;
     }
     p.tpp = tpp;
+    // planes per cell: all of the workgroup's pixel lanes for the usual cells, fewer (several cells per workgroup) when a
+    // cell holds fewer pixels than that -- at ratio 1 a cell is ONE pixel and a workgroup per cell left 15 of 16 lanes idle
+    const int64_t npix_typ = (int64_t)(a->Ho / a->h) * (a->Wo / a->w);
+    int ppc = 256 / tpp;
+    while (ppc > 1 && ppc > npix_typ) ppc >>= 1;
+    p.ppc = ppc;
+    const int cpw = (256 / tpp) / ppc;
     size_t lds = (size_t)(256 / tpp) * a->Cq * sizeof(float);
     p.tab_lds = 0;
-    if (vec) {
+    if (vec && cpw == 1) {
         const int wy_max = (a->Ho + a->h - 1) / a->h + 1, wx_max = (a->Wo + a->w - 1) / a->w + 1;
         const size_t tl = (size_t)(wy_max + wx_max) * (2 * (p.Dh / 4) + 4) * sizeof(float);
         if (lds + tl <= 48 * 1024) {
@@ -256,11 +275,13 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
         naf_set_error("naf_rope_pool_fwd: reduction scratch %zu B exceeds 64 KiB (Cq=%d)", lds, a->Cq);
         return NAF_ERR_UNSUPPORTED;
     }
-    const int64_t nb = (int64_t)a->B * a->h * a->w;
-    if (nb <= 0 || nb > 0x7fffffffLL) {
+    const int64_t ncell = (int64_t)a->B * a->h * a->w;
+    const int64_t nb = (ncell + cpw - 1) / cpw;
+    if (nb <= 0 || ncell > 0x7fffffffLL) {
         naf_set_error("naf_rope_pool_fwd: grid out of range");
         return NAF_ERR_INVALID;
     }
+    p.ncells = (int32_t)ncell;
     const dim3 g((uint32_t)nb), blk(256);
     if (a->x_dtype == NAF_BF16) {
         if (vec) hipLaunchKernelGGL((rope_pool_kernel<bf16_t, 8>), g, blk, lds, s, p);
