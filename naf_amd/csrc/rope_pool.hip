@@ -89,15 +89,16 @@ __device__ __forceinline__ void store_bf16(bf16_t* p, const float (&v)[VEC]) {
 }
 
 // T = input element type, VEC = channels per thread per half (8: vector path, 1: any Dh % 4 == 0)
-template <typename T, int VEC>
+// MULTI: several (small) cells per workgroup; otherwise the cell is the block id and every cell quantity is wave-uniform
+template <typename T, int VEC, bool MULTI>
 __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [256 / tpp][Cq]
     const int tid = threadIdx.x;
     // small cells (ratio 1: ONE pixel per cell) share a workgroup: plane -> (cell of the workgroup, pixel lane of the cell)
-    const int cpw = (256 / p.tpp) / p.ppc;                     // cells per workgroup
-    const int cell_l = (tid / p.tpp) / p.ppc;                  // this thread's cell inside the workgroup
-    const bool cell_ok = (int64_t)blockIdx.x * cpw + cell_l < p.ncells;
-    int L = (int)min((int64_t)blockIdx.x * cpw + cell_l, (int64_t)p.ncells - 1);
+    const int cpw = MULTI ? (256 / p.tpp) / p.ppc : 1;         // cells per workgroup
+    const int cell_l = MULTI ? (tid / p.tpp) / p.ppc : 0;      // this thread's cell inside the workgroup
+    const bool cell_ok = !MULTI || (int64_t)blockIdx.x * cpw + cell_l < p.ncells;
+    int L = MULTI ? (int)min((int64_t)blockIdx.x * cpw + cell_l, (int64_t)p.ncells - 1) : (int)blockIdx.x;
     const int cx = L % p.w;
     L /= p.w;
     const int cy = L % p.h;
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
 
     const int chunk = tid & (p.tpp - 1);
     const int plane_all = tid / p.tpp;                          // row of the reduction scratch
-    const int plane = plane_all % p.ppc;                        // pixel lane inside the cell
-    const int nplanes = p.ppc;
+    const int plane = MULTI ? plane_all % p.ppc : plane_all;    // pixel lane inside the cell
+    const int nplanes = MULTI ? p.ppc : 256 / p.tpp;
     const bool active = chunk < p.nchunk;
 
     const int half = p.Dh >> 1, quarter = p.Dh >> 2;
@@ -209,6 +210,16 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
         }
     }
     __syncthreads();
+    if constexpr (!MULTI) {
+        const float invn = 1.0f / (float)npix;
+        for (int c = tid; c < p.Cq; c += 256) {
+            float s = 0.f;
+            for (int pl = 0; pl < nplanes; ++pl) s += red[pl * p.Cq + c];
+            const int hd = c / p.Dh, d = c - hd * p.Dh;
+            p.k[b * p.ks[0] + hd * p.ks[1] + (int64_t)cy * p.ks[2] + (int64_t)cx * p.ks[3] + d] = (bf16_t)(s * invn);
+        }
+        return;
+    }
     // key = mean over the cell's planes; thread -> (cell of the workgroup, channel)
     for (int e = tid; e < cpw * p.Cq; e += 256) {
         const int cl = e / p.Cq, c = e - cl * p.Cq;
@@ -283,12 +294,18 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
     }
     p.ncells = (int32_t)ncell;
     const dim3 g((uint32_t)nb), blk(256);
+#define NAF_RP_LAUNCH(T, V)                                                                              \
+    do {                                                                                                   \
+        if (cpw > 1) hipLaunchKernelGGL((rope_pool_kernel<T, V, true>), g, blk, lds, s, p);                 \
+        else hipLaunchKernelGGL((rope_pool_kernel<T, V, false>), g, blk, lds, s, p);                        \
+    } while (0)
     if (a->x_dtype == NAF_BF16) {
-        if (vec) hipLaunchKernelGGL((rope_pool_kernel<bf16_t, 8>), g, blk, lds, s, p);
-        else hipLaunchKernelGGL((rope_pool_kernel<bf16_t, 1>), g, blk, lds, s, p);
+        if (vec) NAF_RP_LAUNCH(bf16_t, 8);
+        else NAF_RP_LAUNCH(bf16_t, 1);
     } else {
-        if (vec) hipLaunchKernelGGL((rope_pool_kernel<float, 8>), g, blk, lds, s, p);
-        else hipLaunchKernelGGL((rope_pool_kernel<float, 1>), g, blk, lds, s, p);
+        if (vec) NAF_RP_LAUNCH(float, 8);
+        else NAF_RP_LAUNCH(float, 1);
     }
+#undef NAF_RP_LAUNCH
     return naf_check_launch("rope_pool_kernel");
 }
