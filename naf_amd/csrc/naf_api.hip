@@ -157,7 +157,7 @@ int naf_xna_select(const naf_xna_args* a) {
     if (a->rope_tab_y != nullptr) {
         // rotate-on-load lives in the MFMA kernel's row-tile path only
         if (a->path == NAF_XNA_GENERIC || !ok || !naf_xna_mfma_rope_ok(a)) {
-            naf_set_error("naf_xna_select: rotate-on-load (rope_tab_*) needs the MFMA path with Wo/w %% 16 == 0 (got path %d, %dx%d -> %dx%d)",
+            naf_set_error("naf_xna_select: rotate-on-load (rope_tab_*) needs the MFMA path with row tiles (Wo/w a multiple of 16, or 14, 15, 28 ...; got path %d, %dx%d -> %dx%d)",
                           a->path, a->h, a->w, a->Ho, a->Wo);
             return -NAF_ERR_UNSUPPORTED;
         }

@@ -35,11 +35,11 @@ int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out) 
     return 1;
 }
 
-// Rotate-on-load (rope_tab_*) is implemented by the kernel's row-tile path: a 16-query tile must be 16 consecutive
-// pixels of one cell row (dx % 16 == 0, <= 1024 tiles per cell).
+// Rotate-on-load (rope_tab_*) is implemented by the kernel's row-tile path: a 16-query tile is (up to) 16 consecutive
+// pixels of one cell row (xna_row_tiles_ok(dx), <= 1024 tiles per cell).
 int naf_xna_mfma_rope_ok(const naf_xna_args* a) {
     const int dy = a->Ho / a->h, dx = a->Wo / a->w;
-    if (dx % 16 != 0 || (int64_t)dy * dx / 16 > 1024) return 0;
+    if (!xna_row_tiles_ok(dx) || (int64_t)dy * ((dx + 15) / 16) > 1024) return 0;
     return naf_xna_mfma_eligible(a, nullptr, nullptr);
 }
 
@@ -63,7 +63,7 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.dy = a->Ho / a->h; p.dx = a->Wo / a->w;
     p.tab_y = a->rope_tab_y; p.tab_x = a->rope_tab_x;
     if (a->rope_tab_y != nullptr && !naf_xna_mfma_rope_ok(a)) {
-        naf_set_error("naf_xna_fwd: rotate-on-load needs Wo/w %% 16 == 0 (got %dx%d -> %dx%d)", a->h, a->w, a->Ho, a->Wo);
+        naf_set_error("naf_xna_fwd: rotate-on-load needs row tiles (Wo/w a multiple of 16, or 14, 15, 28 ...: got %dx%d -> %dx%d)", a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;
     }
     XnaMfmaPlan pl;

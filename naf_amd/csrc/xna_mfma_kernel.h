@@ -71,6 +71,15 @@ constexpr size_t xna_mfma_lds_bytes() {
     return xna_mfma_lds_for(KS, CB, DVT, STG, NW);
 }
 
+// Row tiles: a 16-query tile is (up to) 16 consecutive pixels of ONE cell row -- all tile bookkeeping is wave-uniform and
+// rotate-on-load applies.  Exact for Wo/w a multiple of 16; for other widths the last tile of a row is partial (masked
+// lanes), taken while at most 1/7 of the lanes idle (14-pixel cells of patch-14 backbones, 15, 28, 30, 31 ...);
+// narrower cells pack their pixels across rows instead (generic tile loop).
+__host__ __device__ inline bool xna_row_tiles_ok(int dx) {
+    const int pad = ((dx + 15) & ~15) - dx;
+    return pad * 6 <= dx;
+}
+
 __device__ __forceinline__ void xna_store4(bf16_t* dst, f32x4_t v) {
     bf16x4_t o;
     o[0] = (bf16_t)v[0];
@@ -123,7 +132,9 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     const int x0 = min(max(cx0 - KS / 2, 0), p.w - KS);
 
     const int npix = p.dy * p.dx;
-    const int ntile = (npix + 15) >> 4;         // 16-query tiles per cell
+    const int tpr = max((p.dx + 15) >> 4, 1);   // row tiles per cell row
+    const bool fast = (CB == 1) && xna_row_tiles_ok(p.dx) && (p.dy * tpr <= 1024);
+    const int ntile = fast ? p.dy * tpr : (npix + 15) >> 4;   // 16-query tiles per cell
     const int ttot = ncy * ncx * ntile;         // tiles of the whole block
     const bf16_t* qbb = p.q + b * p.qs[0] + head * p.qs[1];
     OutT* obb = reinterpret_cast<OutT*>(p.out) + b * p.os[0] + head * p.os[1] + chunk * DVT;
@@ -140,16 +151,15 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
 
     // FAST path (see tile_loop): tiles per cell row, magic multiplier for t / tpr (exact for t, tpr <= 1024),
     // uniform cell origins, per-lane byte offset of this lane's query inside a tile
-    const bool fast = (CB == 1) && ((p.dx & 15) == 0) && (ntile <= 1024);
-    const int tpr = max(p.dx >> 4, 1);
     const uint32_t tmagic = (1u << 20) / (uint32_t)tpr + 1u;
     const bf16_t* q_cell = qbb + (int64_t)(cy0 * p.dy) * p.qs[2] + (int64_t)(cx0 * p.dx) * p.qs[3];
     OutT* o_cell = obb + (int64_t)(cy0 * p.dy) * p.os[2] + (int64_t)(cx0 * p.dx) * p.os[3];
-    const uint32_t q_lane = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u;
+    // (lanes past the end of a partial last tile of a row re-read its last pixel; their results are never stored)
     auto q_ptr_fast = [&](int tt) __attribute__((always_inline)) {
         const int ttc = min(tt, ttot - 1);
         const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
-        return reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(q_cell + (int64_t)ty * p.qs[2] + (int64_t)tx0 * p.qs[3]) + q_lane);
+        const uint32_t xl = (uint32_t)min(tx0 + col, p.dx - 1);
+        return reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(q_cell + (int64_t)ty * p.qs[2]) + (xl * (uint32_t)p.qs[3] + (uint32_t)grp * 8u) * 2u);
     };
 
     // first tile's queries: issued before the window staging so their HBM latency hides under it
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     bf16x8_t qf[TPW][2];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-        const bf16_t* qp = q_ptr(wave * TPW + u);
+        const bf16_t* qp = fast ? q_ptr_fast(wave * TPW + u) : q_ptr(wave * TPW + u);
         if (!(ABL & 4)) {
             qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
             qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
@@ -220,12 +230,13 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     // offset and its byte offset from the tile's first pixel are per-lane constants of the whole kernel
     constexpr int NCH = 16 * VCH;            // 16-byte chunks in a tile
     constexpr int NIT = STG ? (NCH + 63) / 64 : 1;
-    int st_lds[NIT];
+    int st_lds[NIT], st_pp[NIT];
     uint32_t st_goff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = min(it * 64 + lane, NCH - 1);
         const int pp = i / VCH, ch = i - pp * VCH;
+        st_pp[it] = pp;
         st_lds[it] = pp * OROW + ch * 8;
         st_goff[it] = (uint32_t)(pp * (int)p.os[3] + ch * 8) * (uint32_t)sizeof(OutT);
     }
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const int ttc = min(tt, ttot - 1);
         const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
         // straight from the tables (128 KB each, L1/L2-resident): an LDS copy would cost the third resident workgroup
-        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx0 * p.dx + tx0 + col) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
+        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx0 * p.dx + min(tx0 + col, p.dx - 1)) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
         cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
         cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
         cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
@@ -333,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                         const int tx0 = ((tb + u < ttot ? tb + u : ttot - 1) - ty * tpr) * 16;
                         Y = cy0 * p.dy + ty;
                         X = cx0 * p.dx + tx0 + col;
+                        ok = ok && (tx0 + col < p.dx);
                     } else {
                         const int ps = tv[u] * 16 + col;
                         ok = ok && ps < npix;
@@ -412,6 +424,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             OutT* obv[TPW];      // cell origin (generic) / tile origin (FAST)
             OutT* opv[TPW];      // this lane's pixel (unstaged stores)
             bool pvalidv[TPW];
+            int tx0v[TPW];       // FAST: first pixel of the tile inside its cell row
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 if constexpr (FAST) {
@@ -419,7 +432,8 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
                     obv[u] = o_cell + (int64_t)ty * p.os[2] + (int64_t)tx0 * p.os[3];
                     opv[u] = reinterpret_cast<OutT*>(reinterpret_cast<char*>(obv[u]) + o_lane);
-                    pvalidv[u] = (tb + u < ttot);
+                    pvalidv[u] = (tb + u < ttot) && (tx0 + col < p.dx);
+                    tx0v[u] = tx0;
                 } else {
                     const int ps = tv[u] * 16 + col;
                     pvalidv[u] = (ps < npix) && (tb + u < ttot);
@@ -427,6 +441,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     const int py = psc / p.dx, px = psc - py * p.dx;
                     obv[u] = obb + (int64_t)(cyv[u] * p.dy) * p.os[2] + (int64_t)(cxv[u] * p.dx) * p.os[3];
                     opv[u] = obv[u] + py * p.os[2] + px * p.os[3];
+                    tx0v[u] = 0;
                 }
             }
             // one 16-channel tile of every query tile: V^T fragments are read once and feed TPW MFMAs
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                         if (ABL & 1) {
                             asm volatile("" ::"v"(wv));
                         } else if constexpr (FAST) {
-                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv;
+                            if (tx0v[0] + st_pp[it] < p.dx) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv;
                         } else {
                             const int pp = (it * 64 + lane) / VCH, ch = (it * 64 + lane) - pp * VCH;
                             const int sp = min(t0 + pp, npix - 1);

@@ -265,6 +265,10 @@ MFMA_CASES = [
     (1, 16, 17, 4, 4, 15, 1024, 4),       # kernel 15 with Dv = 256 (Dv tiles of 128)
     (1, 14, 13, 2, 8, 13, 192, 4),        # kernel 13
     (3, 5, 6, 5, 7, 3, 512, 4),           # odd cell shape 5x7, batch 3
+    (1, 6, 7, 14, 14, 5, 192, 4),         # patch-14 cells: row tiles with a partial (14 of 16) tile per row, staged stores
+    (1, 5, 5, 3, 30, 3, 256, 4),          # 30-pixel rows: a full and a 14-pixel tile per row
+    (1, 9, 9, 7, 15, 9, 1024, 4),         # 15-pixel rows, Dv = 256 (unstaged stores)
+    (1, 7, 8, 14, 28, 7, 128, 4),         # 14 x 28 cells
 ]
 
 
@@ -604,6 +608,8 @@ def test_golden_F7_preshrink_and_pool(dev, golden_dir):
     (1, 64, (8, 8), (128, 128), 7, torch.bfloat16),        # d = 16: one row tile per cell row
     (2, 128, (6, 5), (192, 160), 5, torch.float32),        # d = 32: two tiles per cell row, non-square grid
     (1, 64, (12, 12), (96, 192), 3, torch.bfloat16),       # dy = 8, dx = 16
+    (1, 192, (6, 7), (84, 98), 5, torch.bfloat16),         # patch 14: partial row tiles (14 of 16 lanes)
+    (1, 64, (5, 5), (35, 150), 3, torch.float32),          # dx = 30: a full and a 14-pixel tile per row
 ])
 def test_rotate_on_load_equals_materialised_queries(dev, B, C, lr, out_sz, ksz, out_dtype):
     """naf_xna_fwd(rope_tab_*) on un-rotated guidance == naf_rope_pool_fwd queries + plain naf_xna_fwd, bit for
