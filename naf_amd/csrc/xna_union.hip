@@ -102,7 +102,8 @@ UnionPlan make_plan(int Ho, int h, int Wo, int w, int k, int Dv, int64_t groups)
     return best;
 }
 
-const UnionPlan& plan_for(const naf_xna_args* a) {
+// (returned by value: another thread may evict the cache entry)
+UnionPlan plan_for(const naf_xna_args* a) {
     using Key = std::tuple<int, int, int, int, int, int, int64_t>;
     static std::mutex mu;
     static std::map<Key, UnionPlan> cache;
@@ -145,7 +146,7 @@ int naf_launch_xna_union(const naf_xna_args* a, float scale, hipStream_t s) {
         naf_set_error("naf_xna_fwd: the table-driven MFMA path needs idx_y / idx_x from naf_axis_index_table");
         return NAF_ERR_INVALID;
     }
-    const UnionPlan& pl = plan_for(a);
+    const UnionPlan pl = plan_for(a);
     XnaUnionParams p;
     p.q = static_cast<const bf16_t*>(a->q);
     p.k = static_cast<const bf16_t*>(a->k_lr);
@@ -185,7 +186,7 @@ int naf_launch_xna_union(const naf_xna_args* a, float scale, hipStream_t s) {
 // plan of the request, for tools and tests: {wt, ry, seg, hub, wub, dvt, lds}; returns 1 when eligible
 extern "C" int naf_xna_union_plan(const naf_xna_args* a, int32_t out[7]) {
     if (a == nullptr || out == nullptr || !naf_xna_union_eligible(a)) return 0;
-    const UnionPlan& pl = plan_for(a);
+    const UnionPlan pl = plan_for(a);
     out[0] = pl.wt; out[1] = pl.ry; out[2] = pl.seg; out[3] = pl.hub; out[4] = pl.wub; out[5] = pl.dvt; out[6] = (int32_t)pl.lds;
     return 1;
 }
