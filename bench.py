@@ -217,7 +217,11 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "xna_mfma_kernel",
-                    "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg}
+                    "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
+                    # the same kernel against the matrix pipe (large windows approach the MFMA ridge):
+                    # 2 * k^2 * (256 + C) FLOP per output pixel, dense bf16 MFMA peak 2.5 PFLOP/s
+                    "mfma_tflops": round(2.0 * ksz * ksz * (256 + C) * B * out * out / (xna_ms * 1e-3) / 1e12, 1),
+                    "mfma_frac": round(2.0 * ksz * ksz * (256 + C) * B * out * out / (xna_ms * 1e-3) / 2.5e15, 4)}
         line = {
             "metric": "upsampled Mpixels/sec (NAF forward)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
