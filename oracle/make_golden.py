@@ -198,6 +198,16 @@ for tag, hw, lr9, C9, iseed in (("a", (64, 64), (28, 28), 64, 901), ("b", (100, 
     f9[f"{tag}_shape"] = np.array([*hw, *lr9, C9, iseed])
 save("F9_noninteger_ratio", param_seed=9, k=9, **f9)
 
+# ---- F10: patch-14 geometry end to end (DINOv2-style backbones, vit_wrapper.py:19-21: 14-pixel cells) -------------
+p10 = O.make_params(dim=256, heads_rope=4, seed=10)
+m10 = ref_model(p10, kernel_size=5)
+img10 = O.hash_normal((1, 3, 140, 168), seed=1001)
+ft10 = O.hash_normal((1, 64, 10, 12), seed=1002)
+o_ref = m10(img10, ft10, (140, 168))
+report["F10 patch-14 cells"] = maxdiff(o_ref, O.naf_forward(p10, img10, ft10, (140, 168), kernel_size=5))
+save("F10_patch14", param_seed=10, image_seed=1001, feat_seed=1002, k=5, shape=[140, 168, 10, 12, 64],
+     sample=o_ref[:, ::2, ::3, 1::3].contiguous())   # every 2nd channel, 3rd row, 3rd column
+
 print("\noracle vs imported reference (max abs diff, fp32):")
 worst = 0.0
 for k_, v_ in report.items():
@@ -211,4 +221,4 @@ with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
     f.write("oracle/naf_oracle.py vs imported reference + natten shim (max abs diff, fp32)\n")
     for k_, v_ in report.items():
         f.write(f"{k_:28s} {v_:.3e}\n")
-print("OK: oracle pinned to the imported reference (<= 1e-5) on F1-F9")
+print("OK: oracle pinned to the imported reference (<= 1e-5) on F1-F10")

@@ -580,6 +580,28 @@ def test_golden_F9_noninteger_ratio(dev, golden_dir, tag):
     assert _forward_stats(got, ref)[1] <= 6e-3
 
 
+@pytest.mark.parametrize("feat_dtype", [torch.float32, torch.bfloat16])
+def test_golden_F10_patch14(dev, golden_dir, feat_dtype):
+    """14-pixel cells (patch-14 backbones) end to end against the REFERENCE's output: the cell kernel's row tiles with a
+    partial last tile, queries rotated on load."""
+    from naf_amd import ops
+    g = _g(golden_dir, "F10_patch14")
+    p = O.make_params(seed=int(g["param_seed"]))
+    m = _load_model(dev, p, kernel_size=int(g["k"]))
+    H, W, h, w, C = (int(v) for v in g["shape"])
+    img = O.hash_normal((1, 3, H, W), int(g["image_seed"])).to(dev)
+    ft = O.hash_normal((1, C, h, w), int(g["feat_seed"])).to(dev).to(feat_dtype)
+    plan = m._forward_plan(img, ft, (H, W))
+    assert plan is not None
+    q_raw = torch.empty(1, 4, H, W, 64, dtype=torch.bfloat16, device=dev)
+    assert ops.xna_rope_fusable(q_raw, (h, w), C // 4, int(g["k"]), m.image_encoder.rope.tables(H, W))
+    out = m(img, ft, (H, W)).float().cpu()
+    got, ref = out[:, ::2, ::3, 1::3], torch.from_numpy(g["sample"])
+    tol = 1.0 if feat_dtype == torch.float32 else 1.35
+    assert_close(got, ref, 6e-2 * tol, 3e-2 * tol, "F10 strided sample vs reference")
+    assert _forward_stats(got, ref)[1] <= 6e-3 * tol
+
+
 def test_golden_F6_denoise_like(dev, golden_dir):
     g = _g(golden_dir, "F6_denoise_d1")
     p = O.make_params(dim=int(g["dim"]), heads_rope=1, seed=int(g["param_seed"]))

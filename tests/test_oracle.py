@@ -74,6 +74,15 @@ def test_golden_F9_noninteger_ratio(golden_dir):
         assert np.abs(got.numpy() - g[f"{tag}_sample"]).max() <= TOL
 
 
+def test_golden_F10_patch14(golden_dir):
+    g = _load(golden_dir, "F10_patch14")
+    p = O.make_params(seed=int(g["param_seed"]))
+    H, W, h, w, C = (int(v) for v in g["shape"])
+    out = O.naf_forward(p, O.hash_normal((1, 3, H, W), int(g["image_seed"])), O.hash_normal((1, C, h, w), int(g["feat_seed"])),
+                        (H, W), kernel_size=int(g["k"]))
+    assert np.abs(out[:, ::2, ::3, 1::3].numpy() - g["sample"]).max() <= TOL
+
+
 def test_golden_F5_full_P1(golden_dir):
     """BASELINE configs[0]: 1x3x224x224 image, 1x384x14x14 features -> 224x224, window 7."""
     g = _load(golden_dir, "F5_full_P1")
