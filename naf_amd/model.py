@@ -116,9 +116,10 @@ class _GroupNormTrain(torch.autograd.Function):
         x, mean, rstd, weight = ctx.saved_tensors
         B, C, H, W = x.shape
         # ATen's kernel indexes dense NCHW memory (autograd hands it grad.contiguous() as well)
-        dx, dw, db = torch.ops.aten.native_group_norm_backward(dy.contiguous(), x.contiguous(), mean, rstd, weight, B, C, H * W,
-                                                               ctx.groups, [True, True, True])
-        return dx.contiguous(memory_format=torch.channels_last), dw, db, None, None
+        # (and one dtype: under autocast x / dy arrive in bf16 while the statistics and the affine parameters are fp32)
+        dx, dw, db = torch.ops.aten.native_group_norm_backward(dy.float().contiguous(), x.float().contiguous(), mean, rstd,
+                                                               weight.float(), B, C, H * W, ctx.groups, [True, True, True])
+        return dx.to(x.dtype).contiguous(memory_format=torch.channels_last), dw.to(weight.dtype), db.to(weight.dtype), None, None
 
 
 class _ReflectPad(torch.autograd.Function):
@@ -439,13 +440,15 @@ class NAF(nn.Module):
         """Capture this forward for the given shapes in a hipGraph; see ``GraphedForward``."""
         return GraphedForward(self, image, features, output_size)
 
-    def forward_train(self, image, features, output_size):
+    def forward_train(self, image, features, output_size, amp=False):
         """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
         and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
         differentiate them (the fused inference stem has no backward).  Deterministic eval-mode RoPE coordinates
         (the reference's train-time coordinate jitter, rope.py:107-124, is not implemented).  Needs the shapes
-        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9)."""
+        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9).
+        ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
+        mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32."""
         if not (image.is_cuda and features.is_cuda):
             raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback)")
         enc = self.image_encoder
@@ -458,7 +461,9 @@ class NAF(nn.Module):
                               mode="bilinear", align_corners=False)
         if enc.use_encoder:
             x = x.float().contiguous(memory_format=torch.channels_last)
-            x = torch.cat([enc._branch_train(x, enc.encoder), enc._branch_train(x, enc.sem_encoder)], dim=1)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(amp)):
+                x = torch.cat([enc._branch_train(x, enc.encoder), enc._branch_train(x, enc.sem_encoder)], dim=1)
+            x = x.float()
         if x.shape[-2:] != (ho, wo):
             x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column

@@ -813,6 +813,30 @@ def test_forward_train_gradients_match_oracle(dev):
     assert float((fd.grad.float().cpu() - fo.grad).abs().max()) <= 3e-2 * gs + 1e-3
 
 
+def test_forward_train_amp_tracks_the_fp32_path(dev):
+    """forward_train(amp=True) = the reference's use_bf16 mode (train.py:120): bf16 stem convolutions under autocast.
+    Output and gradients stay within bf16-level distance of the fp32 training path."""
+    p = O.make_params(seed=23)
+    img = O.hash_normal((1, 3, 64, 64), 531).to(dev)
+    ft0 = O.hash_normal((1, 128, 4, 4), 532).to(dev)
+    wgt = O.hash_normal((1, 128, 64, 64), 533).to(dev)
+    grads, outs = [], []
+    for amp in (False, True):
+        m = _load_model(dev, p, kernel_size=3)
+        for prm in m.parameters():
+            prm.requires_grad_(True)
+        fd = ft0.clone().requires_grad_(True)
+        out = m.forward_train(img, fd, (64, 64), amp=amp)
+        (out.float() * wgt).sum().backward()
+        outs.append(out.float())
+        grads.append({n: q.grad.float() for n, q in m.named_parameters() if q.grad is not None} | {"features": fd.grad.float()})
+    assert_close(outs[1].cpu(), outs[0].cpu(), 8e-2, 4e-2, "amp output")
+    for n, g0 in grads[0].items():
+        scale = float(g0.abs().max())
+        err = float((grads[1][n] - g0).abs().max())
+        assert err <= 0.12 * scale + 1e-3, f"{n}: amp grad err {err:.3e} vs max {scale:.3e}"
+
+
 @pytest.mark.parametrize("shape,fmt", [((1, 3, 40, 56), "f32"), ((2, 3, 33, 47), "bf16_strided")])
 def test_first_1x1_layer_recomputes_conv0_bit_exactly(dev, shape, fmt):
     """naf_stem_conv_fwd(first = conv0 args) == naf_stem_conv0_fwd + naf_stem_conv_fwd, bit for bit, and the

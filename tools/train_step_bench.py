@@ -13,9 +13,11 @@ img = torch.randn(1, 3, 448, 448, device=dev)
 ft = torch.randn(1, 384, 28, 28, device=dev)
 tgt = torch.randn(1, 384, 448, 448, device=dev)
 
+AMP = "--amp" in sys.argv
+
 def step():
     opt.zero_grad(set_to_none=True)
-    out = m.forward_train(img, ft, (448, 448))
+    out = m.forward_train(img, ft, (448, 448), amp=AMP)
     loss = (out.float() - tgt).pow(2).mean()
     loss.backward()
     opt.step()
@@ -29,5 +31,5 @@ e0.record()
 n = 10
 for _ in range(n): l = step()
 e1.record(); torch.cuda.synchronize()
-print("fwd+bwd+SGD step: %.2f ms   peak memory %.0f MB   (reference, A100-40GB: 163.08 ms, 6016.5 MB)   loss %.4f"
+print(("amp (bf16 stem convs) " if AMP else "") + "fwd+bwd+SGD step: %.2f ms   peak memory %.0f MB   (reference, A100-40GB: 163.08 ms, 6016.5 MB)   loss %.4f"
       % (e0.elapsed_time(e1) / n, torch.cuda.max_memory_allocated() / 2**20, float(l)))
