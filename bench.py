@@ -133,13 +133,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the NAF hot path has no CPU implementation)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NAF_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives go through gloo) -- for testing this script only, never for reported numbers
+    backend = os.environ.get("NAF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from naf_amd import NAF, ops
     from naf_amd import dist as nd
@@ -228,7 +235,8 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(value / PUBLISHED_MPIX[args.workload], 2) if (args.workload in PUBLISHED_MPIX and world == 1 and B == 1
                                                                                   and not args.attention_only) else None),
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16",
+            "data": "synthetic" if backend == "nccl" else f"synthetic (DRY RUN over {backend}, ranks share GPUs: not a measurement)",
             "config": {"workload": f"{args.workload}: {B}x3x{out}x{out} guidance, {B}x{C}x{lr}x{lr} features -> "
                                    f"{out}x{out}, window {ksz}, per GPU", "per_gpu_batch": B, "parallelism": f"batch-shard x{world}",
                        "scope": ("attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)")
