@@ -79,8 +79,9 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  * naf_stem_conv0_fwd : Conv2d(3 -> 128, ksize 1 or 3, reflect) + bias         (convolutions.py:68-75)
  *   image device [B, 3, H, W] f32/bf16, element strides {b, c, y, x}; weight device f32 [128][3][k][k]
  *   (the module's own parameter), bias f32 [128]; y device bf16, strides {b, y, x}, 128 ch contiguous;
- *   stats_out accumulates sum / sum^2 of y per GroupNorm group.  y may be NULL: statistics only (for
- *   naf_stem_conv_args.first below).
+ *   stats_out accumulates sum / sum^2 of y per GroupNorm group (zeroed by the caller).  y may be NULL: statistics only
+ *   (for naf_stem_conv_args.first below); with ksize 1 they are then computed from the image's first and second
+ *   moments (y is linear in the image), which agrees with the sums of the stored pass to ~1e-7 relative.
  * naf_stem_conv_fwd  : GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, ksize 1 or 3, reflect) + bias
  *   (one norm/act/conv triple of EncBlock.forward, convolutions.py:52-61).  x device bf16 with its
  *   stats_in; gn_weight/gn_bias f32 [128]; w_packed device bf16 [k*k][128 oc][128 ic]
@@ -88,8 +89,8 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   `first` (optional, ksize 1 only): the layer is the FIRST residual-block convolution of the 1x1 branch and
  *   recomputes its input bf16(conv0(image)) from `first` (image, weight, bias of the 1x1 conv0; first->y and
  *   first->stats_out are ignored) instead of reading x, so that the conv0 activation never exists in memory;
- *   stats_in then are the sums a naf_stem_conv0_fwd(y = NULL) call produced.  Results are bit-identical to
- *   the two-call sequence. */
+ *   stats_in then are the sums a naf_stem_conv0_fwd(y = NULL) call produced.  Given the same stats_in the results
+ *   are bit-identical to the two-call sequence. */
 typedef struct naf_stem_conv0_args {
     const void* image;
     void* y;

@@ -236,6 +236,61 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
     }
 }
 
+// ---- statistics of the 1x1 layer without running it -------------------------------------------------------------
+// y = W x + b is linear in the 3-channel image, so the GroupNorm sums of y follow from the image's first and second
+// moments: sum_px y_c = W_c . S1 + N b_c,  sum_px y_c^2 = W_c^T S2 W_c + 2 b_c W_c . S1 + N b_c^2  with S1 = sum_px x,
+// S2 = sum_px x x^T (9 numbers per image, fp64).  Replaces the statistics-only MFMA pass over the image (0.037-0.042 ms
+// at 1024^2: one segment of matrix work and epilogue per 32 pixels just to add up its outputs) by one read of the
+// 12 MB image.  The 9 moments are accumulated in the caller's (zeroed) stats slots, which the second kernel then
+// overwrites with the 16 group sums.
+template <typename T>
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict__ img, int64_t ibs, int is1, int is2, int is3, int H, int W,
+                                                            double* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const T* ib = img + (int64_t)b * ibs;
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // S1[0..2], S2: 00 01 02 11 12 22
+    const int64_t npx = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const int o = y * is2 + x * is3;
+        const double c0 = (double)(float)ib[o], c1 = (double)(float)ib[o + is1], c2 = (double)(float)ib[o + 2 * is1];
+        m[0] += c0; m[1] += c1; m[2] += c2;
+        m[3] += c0 * c0; m[4] += c0 * c1; m[5] += c0 * c2; m[6] += c1 * c1; m[7] += c1 * c2; m[8] += c2 * c2;
+    }
+    __shared__ double red[4][9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double v = m[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) atomicAdd(&stats[b * 16 + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                double npx) {
+    const int b = blockIdx.x, c = threadIdx.x;   // one thread per output channel
+    double m[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m[j] = stats[b * 16 + j];
+    __syncthreads();                              // every thread has read the moments before the slots are overwritten
+    const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], bc = bias[c];
+    const double ws1 = w0 * m[0] + w1 * m[1] + w2 * m[2];
+    double s1 = ws1 + npx * bc;
+    double s2 = w0 * w0 * m[3] + w1 * w1 * m[6] + w2 * w2 * m[8] + 2.0 * (w0 * w1 * m[4] + w0 * w2 * m[5] + w1 * w2 * m[7]) + 2.0 * bc * ws1 + npx * bc * bc;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {             // 16 channels of a GroupNorm group = 16 consecutive lanes
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((c & 15) == 0) {
+        stats[(b * 8 + (c >> 4)) * 2 + 0] = s1;
+        stats[(b * 8 + (c >> 4)) * 2 + 1] = s2;
+    }
+}
+
 int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     StemConv0Params p;
     p.img = a->image;
@@ -250,6 +305,21 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     if (ng > 0x7fffffffLL || span >= 0x7fffffffLL || a->B > 65535) {
         naf_set_error("naf_stem_conv0_fwd: image too large for 32-bit tap offsets (span %lld elements, batch %d)", (long long)span, a->B);
         return NAF_ERR_UNSUPPORTED;
+    }
+    if (a->y == nullptr && a->ksize == 1) {   // statistics of the 1x1 layer: from the image's moments, no matrix work
+        const int64_t npx = (int64_t)a->H * a->W;
+        int nb = (int)((npx + 256 * 8 - 1) / (256 * 8));
+        const int cap = naf_cu_count() * 4;
+        nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+        const dim3 g((uint32_t)nb, (uint32_t)a->B), blk(256);
+        if (a->image_dtype == NAF_BF16)
+            hipLaunchKernelGGL(conv0_moments_kernel<bf16_t>, g, blk, 0, s, static_cast<const bf16_t*>(a->image), a->image_stride[0],
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out);
+        else
+            hipLaunchKernelGGL(conv0_moments_kernel<float>, g, blk, 0, s, static_cast<const float*>(a->image), a->image_stride[0],
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out);
+        hipLaunchKernelGGL(conv0_moment_sums_kernel, dim3((uint32_t)a->B), dim3(128), 0, s, a->stats_out, a->weight, a->bias, (double)npx);
+        return naf_check_launch("conv0_moments_kernel");
     }
     p.ngroups = (int32_t)ng;
     p.ibs = a->image_stride[0];

@@ -855,13 +855,16 @@ def test_first_1x1_layer_recomputes_conv0_bit_exactly(dev, shape, fmt):
     x0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
     st = torch.zeros((4, B, 8, 2), dtype=torch.float64, device=dev)
     ops.stem_conv0(img, w0, b0, x0, st[0])
-    ops.stem_conv0(img, w0, b0, None, st[1])
-    assert torch.equal(st[0], st[1])
+    ops.stem_conv0(img, w0, b0, None, st[1])        # statistics only: from the image's moments (fp64), no matrix work
+    assert torch.allclose(st[0], st[1], rtol=2e-6, atol=1e-3), float((st[0] - st[1]).abs().max())
     ya, yb = torch.empty_like(x0), torch.empty_like(x0)
     ops.stem_conv(x0, st[0], gw, gb, 1e-5, wp, cb, ya, st[2])
-    ops.stem_conv(None, st[1], gw, gb, 1e-5, wp, cb, yb, st[3], first=(img, w0, b0))
+    ops.stem_conv(None, st[0], gw, gb, 1e-5, wp, cb, yb, st[3], first=(img, w0, b0))     # same statistics: same bits
     assert torch.equal(ya, yb), float((ya.float() - yb.float()).abs().max())
     assert torch.allclose(st[2], st[3], rtol=1e-12, atol=1e-9)
+    yc = torch.empty_like(x0)
+    ops.stem_conv(None, st[1], gw, gb, 1e-5, wp, cb, yc, torch.zeros_like(st[3]), first=(img, w0, b0))
+    assert float((ya.float() - yc.float()).abs().max()) <= 2.0 ** -6     # moments-based statistics: at most a bf16 ulp apart
 
 
 def test_heads_rope_differs_from_heads_attn(dev):
