@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict_
     const T* ib = img + (int64_t)b * ibs;
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // S1[0..2], S2: 00 01 02 11 12 22
     const int64_t npx = (int64_t)H * W;
+#pragma unroll 4
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
         const int o = y * is2 + x * is3;
@@ -308,8 +309,8 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     }
     if (a->y == nullptr && a->ksize == 1) {   // statistics of the 1x1 layer: from the image's moments, no matrix work
         const int64_t npx = (int64_t)a->H * a->W;
-        int nb = (int)((npx + 256 * 8 - 1) / (256 * 8));
-        const int cap = naf_cu_count() * 4;
+        int nb = (int)((npx + 256 * 16 - 1) / (256 * 16));   // few workgroups: 9 fp64 atomics each land on the same 9 addresses
+        const int cap = naf_cu_count();
         nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
         const dim3 g((uint32_t)nb, (uint32_t)a->B), blk(256);
         if (a->image_dtype == NAF_BF16)
