@@ -154,6 +154,13 @@ typedef struct naf_rope_pool_args {
 } naf_rope_pool_args;
 int naf_rope_pool_fwd(const naf_rope_pool_args* a, naf_stream_t stream);
 
+/* ---- guidance pooling ---------------------------------------------------------------------------------
+ * Replaces F.adaptive_avg_pool2d(x, output_size) of ImageEncoder.encode (naf.py:34) when the image is larger than the
+ * output: x device bf16 dense channels-last [B, H, W, C] -> y device bf16 dense channels-last [B, Ho, Wo, C],
+ * C % 8 == 0, both 16-byte aligned; windows [floor(i*H/Ho), ceil((i+1)*H/Ho)) like torch, fp32 accumulation. */
+int naf_pool_guidance(void* y, const void* x, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C,
+                      naf_stream_t stream);
+
 /* ---- value packing --------------------------------------------------------------------------------
  * Replaces the rearrange + dtype cast of the value tensor in CrossAttention._resize
  * (attentions.py:50-51) WITHOUT the nearest-exact upsampling (values stay low-res).
@@ -255,7 +262,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------
  * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
- * encoder branches with img_layers blocks, RoPE heads = attention heads, image size == output size): every launch
+ * encoder branches with img_layers blocks, RoPE heads = attention heads, image at most 4x the output size): every launch
  * of the path above -- conv stem, key pooling, value packing, attention -- is issued from one host call on the
  * caller's stream, so a C/C++ host needs nothing else and a Python host pays one foreign call per forward instead
  * of fourteen.  Any geometry naf_xna_fwd accepts is served: with an integer ratio and Wo/w a multiple of 16 the
@@ -264,16 +271,17 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  * naf_axis_index_table_device.  The call is capturable in a hipGraph (no host-side copies, no allocation).
  *   image     device [B, 3, H, W] f32/bf16, strides {b, c, y, x}
  *   features  device [B, C, h, w] f32/bf16, strides {b, c, y, x}
- *   out       device out_dtype, dense channels-last [B, H, W, C] (logical [B, C, H, W] view for the caller)
+ *   out       device out_dtype, dense channels-last [B, Ho, Wo, C] (logical [B, C, Ho, Wo] view for the caller)
  *   branch[i] parameters of encoder / sem_encoder (naf.py:26-27): conv0 weight f32 [128][3][k0][k0] + bias, then
  *             per block layer l < nlayer: GroupNorm weight / bias f32 [128], conv weight packed bf16
  *             [k*k][128][128] (= weight.permute(2,3,0,1)) and bias f32 [128]
- *   tab_y / tab_x  RoPE tables from naf_rope_tables for (H, W)
+ *   tab_y / tab_x  RoPE tables from naf_rope_tables for the OUTPUT size (Ho, Wo)
  *   workspace device scratch of naf_forward_workspace_bytes() bytes (activations, GroupNorm sums, keys, packed
  *             values, queries / index tables where needed); the library still owns no memory
  *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
- * Configurations outside the list (other widths, return_weights, image size != output size) return
+ * Configurations outside the list (other widths, return_weights, images more than 4x the output: naf.py:39-48's
+ * bilinear pre-shrink is the caller's) return
  * NAF_ERR_UNSUPPORTED: compose the individual entry points instead. */
 #define NAF_MAX_STEM_LAYERS 8
 typedef struct naf_stem_branch {
@@ -299,6 +307,7 @@ typedef struct naf_forward_args {
     int32_t nlayer; /* GroupNorm/SiLU/conv layers per branch = 2 * img_layers */
     int32_t image_dtype, feat_dtype, out_dtype; /* naf_dtype */
     int32_t B, H, W, h, w, C, heads, ksize;
+    int32_t Ho, Wo; /* output size; 0 = the image size.  Smaller than the image: the guidance is pooled (naf.py:34) */
     float gn_eps;
     float scale; /* <= 0: Dq^-0.5 */
     int64_t image_stride[4];

@@ -90,7 +90,7 @@ class ForwardArgs(C.Structure):
         ("branch", StemBranch * 2),
         ("nlayer", C.c_int32), ("image_dtype", C.c_int32), ("feat_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("C", C.c_int32),
-        ("heads", C.c_int32), ("ksize", C.c_int32), ("gn_eps", C.c_float), ("scale", C.c_float),
+        ("heads", C.c_int32), ("ksize", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("gn_eps", C.c_float), ("scale", C.c_float),
         ("image_stride", I64x4), ("feat_stride", I64x4),
     ]
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_rope_pool_fwd": (C.c_int, [C.POINTER(RopePoolArgs), C.c_void_p]),
+    "naf_pool_guidance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_pack_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int64), C.c_void_p]),
     "naf_xna_select": (C.c_int, [C.POINTER(XnaArgs)]),

@@ -98,6 +98,13 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int naf_pool_guidance(void* y, const void* x, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C, naf_stream_t stream) {
+    NAF_REQUIRE(x && y, "naf_pool_guidance: NULL pointer");
+    NAF_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0, "naf_pool_guidance: non-positive size");
+    NAF_REQUIRE(C % 8 == 0 && al16(x) && al16(y), "naf_pool_guidance: needs C %% 8 == 0 and 16-byte aligned buffers (C=%d)", C);
+    return naf_launch_pool_guidance(y, x, B, H, W, Ho, Wo, C, static_cast<hipStream_t>(stream));
+}
+
 int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_conv0_fwd: args is NULL");
     NAF_REQUIRE(a->image && a->weight && a->bias && a->stats_out, "naf_stem_conv0_fwd: NULL pointer");   // y may be NULL: statistics only
@@ -242,8 +249,10 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
 // ---- whole forward in one call ---------------------------------------------------------------------------
 namespace {
 struct FwdLayout {
-    size_t stats, buf0, buf1, cat, keys, vp, q, idx_y, idx_x, total;
+    size_t stats, buf0, buf1, cat, guide, keys, vp, q, idx_y, idx_x, total;
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
+    bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
+    int Ho, Wo;   // output size
 };
 bool fwd_rope_fusable(const naf_forward_args* a);
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -255,12 +264,18 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.cat = off;   off = align256(off + px * 256 * 2);
+    L.Ho = a->Ho > 0 ? a->Ho : a->H;
+    L.Wo = a->Wo > 0 ? a->Wo : a->W;
+    L.pooled = L.Ho != a->H || L.Wo != a->W;
+    const size_t opx = (size_t)a->B * L.Ho * L.Wo;
+    L.guide = L.pooled ? off : L.cat;
+    if (L.pooled) off = align256(off + opx * 256 * 2);
     L.keys = off;  off = align256(off + (size_t)a->B * a->h * a->w * 256 * 2);
     L.vp = off;    off = align256(off + (size_t)a->B * a->h * a->w * a->C * 2);
     L.fused = fwd_rope_fusable(a);
-    L.q = off;     off = align256(off + (L.fused ? 0 : px * 256 * 2));
-    L.idx_y = off; off = align256(off + (size_t)a->H * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
-    L.idx_x = off; off = align256(off + (size_t)a->W * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
+    L.q = off;     off = align256(off + (L.fused ? 0 : opx * 256 * 2));
+    L.idx_y = off; off = align256(off + (size_t)L.Ho * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
+    L.idx_x = off; off = align256(off + (size_t)L.Wo * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
     L.total = off;
     return L;
 }
@@ -287,7 +302,8 @@ void fwd_xna_args(const naf_forward_args* a, const FwdLayout* L, bool fused, naf
     const void* fake = reinterpret_cast<const void*>(0x100);
     const int Dv = a->C / a->heads;
     *x = naf_xna_args{};
-    x->q = real ? ws + (fused ? L->cat : L->q) : fake;
+    const int Ho = a->Ho > 0 ? a->Ho : a->H, Wo = a->Wo > 0 ? a->Wo : a->W;
+    x->q = real ? ws + (fused ? L->guide : L->q) : fake;
     x->k_lr = real ? ws + L->keys : fake;
     x->v_lr = real ? ws + L->vp : fake;
     x->out = a->out;
@@ -299,14 +315,14 @@ void fwd_xna_args(const naf_forward_args* a, const FwdLayout* L, bool fused, naf
         x->idx_y = real ? reinterpret_cast<const int32_t*>(ws + L->idx_y) : static_cast<const int32_t*>(fake);
         x->idx_x = real ? reinterpret_cast<const int32_t*>(ws + L->idx_x) : static_cast<const int32_t*>(fake);
     }
-    x->B = a->B; x->heads = a->heads; x->Ho = a->H; x->Wo = a->W; x->h = a->h; x->w = a->w;
+    x->B = a->B; x->heads = a->heads; x->Ho = Ho; x->Wo = Wo; x->h = a->h; x->w = a->w;
     x->Dq = 256 / a->heads; x->Dv = Dv; x->ky = a->ksize; x->kx = a->ksize;
     x->out_dtype = a->out_dtype; x->scale = a->scale;
     const int64_t Dq = x->Dq;
-    const int64_t qs[4] = {(int64_t)a->H * a->W * 256, Dq, (int64_t)a->W * 256, 256};
+    const int64_t qs[4] = {(int64_t)Ho * Wo * 256, Dq, (int64_t)Wo * 256, 256};
     const int64_t ks[4] = {(int64_t)a->h * a->w * 256, Dq, (int64_t)a->w * 256, 256};
     const int64_t vs[4] = {(int64_t)a->h * a->w * a->C, Dv, (int64_t)a->w * a->C, a->C};
-    const int64_t os[4] = {(int64_t)a->H * a->W * a->C, Dv, (int64_t)a->W * a->C, a->C};
+    const int64_t os[4] = {(int64_t)Ho * Wo * a->C, Dv, (int64_t)Wo * a->C, a->C};
     for (int i = 0; i < 4; ++i) { x->q_stride[i] = qs[i]; x->k_stride[i] = ks[i]; x->v_stride[i] = vs[i]; x->o_stride[i] = os[i]; }
 }
 bool fwd_rope_fusable(const naf_forward_args* a) {
@@ -330,7 +346,9 @@ int naf_forward_supported(const naf_forward_args* a) {
     const int rc = fwd_validate(a);
     if (rc != NAF_OK) return -rc;
     if (256 % (4 * a->heads) != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
-    if (a->H < 2 || a->W < 2 || a->H < a->h || a->W < a->w) return 0;
+    const int Ho = a->Ho > 0 ? a->Ho : a->H, Wo = a->Wo > 0 ? a->Wo : a->W;
+    if (a->H < 2 || a->W < 2 || Ho < a->h || Wo < a->w) return 0;
+    if (Ho > a->H || Wo > a->W || a->H > 4 * Ho || a->W > 4 * Wo) return 0;   // the bilinear pre-shrink (naf.py:39-48) is the caller's
     if (reinterpret_cast<uintptr_t>(a->out) % 16) return 0;
     if (fwd_rope_fusable(a)) return 1;
     naf_forward_args g = *a;
@@ -396,12 +414,16 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     }
     // keys: pooled RoPE'd guidance; queries: rotated on load by the attention kernel where the geometry allows it
     // (row tiles), otherwise written here
+    if (L.pooled) {   // image larger than the output: pool the guidance first (naf.py:34), everything below runs at (Ho, Wo)
+        const int prc = naf_pool_guidance(ws + L.guide, cat, a->B, a->H, a->W, L.Ho, L.Wo, 256, stream);
+        if (prc != NAF_OK) return prc;
+    }
     naf_rope_pool_args rp{};
-    rp.x = cat; rp.q = L.fused ? nullptr : static_cast<void*>(ws + L.q); rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
-    rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = a->heads; rp.Ho = a->H; rp.Wo = a->W; rp.h = a->h; rp.w = a->w;
-    const int64_t xs[4] = {(int64_t)a->H * a->W * 256, 1, (int64_t)a->W * 256, 256};
+    rp.x = ws + L.guide; rp.q = L.fused ? nullptr : static_cast<void*>(ws + L.q); rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
+    rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = a->heads; rp.Ho = L.Ho; rp.Wo = L.Wo; rp.h = a->h; rp.w = a->w;
+    const int64_t xs[4] = {(int64_t)L.Ho * L.Wo * 256, 1, (int64_t)L.Wo * 256, 256};
     const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / a->heads, (int64_t)a->w * 256, 256};
-    const int64_t qst[4] = {(int64_t)a->H * a->W * 256, 256 / a->heads, (int64_t)a->W * 256, 256};
+    const int64_t qst[4] = {(int64_t)L.Ho * L.Wo * 256, 256 / a->heads, (int64_t)L.Wo * 256, 256};
     for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = L.fused ? 0 : qst[i]; rp.k_stride[i] = kst[i]; }
     int rc = naf_rope_pool_fwd(&rp, stream);
     if (rc != NAF_OK) return rc;
@@ -410,8 +432,8 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     naf_xna_args x;
     fwd_xna_args(a, &L, L.fused, &x);
     if (!L.fused && naf_xna_select(&x) != NAF_XNA_MFMA) {   // table-driven kernels: the index tables, built on the device
-        rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_y), a->H, a->h, a->ksize, stream);
-        if (rc == NAF_OK) rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_x), a->W, a->w, a->ksize, stream);
+        rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_y), L.Ho, a->h, a->ksize, stream);
+        if (rc == NAF_OK) rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_x), L.Wo, a->w, a->ksize, stream);
         if (rc != NAF_OK) return rc;
     }
     if (a->events[0] && hipEventRecord(static_cast<hipEvent_t>(a->events[0]), s) != hipSuccess) {

@@ -263,8 +263,12 @@ class ImageEncoder(nn.Module):
             dt = self.stem_dtype
             x = x.to(dt).contiguous(memory_format=torch.channels_last)
             x = torch.cat([self._branch(x, self.encoder, dt), self._branch(x, self.sem_encoder, dt)], dim=1)
-        if x.shape[-2:] != (ho, wo):
-            x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
+        if x.shape[-2:] != (ho, wo):                                           # naf.py:34
+            if (x.dtype == torch.bfloat16 and x.is_cuda and x.shape[1] % 8 == 0 and ho <= x.shape[-2] and wo <= x.shape[-1]
+                    and x.is_contiguous(memory_format=torch.channels_last)):
+                x = ops.pool_guidance(x, (ho, wo))                             # the kernel naf_forward uses as well
+            else:
+                x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))
         return x.contiguous(memory_format=torch.channels_last)
 
 
@@ -402,8 +406,10 @@ class NAF(nn.Module):
         ho, wo = int(output_size[0]), int(output_size[1])
         if not (enc.use_encoder and enc.stem_impl == "hip" and enc._hip_stem_ok() and enc.fuse_conv0 and self.fuse_rope):
             return None
-        if tuple(image.shape[-2:]) != (ho, wo) or image.shape[1] != 3 or self.xna_path != "auto":
+        if image.shape[1] != 3 or self.xna_path != "auto":
             return None
+        if image.shape[-2] > 4 * ho or image.shape[-1] > 4 * wo or image.shape[-2] < ho or image.shape[-1] < wo:
+            return None                      # bilinear pre-shrink / enlarging pool: composed path (torch ops)
         if enc.rope.num_heads != self.upsampler.num_heads or features.dtype not in (torch.bfloat16, torch.float32):
             return None
         if image.dtype not in (torch.bfloat16, torch.float32) or features.shape[1] % self.upsampler.num_heads:
@@ -412,7 +418,7 @@ class NAF(nn.Module):
             return None
         prm_key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (enc.rope.periods.data_ptr(), enc.rope.periods._version)
         key = (prm_key, tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()),
-               features.dtype, str(image.device))
+               features.dtype, str(image.device), (ho, wo))
         hit = self.__dict__.get("_plan_cache")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -431,7 +437,8 @@ class NAF(nn.Module):
         eps = enc.encoder[1].norm1.eps
         plan = ops.ForwardPlan(branches, len(branches[0][4]), eps, enc.rope.tables(ho, wo), image, features,
                                self.upsampler.num_heads, self.upsampler.kernel_size[0],
-                               torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32, self.upsampler.scale)
+                               torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32, self.upsampler.scale,
+                               output_size=(ho, wo))
         plan = plan if plan.supported else None
         self.__dict__["_plan_cache"] = (key, plan)
         return plan

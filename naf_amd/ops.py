@@ -206,6 +206,23 @@ def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: 
     return q, k
 
 
+def pool_guidance(x: torch.Tensor, output_size) -> torch.Tensor:
+    """adaptive_avg_pool2d of the bf16 channels-last guidance [B, C, H, W] (logical) to ``output_size`` (naf.py:34);
+    returns a logical [B, C, Ho, Wo] view of a dense channels-last buffer."""
+    _gpu(x, "x")
+    B, Cc, H, W = x.shape
+    Ho, Wo = int(output_size[0]), int(output_size[1])
+    xc = x.permute(0, 2, 3, 1)
+    if x.dtype != torch.bfloat16 or not xc.is_contiguous() or Cc % 8:
+        raise ValueError("pool_guidance: expected a dense channels-last bf16 tensor with C % 8 == 0")
+    y = torch.empty((B, Ho, Wo, Cc), dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device), _Timed("pool_guidance"):
+        rc = lib.naf_pool_guidance(y.data_ptr(), xc.data_ptr(), B, H, W, Ho, Wo, Cc, _stream(x))
+    _lib.check(rc, "naf_pool_guidance")
+    return y.permute(0, 3, 1, 2)
+
+
 def pack_values(v: torch.Tensor) -> torch.Tensor:
     """[B, C, h, w] (bf16/fp32, any strides) -> dense channels-last bf16 [B, h, w, C]."""
     _gpu(v, "lr_features")
@@ -411,15 +428,17 @@ class ForwardPlan:
     Built once per (parameter versions, shapes); ``run`` only swaps the image / features / output pointers."""
 
     def __init__(self, branches, nlayer: int, gn_eps: float, tabs, image: torch.Tensor, features: torch.Tensor,
-                 heads: int, ksize: int, out_dtype: torch.dtype, scale: Optional[float]):
+                 heads: int, ksize: int, out_dtype: torch.dtype, scale: Optional[float], output_size=None):
         lib = _lib.load()
         B, _, H, W = image.shape
+        Ho, Wo = (int(output_size[0]), int(output_size[1])) if output_size is not None else (H, W)
         _, Cc, h, w = features.shape
         a = ForwardArgs()
         a.tab_y, a.tab_x = tabs[0].data_ptr(), tabs[1].data_ptr()
         a.nlayer = nlayer
         a.image_dtype, a.feat_dtype, a.out_dtype = _DT[image.dtype], _DT[features.dtype], _DT[out_dtype]
         a.B, a.H, a.W, a.h, a.w, a.C, a.heads, a.ksize = B, H, W, h, w, Cc, heads, ksize
+        a.Ho, a.Wo = Ho, Wo
         a.gn_eps = float(gn_eps)
         a.scale = float(scale) if scale else 0.0
         self._keep = [tabs]
@@ -437,9 +456,10 @@ class ForwardPlan:
         a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), image.data_ptr() & ~0xFF
         self.supported = lib.naf_forward_supported(C.byref(a)) == 1
         self.args, self.lib = a, lib
-        self.out_dtype, self.shape_out = out_dtype, (B, H, W, Cc)
+        self.out_dtype, self.shape_out = out_dtype, (B, Ho, Wo, Cc)
         self.ws_bytes = int(lib.naf_forward_workspace_bytes(C.byref(a))) if self.supported else 0
-        self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype)
+        self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype,
+                    (Ho, Wo))
 
     def run(self, image: torch.Tensor, features: torch.Tensor, events=None) -> torch.Tensor:
         a = self.args

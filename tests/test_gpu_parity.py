@@ -1026,8 +1026,8 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     assert a.dtype == b.dtype and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
-    # shapes it does not serve fall back to the composed path transparently
-    assert m._forward_plan(img, ft, (48, 64)) is None
+    # shapes it does not serve (bilinear pre-shrink: image more than 4x the output) fall back to the composed path
+    assert m._forward_plan(img, ft, (16, 16)) is None
 
 
 @pytest.mark.parametrize("hw,lr,C,ksz,path", [
@@ -1083,3 +1083,34 @@ def test_device_index_table_equals_host_table(dev, L_out, L_in, k):
                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     assert torch.equal(d.cpu(), host)
+
+
+@pytest.mark.parametrize("shape,out", [((2, 64, 40, 56), (10, 14)), ((1, 256, 45, 70), (45, 23)), ((1, 8, 33, 47), (7, 40)), ((1, 256, 64, 64), (64, 64))])
+def test_pool_guidance_matches_torch(dev, shape, out):
+    """naf_pool_guidance == F.adaptive_avg_pool2d on the bf16 channels-last guidance (fp32 accumulation, one rounding)."""
+    import torch.nn.functional as F
+    from naf_amd import ops
+    x = O.hash_normal(shape, 1201).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    got = ops.pool_guidance(x, out).float().cpu()
+    ref = F.adaptive_avg_pool2d(x.float().cpu(), out)
+    assert_close(got, ref, 1e-6, 2.0 ** -8, f"pool {shape} -> {out}")
+
+
+@pytest.mark.parametrize("img_hw,out_hw,lr,C,ksz", [((96, 128), (48, 64), (6, 8), 128, 5),      # image 2x the output, 8x8 cells (union)
+                                                    ((100, 90), (32, 32), (2, 2), 64, 1),       # 3.1x / 2.8x, 16x16 cells (rotate on load)
+                                                    ((64, 64), (28, 28), (14, 14), 64, 3)])     # pooled AND 2x2 cells
+def test_single_call_forward_with_pooled_guidance(dev, img_hw, out_hw, lr, C, ksz):
+    """Image larger than the output (naf.py:34, the reference's 'out 56^2 ... 224^2 from image 448^2' rows): naf_forward
+    pools the guidance itself; same bits as the composed path, same values as the oracle."""
+    p = O.make_params(seed=45)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *img_hw), 981).to(dev)
+    ft = O.hash_normal((1, C, *lr), 982).to(dev)
+    assert m._forward_plan(img, ft, out_hw) is not None
+    a = m(img, ft, out_hw)
+    m.single_call = False
+    b = m(img, ft, out_hw)
+    m.single_call = True
+    assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pooled forward vs oracle {img_hw} -> {out_hw}")
