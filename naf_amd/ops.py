@@ -464,7 +464,11 @@ class ForwardPlan:
     def run(self, image: torch.Tensor, features: torch.Tensor, events=None) -> torch.Tensor:
         a = self.args
         dev = image.device
-        ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+        # the workspace belongs to the plan (one allocation per geometry, not per call); like the reference's RoPE cache
+        # (rope.py:159-163) this makes a module non-reentrant across streams / threads
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != dev:
+            ws = self._ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
         out = torch.empty(self.shape_out, dtype=self.out_dtype, device=dev)
         a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), out.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes
