@@ -154,6 +154,14 @@ typedef struct naf_rope_pool_args {
 } naf_rope_pool_args;
 int naf_rope_pool_fwd(const naf_rope_pool_args* a, naf_stream_t stream);
 
+/* ---- image pre-shrink -----------------------------------------------------------------------------------
+ * Replaces the F.interpolate(mode="bilinear", align_corners=False) of ImageEncoder.forward (naf.py:39-48) that the
+ * reference applies to images more than 4x the output size: image device f32 / bf16 [B, 3, H, W], strides {b, c, y, x}
+ * -> out device float dense [B, 3, Hs, Ws]; ATen's arithmetic, no antialiasing.  The target size
+ * (min(H, 4*Ho, 4*Wo), min(W, 4*Wo, 4*Ho)) is the caller's to compute (naf_forward does it itself). */
+int naf_preshrink_image(float* out, const void* image, int32_t image_dtype, int32_t B, int32_t H, int32_t W, int32_t Hs,
+                        int32_t Ws, const int64_t image_stride[4], naf_stream_t stream);
+
 /* ---- guidance pooling ---------------------------------------------------------------------------------
  * Replaces F.adaptive_avg_pool2d(x, output_size) of ImageEncoder.encode (naf.py:34) when the image is larger than the
  * output: x device bf16 dense channels-last [B, H, W, C] -> y device bf16 dense channels-last [B, Ho, Wo, C],
@@ -262,7 +270,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------
  * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
- * encoder branches with img_layers blocks, RoPE heads = attention heads, image at most 4x the output size): every launch
+ * encoder branches with img_layers blocks, RoPE heads = attention heads, image at least as large as the output): every launch
  * of the path above -- conv stem, key pooling, value packing, attention -- is issued from one host call on the
  * caller's stream, so a C/C++ host needs nothing else and a Python host pays one foreign call per forward instead
  * of fourteen.  Any geometry naf_xna_fwd accepts is served: with an integer ratio and Wo/w a multiple of 16 the
@@ -280,8 +288,9 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  *             values, queries / index tables where needed); the library still owns no memory
  *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
- * Configurations outside the list (other widths, return_weights, images more than 4x the output: naf.py:39-48's
- * bilinear pre-shrink is the caller's) return
+ * An image more than 4x the output is first shrunk (naf_preshrink_image), an image larger than the output has its
+ * guidance pooled (naf_pool_guidance), exactly as naf.py:37-49 does.  Configurations outside the list (other widths,
+ * return_weights, outputs larger than the image) return
  * NAF_ERR_UNSUPPORTED: compose the individual entry points instead. */
 #define NAF_MAX_STEM_LAYERS 8
 typedef struct naf_stem_branch {

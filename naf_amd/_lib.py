@@ -105,6 +105,8 @@ SIGNATURES = {
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_rope_pool_fwd": (C.c_int, [C.POINTER(RopePoolArgs), C.c_void_p]),
+    "naf_preshrink_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(I64x4), C.c_void_p]),
     "naf_pool_guidance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_pack_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(C.c_int64), C.c_void_p]),

@@ -98,6 +98,14 @@ int naf_pack_values(void* vp, const void* v, int32_t v_dtype, int32_t B, int32_t
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int naf_preshrink_image(float* out, const void* image, int32_t image_dtype, int32_t B, int32_t H, int32_t W, int32_t Hs, int32_t Ws,
+                        const int64_t image_stride[4], naf_stream_t stream) {
+    NAF_REQUIRE(out && image && image_stride, "naf_preshrink_image: NULL pointer");
+    NAF_REQUIRE(image_dtype == NAF_BF16 || image_dtype == NAF_F32, "naf_preshrink_image: image_dtype %d", image_dtype);
+    NAF_REQUIRE(B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, "naf_preshrink_image: non-positive size");
+    return naf_launch_preshrink(out, image, image_dtype, B, H, W, Hs, Ws, image_stride, static_cast<hipStream_t>(stream));
+}
+
 int naf_pool_guidance(void* y, const void* x, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C, naf_stream_t stream) {
     NAF_REQUIRE(x && y, "naf_pool_guidance: NULL pointer");
     NAF_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0, "naf_pool_guidance: non-positive size");
@@ -253,20 +261,29 @@ struct FwdLayout {
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
     int Ho, Wo;   // output size
+    size_t img;   // pre-shrunk fp32 image [B, 3, Hs, Ws] (naf.py:39-48) when the image is more than 4x the output
+    bool shrunk;
+    int Hs, Ws;   // size the stem runs at
 };
 bool fwd_rope_fusable(const naf_forward_args* a);
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 FwdLayout fwd_layout(const naf_forward_args* a) {
     FwdLayout L;
-    const size_t px = (size_t)a->B * a->H * a->W;
+    L.Ho = a->Ho > 0 ? a->Ho : a->H;
+    L.Wo = a->Wo > 0 ? a->Wo : a->W;
+    L.shrunk = a->H > 4 * L.Ho || a->W > 4 * L.Wo;
+    auto min3 = [](int x, int y, int z) { return x < y ? (x < z ? x : z) : (y < z ? y : z); };
+    L.Hs = L.shrunk ? min3(a->H, 4 * L.Ho, 4 * L.Wo) : a->H;          // naf.py:42-43 (the reference's own min() arguments)
+    L.Ws = L.shrunk ? min3(a->W, 4 * L.Wo, 4 * L.Ho) : a->W;
+    const size_t px = (size_t)a->B * L.Hs * L.Ws;
     size_t off = 0;
+    L.img = off;
+    if (L.shrunk) off = align256(off + px * 3 * sizeof(float));
     L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * a->B * 16 * sizeof(double));
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.cat = off;   off = align256(off + px * 256 * 2);
-    L.Ho = a->Ho > 0 ? a->Ho : a->H;
-    L.Wo = a->Wo > 0 ? a->Wo : a->W;
-    L.pooled = L.Ho != a->H || L.Wo != a->W;
+    L.pooled = L.Ho != L.Hs || L.Wo != L.Ws;
     const size_t opx = (size_t)a->B * L.Ho * L.Wo;
     L.guide = L.pooled ? off : L.cat;
     if (L.pooled) off = align256(off + opx * 256 * 2);
@@ -348,7 +365,11 @@ int naf_forward_supported(const naf_forward_args* a) {
     if (256 % (4 * a->heads) != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
     const int Ho = a->Ho > 0 ? a->Ho : a->H, Wo = a->Wo > 0 ? a->Wo : a->W;
     if (a->H < 2 || a->W < 2 || Ho < a->h || Wo < a->w) return 0;
-    if (Ho > a->H || Wo > a->W || a->H > 4 * Ho || a->W > 4 * Wo) return 0;   // the bilinear pre-shrink (naf.py:39-48) is the caller's
+    if (Ho > a->H || Wo > a->W) return 0;   // an enlarging pool is not served
+    {
+        const FwdLayout Lq = fwd_layout(a);
+        if (Lq.Hs < Ho || Lq.Ws < Wo || Lq.Hs < 2 || Lq.Ws < 2) return 0;
+    }
     if (reinterpret_cast<uintptr_t>(a->out) % 16) return 0;
     if (fwd_rope_fusable(a)) return 1;
     naf_forward_args g = *a;
@@ -379,15 +400,27 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     }
     void* bufs[2] = {ws + L.buf0, ws + L.buf1};
     char* cat = ws + L.cat;
-    const int64_t dense[3] = {(int64_t)a->H * a->W * 128, (int64_t)a->W * 128, 128};
-    const int64_t cat_st[3] = {(int64_t)a->H * a->W * 256, (int64_t)a->W * 256, 256};
+    // the image the stem runs on: the caller's, or its bilinear pre-shrink (naf.py:39-48) when it is more than 4x the output
+    const void* simg = a->image;
+    int simg_dtype = a->image_dtype;
+    int64_t simg_stride[4] = {a->image_stride[0], a->image_stride[1], a->image_stride[2], a->image_stride[3]};
+    const int SH = L.Hs, SW = L.Ws;
+    if (L.shrunk) {
+        const int src = naf_preshrink_image(reinterpret_cast<float*>(ws + L.img), a->image, a->image_dtype, a->B, a->H, a->W, SH, SW, a->image_stride, stream);
+        if (src != NAF_OK) return src;
+        simg = ws + L.img;
+        simg_dtype = NAF_F32;
+        simg_stride[0] = (int64_t)3 * SH * SW; simg_stride[1] = (int64_t)SH * SW; simg_stride[2] = SW; simg_stride[3] = 1;
+    }
+    const int64_t dense[3] = {(int64_t)SH * SW * 128, (int64_t)SW * 128, 128};
+    const int64_t cat_st[3] = {(int64_t)SH * SW * 256, (int64_t)SW * 256, 256};
     for (int br = 0; br < 2; ++br) {
         const naf_stem_branch& b = a->branch[br];
         double* st = stats + (size_t)br * (a->nlayer + 1) * stat_stride;
         naf_stem_conv0_args c0{};
-        c0.image = a->image; c0.weight = b.conv0_weight; c0.bias = b.conv0_bias; c0.stats_out = st;
-        c0.image_dtype = a->image_dtype; c0.ksize = b.conv0_ksize; c0.B = a->B; c0.H = a->H; c0.W = a->W;
-        for (int i = 0; i < 4; ++i) c0.image_stride[i] = a->image_stride[i];
+        c0.image = simg; c0.weight = b.conv0_weight; c0.bias = b.conv0_bias; c0.stats_out = st;
+        c0.image_dtype = simg_dtype; c0.ksize = b.conv0_ksize; c0.B = a->B; c0.H = SH; c0.W = SW;
+        for (int i = 0; i < 4; ++i) c0.image_stride[i] = simg_stride[i];
         // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
         const bool recompute = b.conv0_ksize == 1 && b.ksize == 1;
         c0.y = recompute ? nullptr : bufs[0];
@@ -405,7 +438,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
             c.gn_weight = b.gn_weight[l]; c.gn_bias = b.gn_bias[l];
             c.stats_in = st + (size_t)l * stat_stride;
             c.stats_out = last ? nullptr : st + (size_t)(l + 1) * stat_stride;
-            c.ksize = b.ksize; c.B = a->B; c.H = a->H; c.W = a->W; c.eps = a->gn_eps;
+            c.ksize = b.ksize; c.B = a->B; c.H = SH; c.W = SW; c.eps = a->gn_eps;
             for (int i = 0; i < 3; ++i) { c.x_stride[i] = dense[i]; c.y_stride[i] = last ? cat_st[i] : dense[i]; }
             rc = naf_stem_conv_fwd(&c, stream);
             if (rc != NAF_OK) return rc;
@@ -415,7 +448,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     // keys: pooled RoPE'd guidance; queries: rotated on load by the attention kernel where the geometry allows it
     // (row tiles), otherwise written here
     if (L.pooled) {   // image larger than the output: pool the guidance first (naf.py:34), everything below runs at (Ho, Wo)
-        const int prc = naf_pool_guidance(ws + L.guide, cat, a->B, a->H, a->W, L.Ho, L.Wo, 256, stream);
+        const int prc = naf_pool_guidance(ws + L.guide, cat, a->B, SH, SW, L.Ho, L.Wo, 256, stream);
         if (prc != NAF_OK) return prc;
     }
     naf_rope_pool_args rp{};

@@ -46,6 +46,7 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);           
 int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, int h, int w,
                            const int64_t* vs, hipStream_t s);                    // pack.hip
 
+int naf_launch_preshrink(float* out, const void* img, int dtype, int B, int H, int W, int Hs, int Ws, const int64_t* st, hipStream_t s);   // resize.hip
 int naf_launch_pool_guidance(void* y, const void* x, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s);   // pool.hip
 
 int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);            // stem_conv0.hip

@@ -255,8 +255,11 @@ class ImageEncoder(nn.Module):
         ho, wo = output_size
         x = image
         if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
-            x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
-                              mode="bilinear", align_corners=False)
+            size = (min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho))
+            if x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype in (torch.float32, torch.bfloat16):
+                x = ops.preshrink_image(x, size)                               # the kernel naf_forward uses as well
+            else:
+                x = F.interpolate(x.float(), size=size, mode="bilinear", align_corners=False)
         if self.use_encoder and self.stem_impl == "hip" and self._hip_stem_ok():
             x = self._stem_hip(x)
         elif self.use_encoder:
@@ -408,8 +411,8 @@ class NAF(nn.Module):
             return None
         if image.shape[1] != 3 or self.xna_path != "auto":
             return None
-        if image.shape[-2] > 4 * ho or image.shape[-1] > 4 * wo or image.shape[-2] < ho or image.shape[-1] < wo:
-            return None                      # bilinear pre-shrink / enlarging pool: composed path (torch ops)
+        if image.shape[-2] < ho or image.shape[-1] < wo:
+            return None                      # enlarging pool: composed path (torch op)
         if enc.rope.num_heads != self.upsampler.num_heads or features.dtype not in (torch.bfloat16, torch.float32):
             return None
         if image.dtype not in (torch.bfloat16, torch.float32) or features.shape[1] % self.upsampler.num_heads:

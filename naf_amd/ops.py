@@ -206,6 +206,22 @@ def rope_pool(x: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, heads: 
     return q, k
 
 
+def preshrink_image(image: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(image, size, mode="bilinear", align_corners=False) of naf.py:39-48 -> fp32 [B, 3, Hs, Ws]."""
+    _gpu(image, "image")
+    if image.dtype not in _DT or image.dim() != 4 or image.shape[1] != 3:
+        raise ValueError("preshrink_image: expected a [B, 3, H, W] float32 / bfloat16 image")
+    B, _, H, W = image.shape
+    Hs, Ws = int(size[0]), int(size[1])
+    out = torch.empty((B, 3, Hs, Ws), dtype=torch.float32, device=image.device)
+    st = _strides4(image, (0, 1, 2, 3))
+    lib = _lib.load()
+    with torch.cuda.device(image.device), _Timed("preshrink"):
+        rc = lib.naf_preshrink_image(out.data_ptr(), image.data_ptr(), _DT[image.dtype], B, H, W, Hs, Ws, C.byref(st), _stream(image))
+    _lib.check(rc, "naf_preshrink_image")
+    return out
+
+
 def pool_guidance(x: torch.Tensor, output_size) -> torch.Tensor:
     """adaptive_avg_pool2d of the bf16 channels-last guidance [B, C, H, W] (logical) to ``output_size`` (naf.py:34);
     returns a logical [B, C, Ho, Wo] view of a dense channels-last buffer."""

@@ -1026,8 +1026,8 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     assert a.dtype == b.dtype and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
-    # shapes it does not serve (bilinear pre-shrink: image more than 4x the output) fall back to the composed path
-    assert m._forward_plan(img, ft, (16, 16)) is None
+    # shapes it does not serve (an output larger than the image) fall back to the composed path
+    assert m._forward_plan(img, ft, (192, 256)) is None
 
 
 @pytest.mark.parametrize("hw,lr,C,ksz,path", [
@@ -1114,3 +1114,34 @@ def test_single_call_forward_with_pooled_guidance(dev, img_hw, out_hw, lr, C, ks
     assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pooled forward vs oracle {img_hw} -> {out_hw}")
+
+
+@pytest.mark.parametrize("shape,size,fmt", [((2, 3, 97, 130), (24, 32), "f32"), ((1, 3, 64, 200), (40, 40), "bf16_nhwc"), ((1, 3, 33, 33), (32, 8), "f32")])
+def test_preshrink_matches_torch_bilinear(dev, shape, size, fmt):
+    """naf_preshrink_image == F.interpolate(mode="bilinear", align_corners=False) (naf.py:39-48), ATen's arithmetic."""
+    import torch.nn.functional as F
+    from naf_amd import ops
+    img = O.hash_normal(shape, 1301)
+    if fmt == "bf16_nhwc":
+        img = img.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    got = ops.preshrink_image(img.to(dev), size).cpu()
+    ref = F.interpolate(img.float(), size=size, mode="bilinear", align_corners=False)
+    assert_close(got, ref, 2e-6, 2e-6, f"preshrink {shape} -> {size}")
+
+
+@pytest.mark.parametrize("img_hw,out_hw,lr,C,ksz", [((200, 136), (32, 32), (2, 2), 64, 1),      # 6.25x / 4.25x: shrunk to 128 x 128, then pooled
+                                                    ((130, 40), (16, 32), (4, 8), 128, 3)])     # only the height exceeds 4x
+def test_single_call_forward_with_preshrunk_image(dev, img_hw, out_hw, lr, C, ksz):
+    """Image more than 4x the output (naf.py:39-48): naf_forward shrinks it itself; same bits as the composed path."""
+    p = O.make_params(seed=47)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *img_hw), 991).to(dev)
+    ft = O.hash_normal((1, C, *lr), 992).to(dev)
+    assert m._forward_plan(img, ft, out_hw) is not None
+    a = m(img, ft, out_hw)
+    m.single_call = False
+    b = m(img, ft, out_hw)
+    m.single_call = True
+    assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pre-shrunk forward vs oracle {img_hw} -> {out_hw}")
