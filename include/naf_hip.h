@@ -163,8 +163,7 @@ int naf_preshrink_image(float* out, const void* image, int32_t image_dtype, int3
                         int32_t Ws, const int64_t image_stride[4], naf_stream_t stream);
 
 /* ---- guidance pooling ---------------------------------------------------------------------------------
- * Replaces F.adaptive_avg_pool2d(x, output_size) of ImageEncoder.encode (naf.py:34) when the image is larger than the
- * output: x device bf16 dense channels-last [B, H, W, C] -> y device bf16 dense channels-last [B, Ho, Wo, C],
+ * Replaces F.adaptive_avg_pool2d(x, output_size) of ImageEncoder.encode (naf.py:34) when image and output size differ: x device bf16 dense channels-last [B, H, W, C] -> y device bf16 dense channels-last [B, Ho, Wo, C],
  * C % 8 == 0, both 16-byte aligned; windows [floor(i*H/Ho), ceil((i+1)*H/Ho)) like torch, fp32 accumulation. */
 int naf_pool_guidance(void* y, const void* x, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t C,
                       naf_stream_t stream);
@@ -270,7 +269,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------
  * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
- * encoder branches with img_layers blocks, RoPE heads = attention heads, image at least as large as the output): every launch
+ * encoder branches with img_layers blocks, RoPE heads = attention heads, any image and output size): every launch
  * of the path above -- conv stem, key pooling, value packing, attention -- is issued from one host call on the
  * caller's stream, so a C/C++ host needs nothing else and a Python host pays one foreign call per forward instead
  * of fourteen.  Any geometry naf_xna_fwd accepts is served: with an integer ratio and Wo/w a multiple of 16 the
@@ -289,8 +288,8 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
  * An image more than 4x the output is first shrunk (naf_preshrink_image), an image larger than the output has its
- * guidance pooled (naf_pool_guidance), exactly as naf.py:37-49 does.  Configurations outside the list (other widths,
- * return_weights, outputs larger than the image) return
+ * guidance pooled (naf_pool_guidance; an output larger than the image is the same adaptive pooling), exactly as
+ * naf.py:37-49 does.  Configurations outside the list (other widths, return_weights) return
  * NAF_ERR_UNSUPPORTED: compose the individual entry points instead. */
 #define NAF_MAX_STEM_LAYERS 8
 typedef struct naf_stem_branch {

@@ -365,10 +365,9 @@ int naf_forward_supported(const naf_forward_args* a) {
     if (256 % (4 * a->heads) != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
     const int Ho = a->Ho > 0 ? a->Ho : a->H, Wo = a->Wo > 0 ? a->Wo : a->W;
     if (a->H < 2 || a->W < 2 || Ho < a->h || Wo < a->w) return 0;
-    if (Ho > a->H || Wo > a->W) return 0;   // an enlarging pool is not served
     {
         const FwdLayout Lq = fwd_layout(a);
-        if (Lq.Hs < Ho || Lq.Ws < Wo || Lq.Hs < 2 || Lq.Ws < 2) return 0;
+        if (Lq.Hs < 2 || Lq.Ws < 2) return 0;
     }
     if (reinterpret_cast<uintptr_t>(a->out) % 16) return 0;
     if (fwd_rope_fusable(a)) return 1;

@@ -267,7 +267,7 @@ class ImageEncoder(nn.Module):
             x = x.to(dt).contiguous(memory_format=torch.channels_last)
             x = torch.cat([self._branch(x, self.encoder, dt), self._branch(x, self.sem_encoder, dt)], dim=1)
         if x.shape[-2:] != (ho, wo):                                           # naf.py:34
-            if (x.dtype == torch.bfloat16 and x.is_cuda and x.shape[1] % 8 == 0 and ho <= x.shape[-2] and wo <= x.shape[-1]
+            if (x.dtype == torch.bfloat16 and x.is_cuda and x.shape[1] % 8 == 0
                     and x.is_contiguous(memory_format=torch.channels_last)):
                 x = ops.pool_guidance(x, (ho, wo))                             # the kernel naf_forward uses as well
             else:
@@ -411,8 +411,6 @@ class NAF(nn.Module):
             return None
         if image.shape[1] != 3 or self.xna_path != "auto":
             return None
-        if image.shape[-2] < ho or image.shape[-1] < wo:
-            return None                      # enlarging pool: composed path (torch op)
         if enc.rope.num_heads != self.upsampler.num_heads or features.dtype not in (torch.bfloat16, torch.float32):
             return None
         if image.dtype not in (torch.bfloat16, torch.float32) or features.shape[1] % self.upsampler.num_heads:

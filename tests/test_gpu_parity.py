@@ -1026,8 +1026,9 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     assert a.dtype == b.dtype and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
-    # shapes it does not serve (an output larger than the image) fall back to the composed path
-    assert m._forward_plan(img, ft, (192, 256)) is None
+    # a different architecture (other window per axis) falls back to the composed path
+    m.upsampler.kernel_size = (5, 3)
+    assert m._forward_plan(img, ft, (96, 128)) is None
 
 
 @pytest.mark.parametrize("hw,lr,C,ksz,path", [
@@ -1085,7 +1086,8 @@ def test_device_index_table_equals_host_table(dev, L_out, L_in, k):
     assert torch.equal(d.cpu(), host)
 
 
-@pytest.mark.parametrize("shape,out", [((2, 64, 40, 56), (10, 14)), ((1, 256, 45, 70), (45, 23)), ((1, 8, 33, 47), (7, 40)), ((1, 256, 64, 64), (64, 64))])
+@pytest.mark.parametrize("shape,out", [((2, 64, 40, 56), (10, 14)), ((1, 256, 45, 70), (45, 23)), ((1, 8, 33, 47), (7, 40)), ((1, 256, 64, 64), (64, 64)),
+                                       ((1, 64, 20, 24), (50, 31))])
 def test_pool_guidance_matches_torch(dev, shape, out):
     """naf_pool_guidance == F.adaptive_avg_pool2d on the bf16 channels-last guidance (fp32 accumulation, one rounding)."""
     import torch.nn.functional as F
@@ -1098,7 +1100,8 @@ def test_pool_guidance_matches_torch(dev, shape, out):
 
 @pytest.mark.parametrize("img_hw,out_hw,lr,C,ksz", [((96, 128), (48, 64), (6, 8), 128, 5),      # image 2x the output, 8x8 cells (union)
                                                     ((100, 90), (32, 32), (2, 2), 64, 1),       # 3.1x / 2.8x, 16x16 cells (rotate on load)
-                                                    ((64, 64), (28, 28), (14, 14), 64, 3)])     # pooled AND 2x2 cells
+                                                    ((64, 64), (28, 28), (14, 14), 64, 3),      # pooled AND 2x2 cells
+                                                    ((40, 48), (64, 64), (4, 4), 64, 3)])       # output LARGER than the image
 def test_single_call_forward_with_pooled_guidance(dev, img_hw, out_hw, lr, C, ksz):
     """Image larger than the output (naf.py:34, the reference's 'out 56^2 ... 224^2 from image 448^2' rows): naf_forward
     pools the guidance itself; same bits as the composed path, same values as the oracle."""
