@@ -289,7 +289,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
  * An image more than 4x the output is first shrunk (naf_preshrink_image), an image larger than the output has its
  * guidance pooled (naf_pool_guidance; an output larger than the image is the same adaptive pooling), exactly as
- * naf.py:37-49 does.  Configurations outside the list (other widths, return_weights) return
+ * naf.py:37-49 does; `logits` adds the reference's return_weights output.  Other widths return
  * NAF_ERR_UNSUPPORTED: compose the individual entry points instead. */
 #define NAF_MAX_STEM_LAYERS 8
 typedef struct naf_stem_branch {
@@ -311,6 +311,7 @@ typedef struct naf_forward_args {
     void* workspace;
     size_t workspace_bytes;
     void* events[2];
+    float* logits; /* optional: return_weights (attentions.py:27-28), dense [B, heads, Ho, Wo, ksize*ksize]; NULL = none */
     naf_stem_branch branch[2];
     int32_t nlayer; /* GroupNorm/SiLU/conv layers per branch = 2 * img_layers */
     int32_t image_dtype, feat_dtype, out_dtype; /* naf_dtype */

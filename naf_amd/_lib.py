@@ -86,7 +86,7 @@ class StemBranch(C.Structure):
 class ForwardArgs(C.Structure):
     _fields_ = [
         ("image", C.c_void_p), ("features", C.c_void_p), ("out", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("events", C.c_void_p * 2),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("events", C.c_void_p * 2), ("logits", C.c_void_p),
         ("branch", StemBranch * 2),
         ("nlayer", C.c_int32), ("image_dtype", C.c_int32), ("feat_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("C", C.c_int32),

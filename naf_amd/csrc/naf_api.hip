@@ -324,6 +324,7 @@ void fwd_xna_args(const naf_forward_args* a, const FwdLayout* L, bool fused, naf
     x->k_lr = real ? ws + L->keys : fake;
     x->v_lr = real ? ws + L->vp : fake;
     x->out = a->out;
+    x->logits = a->logits;
     if (fused) {
         x->rope_tab_y = a->tab_y; x->rope_tab_x = a->tab_x;
         x->path = NAF_XNA_MFMA;

@@ -502,7 +502,7 @@ class NAF(nn.Module):
                                f"image on {image.device}, features on {features.device}")
         if image.dim() != 4 or features.dim() != 4 or image.shape[0] != features.shape[0]:
             raise ValueError(f"expected image [B,3,H,W] and features [B,C,h,w], got {tuple(image.shape)} / {tuple(features.shape)}")
-        if not return_weights and self.single_call:
+        if self.single_call:
             plan = self._forward_plan(image, features, output_size)
             if plan is not None:
                 timer = ops.KERNEL_TIMER
@@ -512,7 +512,7 @@ class NAF(nn.Module):
                     for e in ev:
                         e.record()          # creates the underlying hipEvent_t; naf_forward re-records it around the kernel
                     timer.pairs.setdefault("xna_mfma", []).append(ev)
-                return plan.run(image, features, ev)
+                return plan.run(image, features, ev, return_logits=bool(return_weights))
         fuse_for = None
         if features.shape[1] % self.upsampler.num_heads == 0:
             fuse_for = (features.shape[1] // self.upsampler.num_heads,

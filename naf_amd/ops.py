@@ -477,7 +477,7 @@ class ForwardPlan:
         self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype,
                     (Ho, Wo))
 
-    def run(self, image: torch.Tensor, features: torch.Tensor, events=None) -> torch.Tensor:
+    def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False):
         a = self.args
         dev = image.device
         # the workspace belongs to the plan (one allocation per geometry, not per call); like the reference's RoPE cache
@@ -490,7 +490,13 @@ class ForwardPlan:
         a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes
         a.events[0] = events[0].cuda_event if events else None
         a.events[1] = events[1].cuda_event if events else None
+        logits = None
+        if return_logits:
+            logits = torch.empty((self.shape_out[0], a.heads, self.shape_out[1], self.shape_out[2], a.ksize * a.ksize),
+                                 dtype=torch.float32, device=dev)
+        a.logits = logits.data_ptr() if logits is not None else None
         with torch.cuda.device(dev):
             rc = self.lib.naf_forward(C.byref(a), _stream(image))
         _lib.check(rc, "naf_forward")
-        return out.permute(0, 3, 1, 2)
+        out = out.permute(0, 3, 1, 2)
+        return (out, logits) if return_logits else out

@@ -1148,3 +1148,22 @@ def test_single_call_forward_with_preshrunk_image(dev, img_hw, out_hw, lr, C, ks
     assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pre-shrunk forward vs oracle {img_hw} -> {out_hw}")
+
+
+@pytest.mark.parametrize("img_hw,lr,C,ksz", [((64, 64), (4, 4), 128, 3),       # rotate-on-load cell kernel writes the logits
+                                             ((64, 64), (28, 28), 64, 9),      # non-integer ratio: scalar table kernel with logits
+                                             ((42, 56), (3, 4), 64, 3)])       # 14-pixel cells
+def test_single_call_forward_return_weights(dev, img_hw, lr, C, ksz):
+    """return_weights=True through naf_forward (logits field) == the composed path, and both match the oracle."""
+    p = O.make_params(seed=49)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, *img_hw), 995).to(dev)
+    ft = O.hash_normal((1, C, *lr), 996).to(dev)
+    a, wa = m(img, ft, img_hw, return_weights=True)
+    m.single_call = False
+    b, wb = m(img, ft, img_hw, return_weights=True)
+    m.single_call = True
+    assert torch.equal(a, b) and torch.equal(wa, wb) and wa.shape == (1, 4, *img_hw, ksz * ksz)
+    ref, ref_w = O.naf_forward(p, img.cpu(), ft.float().cpu(), img_hw, kernel_size=ksz, return_weights=True)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "out with return_weights")
+    assert float((wa.cpu() - ref_w).abs().mean()) <= 2e-2
