@@ -269,7 +269,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------
  * Replaces NAF.forward (src/model/naf.py:104-116) for the default architecture (dim 256 = two 128-channel
- * encoder branches with img_layers blocks, RoPE heads = attention heads, any image and output size): every launch
+ * encoder branches with img_layers blocks, any RoPE / attention head counts dividing it, any image and output size): every launch
  * of the path above -- conv stem, key pooling, value packing, attention -- is issued from one host call on the
  * caller's stream, so a C/C++ host needs nothing else and a Python host pays one foreign call per forward instead
  * of fourteen.  Any geometry naf_xna_fwd accepts is served: with an integer ratio and Wo/w a multiple of 16 the
@@ -316,7 +316,8 @@ typedef struct naf_forward_args {
     int32_t nlayer; /* GroupNorm/SiLU/conv layers per branch = 2 * img_layers */
     int32_t image_dtype, feat_dtype, out_dtype; /* naf_dtype */
     int32_t B, H, W, h, w, C, heads, ksize;
-    int32_t Ho, Wo; /* output size; 0 = the image size.  Smaller than the image: the guidance is pooled (naf.py:34) */
+    int32_t Ho, Wo; /* output size; 0 = the image size.  Different from the image: the guidance is pooled (naf.py:34) */
+    int32_t heads_rope, reserved; /* RoPE heads (naf.py:73-85 heads_rope); 0 = the attention heads */
     float gn_eps;
     float scale; /* <= 0: Dq^-0.5 */
     int64_t image_stride[4];

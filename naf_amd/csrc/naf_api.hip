@@ -344,6 +344,7 @@ void fwd_xna_args(const naf_forward_args* a, const FwdLayout* L, bool fused, naf
     for (int i = 0; i < 4; ++i) { x->q_stride[i] = qs[i]; x->k_stride[i] = ks[i]; x->v_stride[i] = vs[i]; x->o_stride[i] = os[i]; }
 }
 bool fwd_rope_fusable(const naf_forward_args* a) {
+    if (a->heads_rope > 0 && a->heads_rope != a->heads) return false;   // the kernel rotates inside ATTENTION heads
     if (a->heads <= 0 || a->C <= 0 || a->C % a->heads || 256 % a->heads) return false;
     naf_forward_args g = *a;   // geometry only: eligibility must not depend on whether a workspace was passed yet
     g.workspace = nullptr;
@@ -363,7 +364,8 @@ size_t naf_forward_workspace_bytes(const naf_forward_args* a) {
 int naf_forward_supported(const naf_forward_args* a) {
     const int rc = fwd_validate(a);
     if (rc != NAF_OK) return -rc;
-    if (256 % (4 * a->heads) != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
+    const int hr = a->heads_rope > 0 ? a->heads_rope : a->heads;
+    if (256 % (4 * hr) != 0 || 256 % a->heads != 0 || (a->out_dtype != NAF_BF16 && a->out_dtype != NAF_F32)) return 0;
     const int Ho = a->Ho > 0 ? a->Ho : a->H, Wo = a->Wo > 0 ? a->Wo : a->W;
     if (a->H < 2 || a->W < 2 || Ho < a->h || Wo < a->w) return 0;
     {
@@ -453,10 +455,11 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     }
     naf_rope_pool_args rp{};
     rp.x = ws + L.guide; rp.q = L.fused ? nullptr : static_cast<void*>(ws + L.q); rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
-    rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = a->heads; rp.Ho = L.Ho; rp.Wo = L.Wo; rp.h = a->h; rp.w = a->w;
+    const int hrope = a->heads_rope > 0 ? a->heads_rope : a->heads;
+    rp.x_dtype = NAF_BF16; rp.B = a->B; rp.Cq = 256; rp.heads = hrope; rp.Ho = L.Ho; rp.Wo = L.Wo; rp.h = a->h; rp.w = a->w;
     const int64_t xs[4] = {(int64_t)L.Ho * L.Wo * 256, 1, (int64_t)L.Wo * 256, 256};
-    const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / a->heads, (int64_t)a->w * 256, 256};
-    const int64_t qst[4] = {(int64_t)L.Ho * L.Wo * 256, 256 / a->heads, (int64_t)L.Wo * 256, 256};
+    const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / hrope, (int64_t)a->w * 256, 256};
+    const int64_t qst[4] = {(int64_t)L.Ho * L.Wo * 256, 256 / hrope, (int64_t)L.Wo * 256, 256};
     for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = L.fused ? 0 : qst[i]; rp.k_stride[i] = kst[i]; }
     int rc = naf_rope_pool_fwd(&rp, stream);
     if (rc != NAF_OK) return rc;

@@ -411,7 +411,7 @@ class NAF(nn.Module):
             return None
         if image.shape[1] != 3 or self.xna_path != "auto":
             return None
-        if enc.rope.num_heads != self.upsampler.num_heads or features.dtype not in (torch.bfloat16, torch.float32):
+        if features.dtype not in (torch.bfloat16, torch.float32):
             return None
         if image.dtype not in (torch.bfloat16, torch.float32) or features.shape[1] % self.upsampler.num_heads:
             return None
@@ -439,7 +439,7 @@ class NAF(nn.Module):
         plan = ops.ForwardPlan(branches, len(branches[0][4]), eps, enc.rope.tables(ho, wo), image, features,
                                self.upsampler.num_heads, self.upsampler.kernel_size[0],
                                torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32, self.upsampler.scale,
-                               output_size=(ho, wo))
+                               output_size=(ho, wo), heads_rope=enc.rope.num_heads)
         plan = plan if plan.supported else None
         self.__dict__["_plan_cache"] = (key, plan)
         return plan

@@ -444,7 +444,7 @@ class ForwardPlan:
     Built once per (parameter versions, shapes); ``run`` only swaps the image / features / output pointers."""
 
     def __init__(self, branches, nlayer: int, gn_eps: float, tabs, image: torch.Tensor, features: torch.Tensor,
-                 heads: int, ksize: int, out_dtype: torch.dtype, scale: Optional[float], output_size=None):
+                 heads: int, ksize: int, out_dtype: torch.dtype, scale: Optional[float], output_size=None, heads_rope: int = 0):
         lib = _lib.load()
         B, _, H, W = image.shape
         Ho, Wo = (int(output_size[0]), int(output_size[1])) if output_size is not None else (H, W)
@@ -455,6 +455,7 @@ class ForwardPlan:
         a.image_dtype, a.feat_dtype, a.out_dtype = _DT[image.dtype], _DT[features.dtype], _DT[out_dtype]
         a.B, a.H, a.W, a.h, a.w, a.C, a.heads, a.ksize = B, H, W, h, w, Cc, heads, ksize
         a.Ho, a.Wo = Ho, Wo
+        a.heads_rope = int(heads_rope)
         a.gn_eps = float(gn_eps)
         a.scale = float(scale) if scale else 0.0
         self._keep = [tabs]

@@ -1167,3 +1167,21 @@ def test_single_call_forward_return_weights(dev, img_hw, lr, C, ksz):
     ref, ref_w = O.naf_forward(p, img.cpu(), ft.float().cpu(), img_hw, kernel_size=ksz, return_weights=True)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "out with return_weights")
     assert float((wa.cpu() - ref_w).abs().mean()) <= 2e-2
+
+
+@pytest.mark.parametrize("heads_rope,heads_attn", [(1, 4), (8, 2), (2, 4)])
+def test_single_call_forward_with_different_rope_heads(dev, heads_rope, heads_attn):
+    """heads_rope != heads_attn at the default width (naf.py:73-85): naf_forward rotates / pools with the RoPE head split and
+    attends with the attention head split; same bits as the composed path, same values as the oracle."""
+    p = O.make_params(dim=256, heads_rope=heads_rope, seed=51)
+    m = _load_model(dev, p, dim=256, heads_attn=heads_attn, heads_rope=heads_rope, kernel_size=3)
+    img = O.hash_normal((1, 3, 64, 64), 997).to(dev)
+    ft = O.hash_normal((1, 64, 4, 4), 998).to(dev)
+    assert m._forward_plan(img, ft, (64, 64)) is not None
+    a = m(img, ft, (64, 64))
+    m.single_call = False
+    b = m(img, ft, (64, 64))
+    m.single_call = True
+    assert torch.equal(a, b)
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (64, 64), kernel_size=3, heads_attn=heads_attn, heads_rope=heads_rope)
+    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"heads_rope {heads_rope} heads_attn {heads_attn}")
