@@ -1185,3 +1185,47 @@ def test_single_call_forward_with_different_rope_heads(dev, heads_rope, heads_at
     assert torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (64, 64), kernel_size=3, heads_attn=heads_attn, heads_rope=heads_rope)
     assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"heads_rope {heads_rope} heads_attn {heads_attn}")
+
+
+@pytest.mark.parametrize("img_hw,out_hw,lr,C,ksz", [((64, 64), (64, 64), (4, 4), 128, 3), ((96, 80), (48, 40), (6, 5), 64, 5)])
+def test_c_host_program_matches_python(dev, tmp_path, img_hw, out_hw, lr, C, ksz):
+    """examples/c_host.c -- a plain C program (gcc, HIP runtime API, include/naf_hip.h, no Python / torch in the process)
+    -- runs naf_forward on the same parameters and inputs and writes the same bits as the Python module."""
+    import shutil, struct, subprocess
+    from naf_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers on this box")
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include", f"{root}/examples/c_host.c", "-o", exe,
+                    f"-L{libdir}", "-lnaf_hip", "-L/opt/rocm/lib", "-lamdhip64"], check=True, capture_output=True)
+    p = O.make_params(seed=53)
+    m = _load_model(dev, p, kernel_size=ksz)
+    enc = m.image_encoder
+    blob = bytearray()
+    periods = enc.rope.periods.detach().float().cpu().numpy()
+    hdr = [4, enc.encoder[0].kernel_size[0], enc.encoder[1].conv1.kernel_size[0], enc.sem_encoder[0].kernel_size[0],
+           enc.sem_encoder[1].conv1.kernel_size[0], len(periods), 4, 0]
+    blob += struct.pack("<8i", *hdr) + periods.astype("<f4").tobytes()
+    for seq in (enc.encoder, enc.sem_encoder):
+        blob += seq[0].weight.detach().float().cpu().numpy().astype("<f4").tobytes() + seq[0].bias.detach().float().cpu().numpy().astype("<f4").tobytes()
+        for blk in list(seq)[1:]:
+            for norm, conv in ((blk.norm1, blk.conv1), (blk.norm2, blk.conv2)):
+                blob += norm.weight.detach().float().cpu().numpy().astype("<f4").tobytes() + norm.bias.detach().float().cpu().numpy().astype("<f4").tobytes()
+                blob += enc._packed(conv).cpu().view(torch.int16).numpy().astype("<i2").tobytes()
+                blob += conv.bias.detach().float().cpu().numpy().astype("<f4").tobytes()
+    (tmp_path / "params.bin").write_bytes(bytes(blob))
+    img = O.hash_normal((2, 3, *img_hw), 1401)
+    ft = O.hash_normal((2, C, *lr), 1402)
+    (tmp_path / "image.bin").write_bytes(img.numpy().astype("<f4").tobytes())
+    (tmp_path / "features.bin").write_bytes(ft.numpy().astype("<f4").tobytes())
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "image.bin"), str(tmp_path / "features.bin"), str(tmp_path / "out.bin"),
+                        "2", str(img_hw[0]), str(img_hw[1]), str(lr[0]), str(lr[1]), str(C), str(ksz), str(out_hw[0]), str(out_hw[1])],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = torch.from_numpy(np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype="<f4").copy()).view(2, *out_hw, C)
+    ref = m(img.to(dev), ft.to(dev), out_hw)                       # Python host, same library
+    assert ref.dtype == torch.float32 and torch.equal(got, ref.permute(0, 2, 3, 1).cpu().contiguous()), r.stdout
