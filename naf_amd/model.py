@@ -403,8 +403,8 @@ class NAF(nn.Module):
 
     def _forward_plan(self, image, features, output_size):
         """``ops.ForwardPlan`` (one ``naf_forward`` call per forward) when the configuration allows it, else None:
-        default width through the fused stem, image size == output size, equal RoPE / attention heads, rotate-on-load
-        shapes.  Cached until a parameter, the shapes, strides or dtypes change."""
+        default width through the fused stem (any image / output / feature sizes, either head split, return_weights).
+        Cached until a parameter, the shapes, strides or dtypes change."""
         enc = self.image_encoder
         ho, wo = int(output_size[0]), int(output_size[1])
         if not (enc.use_encoder and enc.stem_impl == "hip" and enc._hip_stem_ok() and enc.fuse_conv0 and self.fuse_rope):
