@@ -55,8 +55,9 @@ def make_branch(in_dim: int, hidden: int, kernel_size: int, ks_res: int, num_lay
 
 class RoPE(nn.Module):
     """Holds the `periods` buffer (rope.py:77-81,128-135) and caches the device sin/cos tables per
-    output size, like the reference caches coordinates per (H, W) (rope.py:159-161).  Only the
-    deterministic eval-mode coordinates exist here (train-time shift/jitter/rescale: rope.py:107-124)."""
+    output size, like the reference caches coordinates per (H, W) (rope.py:159-161).  ``tables`` are the deterministic
+    eval-mode tables the HIP kernels read; ``train_tables`` adds the train-time coordinate augmentation (shift / jitter /
+    rescale, rope.py:107-124) for ``NAF.forward_train`` when the module is in training mode."""
 
     def __init__(self, embed_dim: int, num_heads: int, base: float = 100.0, rescale_coords: Optional[float] = None):
         super().__init__()
@@ -66,6 +67,8 @@ class RoPE(nn.Module):
         self.base = base
         self.D_head = embed_dim // num_heads
         self.rescale_coords = rescale_coords
+        self.shift_coords = None          # rope.py:49-51: not set by NAF (naf.py:29), kept for parity of the attribute set
+        self.jitter_coords = None
         d = self.D_head
         periods = base ** (2 * torch.arange(d // 4, dtype=torch.float32) / (d // 2))
         self.register_buffer("periods", periods, persistent=True)
@@ -79,6 +82,29 @@ class RoPE(nn.Module):
             self._tables = ops.rope_tables(p, Ho, Wo)
             self._tables_key = key
         return self._tables
+
+
+def _rope_train_tables(rope: "RoPE", Ho: int, Wo: int):
+    """cos / sin tables [Ho, 2, P], [Wo, 2, P] like ops.rope_tables, with the reference's train-time augmentation of the
+    coordinates (rope.py:107-124): one uniform shift per axis, one log-uniform jitter per axis, one log-uniform rescale for
+    both, drawn per call while ``rope.training``.  'separate' normalisation (rope.py:98-100)."""
+    import math
+    p = rope.periods
+    dev = p.device
+    cy = 2.0 * (torch.arange(Ho, device=dev, dtype=torch.float32) + 0.5) / Ho - 1.0
+    cx = 2.0 * (torch.arange(Wo, device=dev, dtype=torch.float32) + 0.5) / Wo - 1.0
+    if rope.training and rope.shift_coords is not None:
+        sh = torch.empty(2, device=dev).uniform_(-rope.shift_coords, rope.shift_coords)
+        cy, cx = cy + sh[0], cx + sh[1]
+    if rope.training and rope.jitter_coords is not None:
+        j = torch.empty(2, device=dev).uniform_(-math.log(rope.jitter_coords), math.log(rope.jitter_coords)).exp()
+        cy, cx = cy * j[0], cx * j[1]
+    if rope.training and rope.rescale_coords is not None:
+        r = torch.empty(1, device=dev).uniform_(-math.log(rope.rescale_coords), math.log(rope.rescale_coords)).exp()
+        cy, cx = cy * r, cx * r
+    ay = (2.0 * math.pi * cy)[:, None] / p[None, :]                                   # rope.py:139
+    ax = (2.0 * math.pi * cx)[:, None] / p[None, :]
+    return torch.stack([ay.cos(), ay.sin()], dim=1), torch.stack([ax.cos(), ax.sin()], dim=1)
 
 
 class _GroupNormTrain(torch.autograd.Function):
@@ -452,8 +478,8 @@ class NAF(nn.Module):
         """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
         and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
-        differentiate them (the fused inference stem has no backward).  Deterministic eval-mode RoPE coordinates
-        (the reference's train-time coordinate jitter, rope.py:107-124, is not implemented).  Needs the shapes
+        differentiate them (the fused inference stem has no backward).  In ``.train()`` mode the RoPE coordinates get the
+        reference's random rescale (rope.py:107-124, NAF's rope_rescale); in ``.eval()`` mode they are deterministic.  Needs the shapes
         ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9).
         ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
         mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32."""
@@ -475,7 +501,8 @@ class NAF(nn.Module):
         if x.shape[-2:] != (ho, wo):
             x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
-        tab_y, tab_x = enc.rope.tables(ho, wo)                                 # [Ho, 2, P], [Wo, 2, P]
+        # [Ho, 2, P], [Wo, 2, P]; in training mode with the reference's coordinate augmentation (rope.py:107-124)
+        tab_y, tab_x = _rope_train_tables(enc.rope, ho, wo) if enc.rope.training else enc.rope.tables(ho, wo)
         B, Cq = x.shape[:2]
         D = Cq // heads_rope
         cos = torch.cat([tab_y[:, 0, None, :].expand(ho, wo, -1), tab_x[None, :, 0, :].expand(ho, wo, -1)], dim=-1)

@@ -1229,3 +1229,27 @@ def test_c_host_program_matches_python(dev, tmp_path, img_hw, out_hw, lr, C, ksz
     got = torch.from_numpy(np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype="<f4").copy()).view(2, *out_hw, C)
     ref = m(img.to(dev), ft.to(dev), out_hw)                       # Python host, same library
     assert ref.dtype == torch.float32 and torch.equal(got, ref.permute(0, 2, 3, 1).cpu().contiguous()), r.stdout
+
+
+def test_forward_train_rope_augmentation(dev):
+    """forward_train in .train() mode draws the reference's coordinate rescale (rope.py:117-122) per call; in .eval() mode
+    its torch tables are the tables the HIP kernels use."""
+    import naf_amd.model as M
+    p = O.make_params(seed=55)
+    m = _load_model(dev, p, kernel_size=3)
+    ty, tx = m.image_encoder.rope.tables(48, 64)
+    ey, ex = M._rope_train_tables(m.image_encoder.rope, 48, 64)
+    assert float((ty - ey).abs().max()) <= 2e-6 and float((tx - ex).abs().max()) <= 2e-6
+    img = O.hash_normal((1, 3, 64, 64), 1501).to(dev)
+    ft = O.hash_normal((1, 128, 4, 4), 1502).to(dev)
+    a = m.forward_train(img, ft, (64, 64))
+    a2 = m.forward_train(img, ft, (64, 64))                                   # eval: same coordinates (MIOpen may pick another
+    assert float((a.float() - a2.float()).abs().max()) <= 2e-2                # convolution algorithm from call to call)
+    m.train()
+    torch.manual_seed(0)
+    b1 = m.forward_train(img, ft, (64, 64))
+    b2 = m.forward_train(img, ft, (64, 64))
+    assert torch.isfinite(b1).all()
+    assert float((b1.float() - b2.float()).abs().mean()) > 1e-3 and float((a.float() - b1.float()).abs().mean()) > 1e-3   # a new rescale per call
+    b1.float().sum().backward()                                                # and it is differentiable
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.image_encoder.parameters() if q.requires_grad)
