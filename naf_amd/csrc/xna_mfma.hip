@@ -76,6 +76,12 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
         return NAF_ERR_INVALID;
     }
     p.nblocks = (uint32_t)nb;
+    // dispatch order in groups of 16 workgroups per XCD turn (xna_block_order; profiles/r02_hbm_ceiling.txt: all XCDs
+    // sweep the same cell rows, +5..9 % over one band of cell rows per XCD); NAF_XNA_ORDER=0 restores the bands (A/B knob)
+    static const int order = [] { const char* e = getenv("NAF_XNA_ORDER"); return e ? atoi(e) : 16; }();
+    p.order = order;
+    static const int rope_lds = [] { const char* e = getenv("NAF_XNA_ROPE_LDS"); return e ? atoi(e) : 1; }();   // A/B knob
+    p.rope_lds = rope_lds;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.scale = scale;
     for (int i = 0; i < 4; ++i) {

@@ -38,6 +38,8 @@ struct XnaMfmaParams {
     const float* tab_y;  // rotate-on-load: RoPE tables [Ho][2][16] / [Wo][2][16], or nullptr
     const float* tab_x;
     int32_t B, heads, Ho, Wo, h, w, dy, dx, nchunk;
+    int32_t rope_lds;    // rotate-on-load: RoPE tables of the cell through LDS (rows) / registers (columns) instead of per-tile loads
+    int32_t order;       // workgroup order (xna_block_order): 0 = one band of cell rows per XCD, g > 0 = dispatch order in groups of g
     uint32_t nblocks;
     float scale_log2e, scale;
     int64_t qs[4], ks[4], vs[4], os[4];  // {b, head, y, x} element strides
@@ -61,10 +63,29 @@ struct XnaVRow {
     static constexpr int VROW = DVT + 16;  // bf16 elements per V row in LDS (row stride = 8 banks mod 64 for DVT%64==0..)
 };
 
+// Per-wave output staging tile [16 px][DVT] bf16 (staged stores).  Rows of a multiple of 128 bytes are stored unpadded
+// with the 16-byte chunk index XOR-swizzled by the pixel (conflict-free ds_write_b128 / ds_read_b128, 1 KiB less LDS per
+// workgroup than padding: what lets the row RoPE tables below share the LDS at 3 workgroups per CU); other widths are padded.
+#ifdef NAF_XNA_NO_SWIZZLE      // A/B build: padded staging tiles everywhere
+constexpr int xna_stage_row(int dvt) { return dvt + 8; }
+#else
+constexpr int xna_stage_row(int dvt) { return ((dvt / 8) % 8 == 0) ? dvt : dvt + 8; }
+#endif
+template <int DVT>
+struct XnaStageTile {
+    static constexpr int VCH = DVT / 8;
+    static constexpr int OROW = xna_stage_row(DVT);
+    static constexpr bool SWZ = OROW == DVT;
+    __device__ static __forceinline__ int offset(int px, int chunk) { return px * OROW + (SWZ ? (chunk ^ (px & 7)) : chunk) * 8; }
+};
+constexpr int XNA_ROPE_ROWS = 16;   // cell rows whose RoPE row tables ride in LDS (rotate-on-load, cells of <= 16 x 16 px)
+
 // LDS bytes: K window [NSLOT][64+8] + V window [NSLOT][dvt+16] (pad key slots are NOT stored: their reads are
-// clamped to the last real row, P is exactly 0 there) + optional per-wave output staging [4][16][dvt+8].
+// clamped to the last real row, P is exactly 0 there) + optional per-wave output staging tiles + (staged) the cell's
+// RoPE row tables [16][32] fp32.
 constexpr size_t xna_mfma_lds_for(int ks, int cb, int dvt, bool staged, int nw = 4) {
-    return (size_t)((ks + cb - 1) * (ks + cb - 1)) * (72 + dvt + 16) * 2 + (staged ? (size_t)nw * 16 * (dvt + 8) * 2 : 0);
+    return (size_t)((ks + cb - 1) * (ks + cb - 1)) * (72 + dvt + 16) * 2 +
+           (staged ? (size_t)nw * 16 * xna_stage_row(dvt) * 2 + (size_t)XNA_ROPE_ROWS * 32 * 4 : 0);
 }
 template <int KS, int CB, int DVT, bool STG, int NW = 4>
 constexpr size_t xna_mfma_lds_bytes() {
@@ -80,6 +101,24 @@ __host__ __device__ inline bool xna_row_tiles_ok(int dx) {
     return pad * 6 <= dx;
 }
 
+// Logical workgroup id of hardware block `bid` (the hardware places block b on XCD b % 8).
+//   order 0: every XCD owns one contiguous band of logical ids (neighbouring K/V windows meet in one L2, but the chip
+//            writes into 8 far-apart address windows at once);
+//   order g > 0: dispatch order in groups of g: XCD x takes logical ids [8g*j + x*g, +g) for j = 0, 1, ... -- all XCDs
+//            sweep the SAME few cell rows together (one compact, moving address window: what streams fastest through
+//            HBM, profiles/r02_hbm_ceiling.txt) while g consecutive workgroups (neighbouring cells, whose K/V windows
+//            overlap 6/7) still share an L2.  g = 1 is plain dispatch order.  Falls back to g = 1 when n % 8g != 0.
+__device__ __forceinline__ uint32_t xna_block_order(uint32_t bid, uint32_t n, int order, uint32_t per) {
+    (void)per;
+    if (order == 0) return naf_xcd_remap(bid, n);
+    const uint32_t g = (uint32_t)order;
+    if (g > 1u && (n % (8u * g)) == 0u) {
+        const uint32_t xcd = bid & 7u, idx = bid >> 3;
+        return ((idx / g) * 8u + xcd) * g + idx % g;
+    }
+    return bid;
+}
+
 __device__ __forceinline__ void xna_store4(bf16_t* dst, f32x4_t v) {
     bf16x4_t o;
     o[0] = (bf16_t)v[0];
@@ -93,6 +132,15 @@ __device__ __forceinline__ void xna_store4(float* dst, f32x4_t v) { *reinterpret
 // ABL: ablation bits for tools/xna_probe.hip only (the library instantiates ABL = 0):
 //   1 no output stores, 2 no PV MFMAs / V reads, 4 no Q loads, 8 no K/V staging loads, 16 no QK MFMAs,
 //   64 narrow (8 B / lane) bf16 stores on the unstaged path
+//   128 phase timing (tools/xna_probe.hip): s_memtime deltas, one uint64[8] record per wave at p.logits:
+//       [0] entry -> windows staged, [1] tile top -> QK^T + softmax done, [2] PV + LDS tile written, [3] stores issued,
+//       [4] prefetch consumed (end of tile), [5] tiles, [6] whole workgroup
+#define XNA_TSTAMP(var)                                   \
+    if constexpr ((ABL & 128) != 0) {                     \
+        __builtin_amdgcn_sched_barrier(0);                \
+        var = __builtin_readcyclecounter();               \
+        __builtin_amdgcn_sched_barrier(0);                \
+    }
 template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4, int TPW = 1>
 __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p) {
     constexpr int NT = NW * 64;  // threads per workgroup
@@ -101,13 +149,17 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     constexpr int VROW = XnaVRow<DVT>::VROW;
     constexpr int CT = DVT / 16;
     constexpr int VCH = DVT / 8;  // 16-byte chunks per V row
-    constexpr int OROW = DVT + 8;
+    using ST = XnaStageTile<DVT>;
+    constexpr int OROW = ST::OROW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NSLOT * KROW;
-    bf16_t* Os = Vs + NSLOT * VROW;  // [NW waves][16][DVT + 8] when STG
+    bf16_t* Os = Vs + NSLOT * VROW;  // [NW waves][16][OROW] when STG
+    float* Ty = reinterpret_cast<float*>(Os + NW * 16 * OROW);   // STG: RoPE row tables of the cell [XNA_ROPE_ROWS][2][16]
 
+    uint64_t ts_in = 0, ts_staged = 0, ts_acc[5] = {0, 0, 0, 0, 0};
+    XNA_TSTAMP(ts_in)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile bookkeeping runs on the SALU
@@ -115,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     const int grp = lane >> 4;  // MFMA k-group / result row group
 
     const int bh = (p.h + CB - 1) / CB, bw = (p.w + CB - 1) / CB;  // blocks of CB x CB cells
-    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    uint32_t L = xna_block_order(blockIdx.x, p.nblocks, p.order, (uint32_t)(p.heads * p.nchunk));
     const int chunk = L % p.nchunk;
     L /= p.nchunk;
     const int head = L % p.heads;
@@ -179,42 +231,59 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
 
     // ---- stage the K and V windows (L2 -> registers -> LDS).  Slots outside the grid (only possible for the
     // extra row / column of a CB = 2 window at the border) load a clamped cell; no query attends to them.
+    // ALL loads of a batch are issued (clamped chunk index, no branch) before the first LDS write: a load behind a
+    // per-chunk `if` is followed by its own s_waitcnt vmcnt(0) -- seven dependent L2 round trips (9 us of a 21 us
+    // workgroup at k = 7, profiles/r02_xna_phase_timing.txt) instead of one.
     {
         const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
-        constexpr int KTOT = NSLOT * 8;
-#pragma unroll
-        for (int it = 0; it < (KTOT + NT - 1) / NT; ++it) {
-            const int i = it * NT + tid;
-            if ((KTOT % NT == 0) || i < KTOT) {
-                const int key = i >> 3, c = i & 7;
-                u32x4_t val = {0u, 0u, 0u, 0u};
-                if (!(ABL & 8)) {
-                    const int ry = key / WS, rx = key - ry * WS;
-                    const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
-                    val = *reinterpret_cast<const u32x4_t*>(kb + (int64_t)yy * p.ks[2] + (int64_t)xx * p.ks[3] + c * 8);
-                }
-                *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) = val;
-            }
-        }
         const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
-        constexpr int VTOT = NSLOT * VCH;
+        constexpr int KTOT = NSLOT * 8, VTOT = NSLOT * VCH;
+        constexpr int KIT = (KTOT + NT - 1) / NT, VIT = (VTOT + NT - 1) / NT;
+        constexpr int BATCH = 12;                       // 16-byte loads in flight per thread (48 registers)
+        // rotate-on-load with cells of <= 16 x 16 px: the cell's row tables go to LDS here, its column tables to registers
+        // below -- per-tile table loads through the (store-laden) vector memory path cost 0.04 ms at G1
+        const bool rope_lds = STG && CB == 1 && p.rope_lds && p.tab_y != nullptr && p.dy <= XNA_ROPE_ROWS && p.dx <= 16;
+        f32x4_t tyv = {0.f, 0.f, 0.f, 0.f};
+        if (rope_lds && tid < p.dy * 8) tyv = *reinterpret_cast<const f32x4_t*>(p.tab_y + (int64_t)(cy0 * p.dy + (tid >> 3)) * 32 + (tid & 7) * 4);
+        auto src_of = [&](int j) __attribute__((always_inline)) -> const bf16_t* {   // j < KIT: K chunk, else V chunk
+            if (j < KIT) {
+                const int i = min(j * NT + tid, KTOT - 1);
+                const int key = i >> 3, c = i & 7;
+                const int ry = key / WS, rx = key - ry * WS;
+                const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
+                return kb + (int64_t)yy * p.ks[2] + (int64_t)xx * p.ks[3] + c * 8;
+            }
+            const int i = min((j - KIT) * NT + tid, VTOT - 1);
+            const int key = i / VCH, c = i - key * VCH;
+            const int ry = key / WS, rx = key - ry * WS;
+            const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
+            return vb + (int64_t)yy * p.vs[2] + (int64_t)xx * p.vs[3] + c * 8;
+        };
 #pragma unroll
-        for (int it = 0; it < (VTOT + NT - 1) / NT; ++it) {
-            const int i = it * NT + tid;
-            if ((VTOT % NT == 0) || i < VTOT) {
-                const int key = i / VCH, c = i - key * VCH;
-                u32x4_t val = {0u, 0u, 0u, 0u};
-                if (!(ABL & 8)) {
-                    const int ry = key / WS, rx = key - ry * WS;
-                    const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
-                    val = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)yy * p.vs[2] + (int64_t)xx * p.vs[3] + c * 8);
+        for (int j0 = 0; j0 < KIT + VIT; j0 += BATCH) {
+            u32x4_t val[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                if (j0 + u < KIT + VIT) val[u] = (ABL & 8) ? u32x4_t{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(src_of(j0 + u));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int j = j0 + u;
+                if (j < KIT) {
+                    const int i = j * NT + tid;
+                    if ((KTOT % NT == 0) || i < KTOT) *reinterpret_cast<u32x4_t*>(Ks + (i >> 3) * KROW + (i & 7) * 8) = val[u];
+                } else if (j < KIT + VIT) {
+                    const int i = (j - KIT) * NT + tid;
+                    const int key = i / VCH, c = i - key * VCH;
+                    if ((VTOT % NT == 0) || i < VTOT) *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) = val[u];
                 }
-                *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) = val;
             }
         }
+        if (rope_lds && tid < p.dy * 8) *reinterpret_cast<f32x4_t*>(Ty + (tid >> 3) * 32 + (tid & 7) * 4) = tyv;
     }
     const bool rope = p.tab_y != nullptr;   // rotate-on-load (host guarantees the FAST path then)
     __syncthreads();
+    XNA_TSTAMP(ts_staged)
 
     // key slots >= NSLOT are not stored: clamp their row to the last real key (their logits are masked, P = 0)
     auto ka_of = [&](int mt) __attribute__((always_inline)) {   // K row mt*16 + col, 8 d's at ks*32 + grp*8
@@ -237,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const int i = min(it * 64 + lane, NCH - 1);
         const int pp = i / VCH, ch = i - pp * VCH;
         st_pp[it] = pp;
-        st_lds[it] = pp * OROW + ch * 8;
+        st_lds[it] = ST::offset(pp, ch);
         st_goff[it] = (uint32_t)(pp * (int)p.os[3] + ch * 8) * (uint32_t)sizeof(OutT);
     }
     const uint32_t o_lane = (uint32_t)(col * (int)p.os[3]) * (uint32_t)sizeof(OutT);   // unstaged: this lane's pixel
@@ -250,6 +319,11 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     // NEXT tile are fetched from LDS at the top of an iteration and applied at its bottom, when the prefetched
     // queries have landed, so neither latency sits on the tile's critical path.
     auto rope_fetch = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 256) != 0) {   // probe: no table loads
+            cs[0] = cs[1] = f32x4_t{0.6f, 0.6f, 0.6f, 0.6f};
+            cs[2] = cs[3] = f32x4_t{0.8f, 0.8f, 0.8f, 0.8f};
+            return;
+        }
         const int ttc = min(tt, ttot - 1);
         const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
         // straight from the tables (128 KB each, L1/L2-resident): an LDS copy would cost the third resident workgroup
@@ -260,6 +334,10 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
     };
     auto rope_apply = [&](bf16x8_t (&qv)[2], const f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 512) != 0) {   // probe: tables fetched but not applied
+            asm volatile("" ::"v"(cs[0]), "v"(cs[1]), "v"(cs[2]), "v"(cs[3]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float o1, o2;
@@ -269,15 +347,54 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         }
     };
 
-    auto tile_loop = [&](auto fastc, auto ropec) __attribute__((always_inline)) {
+    auto tile_loop = [&](auto fastc, auto ropec, auto rlc) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fastc)::value && (CB == 1);
         constexpr bool ROPE = FAST && decltype(ropec)::value;
+        constexpr bool RL = ROPE && STG && decltype(rlc)::value;    // tables from LDS (rows) / registers (columns)
+        // RL: one tile per cell row (dx <= 16): the column angles of this lane's pixel are the same for every tile
+        f32x4_t csx[4] = {};
+        if constexpr (RL) {
+            const float* tr = p.tab_x + (int64_t)(cx0 * p.dx + min(col, p.dx - 1)) * 32 + (grp & 1) * 8;
+            csx[0] = *reinterpret_cast<const f32x4_t*>(tr);
+            csx[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
+            csx[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
+            csx[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
+        }
+        auto rope_tab = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {   // RL: tile tt = cell row tt
+            const float* tr = Ty + min(tt, ttot - 1) * 32 + (grp & 1) * 8;
+            const f32x4_t l0 = *reinterpret_cast<const f32x4_t*>(tr), l1 = *reinterpret_cast<const f32x4_t*>(tr + 4);
+            const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(tr + 16), l3 = *reinterpret_cast<const f32x4_t*>(tr + 20);
+            const bool rowpart = grp < 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                cs[0][i] = rowpart ? l0[i] : csx[0][i];
+                cs[1][i] = rowpart ? l1[i] : csx[1][i];
+                cs[2][i] = rowpart ? l2[i] : csx[2][i];
+                cs[3][i] = rowpart ? l3[i] : csx[3][i];
+            }
+        };
         if constexpr (ROPE) {
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 f32x4_t cs0[4];
-                rope_fetch(wave * TPW + u, cs0);
+                if constexpr (RL) rope_tab(wave * TPW + u, cs0);
+                else rope_fetch(wave * TPW + u, cs0);
                 rope_apply(qf[u], cs0);
+            }
+        }
+        // PF2: the queries of the tile after next are requested at the top of an iteration, so the ones consumed at its bottom
+        // have been in flight for two tile times (one is not enough behind a CU's queue of row stores: the wave sat
+        // 1.8 k of its 6.3 k cycles per tile waiting for them, profiles/r02_xna_phase_timing.txt).  Needs tables that do not
+        // travel with the queries (no rope, or the LDS / register tables).
+        // Measured (interleaved A/B, tools/xna_probe ... ab): 4-wave workgroups (4 tiles per wave at 16 x 16 cells) gain 5 %
+        // with rotate-on-load and nothing without; 8-wave workgroups have two tiles per wave and lose.
+        constexpr bool PF2 = FAST && TPW == 1 && NW == 4 && (!ROPE || RL) && !(ABL & 1024);
+        bf16x8_t q2[2] = {};
+        if constexpr (PF2) {
+            const bf16_t* qp = q_ptr_fast(wave + NW);
+            if (!(ABL & 4)) {
+                q2[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                q2[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
             }
         }
         for (int tb = wave * TPW; tb < ttot; tb += NW * TPW) {
@@ -285,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             bf16x8_t qn[TPW][2];
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
-                const bf16_t* qp = FAST ? q_ptr_fast(tb + NW * TPW + u) : q_ptr(tb + NW * TPW + u);
+                const bf16_t* qp = FAST ? q_ptr_fast(tb + (PF2 ? 2 : 1) * NW * TPW + u) : q_ptr(tb + NW * TPW + u);
                 if (!(ABL & 4)) {
                     qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
                     qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
@@ -294,11 +411,13 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 }
             }
             f32x4_t csn[TPW][4];
-            if constexpr (ROPE) {
+            if constexpr (ROPE && !RL) {
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) rope_fetch(tb + NW * TPW + u, csn[u]);
             }
             __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued first: it has the whole tile to land
+            uint64_t t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0;
+            XNA_TSTAMP(t_a)
             // per-tile bookkeeping: cell of the tile, its own window inside the staged (union) window
             int cyv[TPW], cxv[TPW], tv[TPW], oyv[TPW], oxv[TPW];
 #pragma unroll
@@ -333,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             }
 
             // ---- return_weights: the scaled scores, key order = row-major window (attentions.py:21-28) ----
-            if (p.logits != nullptr && chunk == 0) {
+            if (!(ABL & 128) && p.logits != nullptr && chunk == 0) {
                 typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
@@ -419,6 +538,11 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     for (int j = 0; j < 8; ++j) pf[u][ks][j] = (bf16_t)s[u][2 * ks + (j >> 2)][j & 3];
             }
 
+            if constexpr ((ABL & 128) != 0) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) asm volatile("" ::"v"(pf[u][0]), "v"(pf[u][KST - 1]));
+            }
+            XNA_TSTAMP(t_b)
             // ---- O^T = V^T . P^T, store ----
             // FAST: o_tile = first pixel of the tile (uniform); generic: per-lane pixel pointer
             OutT* obv[TPW];      // cell origin (generic) / tile origin (FAST)
@@ -470,7 +594,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 // DVT*2-byte contiguous runs (full 128-byte lines) instead of 64 scattered 16-byte pieces.
                 static_assert(sizeof(OutT) == 2 && (CT % 2) == 0 && TPW == 1, "staged stores: bf16, even tile count, one tile");
                 bf16_t* ow = Os + wave * 16 * OROW;
-                bf16_t* owl = ow + col * OROW + (grp & 1) * 16 + (grp >> 1) * 8;
+                const int ochunk = (grp & 1) * 2 + (grp >> 1);   // this lane's 16-byte chunk inside a pair of channel tiles
 #pragma unroll
                 for (int ct = 0; ct < CT; ct += 2) {
                     f32x4_t a[TPW], bq[TPW];
@@ -485,9 +609,10 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
                     const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                    *reinterpret_cast<u32x4_t*>(owl + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    *reinterpret_cast<u32x4_t*>(ow + ST::offset(col, ct * 2 + ochunk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
                 }
                 const int t0 = tv[0] * 16;
+                XNA_TSTAMP(t_c)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
@@ -553,14 +678,34 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             // keep the consumption of the prefetch (and its vmcnt wait) BELOW this tile's stores: hoisted above
             // them, the wait would also cover the previous tile's stores
             __builtin_amdgcn_sched_barrier(0);
+            XNA_TSTAMP(t_d)
+            if constexpr (PF2) {
+                qf[0][0] = q2[0];
+                qf[0][1] = q2[1];
+                q2[0] = qn[0][0];
+                q2[1] = qn[0][1];
+            } else {
 #pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                qf[u][0] = qn[u][0];
-                qf[u][1] = qn[u][1];
+                for (int u = 0; u < TPW; ++u) {
+                    qf[u][0] = qn[u][0];
+                    qf[u][1] = qn[u][1];
+                }
             }
-            if constexpr (ROPE) {
+            if constexpr (RL) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    rope_tab(tb + NW * TPW + u, csn[u]);
+                    rope_apply(qf[u], csn[u]);
+                }
+            } else if constexpr (ROPE) {
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) rope_apply(qf[u], csn[u]);
+            }
+            if constexpr ((ABL & 128) != 0) {
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) asm volatile("" ::"v"(qf[u][0]), "v"(qf[u][1]));
+                XNA_TSTAMP(t_e)
+                ts_acc[0] += t_b - t_a; ts_acc[1] += t_c - t_b; ts_acc[2] += t_d - t_c; ts_acc[3] += t_e - t_d; ts_acc[4] += 1;
             }
         }
         // Drain the (unused) prefetch of the tile after the last one HERE, per loop instance.  The three instances
@@ -569,14 +714,30 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         // then waits for vmcnt(0) -- i.e. for the previous tile's six row stores -- at the top of EVERY iteration.
         // An asm that reads the prefetched registers makes the compiler put the wait at this exit; the instance
         // number keeps the three copies from being tail-merged into one block at the end of the kernel.
-        constexpr int LOOP_ID = FAST ? (ROPE ? 2 : 1) : 0;
+        constexpr int LOOP_ID = FAST ? (ROPE ? (RL ? 3 : 2) : 1) : 0;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) asm volatile("; xna tile loop %0 drained" ::"n"(LOOP_ID), "v"(qf[u][0]), "v"(qf[u][1]));
+        if constexpr (PF2) asm volatile("; xna tile loop %0 drained (2nd prefetch)" ::"n"(LOOP_ID), "v"(q2[0]), "v"(q2[1]));
     };
     // (the host only passes tables when the FAST conditions hold)
-    if (fast && rope) tile_loop(std::true_type{}, std::true_type{});
-    else if (fast) tile_loop(std::true_type{}, std::false_type{});
-    else tile_loop(std::false_type{}, std::false_type{});
+    const bool rope_lds = STG && CB == 1 && p.rope_lds && rope && p.dy <= XNA_ROPE_ROWS && p.dx <= 16;
+    if (fast && rope && rope_lds) tile_loop(std::true_type{}, std::true_type{}, std::true_type{});
+    else if (fast && rope) tile_loop(std::true_type{}, std::true_type{}, std::false_type{});
+    else if (fast) tile_loop(std::true_type{}, std::false_type{}, std::false_type{});
+    else tile_loop(std::false_type{}, std::false_type{}, std::false_type{});
+    if constexpr ((ABL & 128) != 0) {
+        uint64_t ts_out = 0;
+        XNA_TSTAMP(ts_out)
+        if (lane == 0) {
+            // one private 64-byte record per wave (no atomics: 0.5 M same-address atomics would take milliseconds)
+            unsigned long long* tm = reinterpret_cast<unsigned long long*>(p.logits) + ((size_t)blockIdx.x * NW + wave) * 8;
+            tm[0] = ts_staged - ts_in;
+            for (int i = 0; i < 4; ++i) tm[1 + i] = ts_acc[i];
+            tm[5] = ts_acc[4];
+            tm[6] = ts_out - ts_in;
+            tm[7] = 1ull;
+        }
+    }
 }
 
 template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4>
@@ -616,9 +777,12 @@ struct XnaMfmaPlan {
 // Windows of 11x11 and up are LDS/MFMA-bound (G2, k = 11 / 15): pair the tiles.  Smaller windows are HBM-bound
 // and prefer the staged whole-row stores (one tile at a time).
 constexpr int xna_mfma_tpw(int ks) { return ks >= 11 ? 2 : 1; }
-// Workgroups whose windows fill more than half the LDS run alone on a CU: give them 8 waves (2 per SIMD).
+// Workgroups whose windows fill more than half the LDS run alone on a CU: give them 8 waves (2 per SIMD).  Staged plans
+// whose 4-wave workgroups fit only three times per CU (12 waves; registers allow 16) take 8 waves when two such workgroups
+// fit: G1 with rotate-on-load 0.472 -> 0.436 ms (the kernel is bound by waves in flight x bytes per tile / tile latency).
 constexpr int xna_mfma_nw(int ks, int cb, int dvt, bool staged) {
-    return (!staged && xna_mfma_lds_for(ks, cb, dvt, false) > 80 * 1024) ? 8 : 4;
+    if (!staged) return xna_mfma_lds_for(ks, cb, dvt, false) > 80 * 1024 ? 8 : 4;
+    return ((160 * 1024) / xna_mfma_lds_for(ks, cb, dvt, true, 4) < 4 && xna_mfma_lds_for(ks, cb, dvt, true, 8) <= 80 * 1024) ? 8 : 4;
 }
 
 // The largest Dv tile that divides Dv and fits 160 KiB; 2x2 cell blocks when free (KS = 7, 15) and they fit;

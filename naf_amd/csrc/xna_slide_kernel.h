@@ -26,10 +26,14 @@ struct XnaSlideParams {
     int32_t seg_len;   // cells per segment
 };
 
-template <int KS, int DVT, typename OutT, int NW, bool ROPE>
+// TPWV = tiles a wave processes together (2: large windows, every K / V^T fragment feeds two MFMAs; 1: HBM-bound small
+// windows).  STG (bf16 output, TPWV == 1): whole-row stores through a per-wave LDS tile, as in xna_mfma_kernel.
+// ABL: ablation bits for tools/xna_probe.hip (1 no output stores, 4 no query loads, 8 no window column loads).
+template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams sp) {
     const XnaMfmaParams& p = sp.m;
-    constexpr int NT = NW * 64, TPW = 2;
+    constexpr int NT = NW * 64, TPW = TPWV;
+    static_assert(!STG || (TPWV == 1 && sizeof(OutT) == 2 && (DVT % 32) == 0), "staged stores: bf16, one tile per wave, even channel-tile count");
     using G = XnaGeom<KS, 1>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW;
     constexpr int VROW = XnaVRow<DVT>::VROW;
@@ -40,12 +44,15 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NSLOT * KROW;
+    bf16_t* Os = Vs + NSLOT * VROW;                     // STG: [NW waves][16][OROW]
+    using ST = XnaStageTile<DVT>;
+    constexpr int OROW = ST::OROW;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, grp = lane >> 4;
 
-    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    uint32_t L = xna_block_order(blockIdx.x, p.nblocks, p.order, (uint32_t)(p.heads * p.nchunk));
     const int chunk = L % p.nchunk;
     L /= p.nchunk;
     const int head = L % p.heads;
@@ -103,26 +110,57 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         const bf16_t* qp = q_ptr(wave * TPW + u);
-        qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
-        qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+        if (!(ABL & 4)) {
+            qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+            qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+        } else {
+            qf[u][0] = qf[u][1] = bf16x8_t{};
+        }
     }
 
     // ---- full window of the segment's first cell; low-res column x -> column slot x % KS ----
     const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
     const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
     {
+        // all loads of a batch are issued before the first LDS write (see xna_mfma_kernel.h: a load behind a per-chunk
+        // branch costs one L2 round trip EACH)
         const int x0 = win_x0(cx_lo);
-        for (int i = tid; i < NSLOT * 8; i += NT) {
-            const int key = i >> 3, c = i & 7;
-            const int ry = key / KS, xc = x0 + (key - ry * KS);
-            *reinterpret_cast<u32x4_t*>(Ks + (ry * KS + xc % KS) * KROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)xc * p.ks[3] + c * 8);
-        }
-        for (int i = tid; i < NSLOT * VCH; i += NT) {
+        constexpr int KTOT = NSLOT * 8, VTOT = NSLOT * VCH;
+        constexpr int KIT = (KTOT + NT - 1) / NT, VIT = (VTOT + NT - 1) / NT;
+        constexpr int BATCH = 12;
+        auto chunk_of = [&](int j, int& lds_off) __attribute__((always_inline)) -> const bf16_t* {
+            if (j < KIT) {
+                const int i = min(j * NT + tid, KTOT - 1);
+                const int key = i >> 3, c = i & 7;
+                const int ry = key / KS, xc = x0 + (key - ry * KS);
+                lds_off = (ry * KS + xc % KS) * KROW + c * 8;
+                return kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)xc * p.ks[3] + c * 8;
+            }
+            const int i = min((j - KIT) * NT + tid, VTOT - 1);
             const int key = i / VCH, c = i - key * VCH;
             const int ry = key / KS, xc = x0 + (key - ry * KS);
-            *reinterpret_cast<u32x4_t*>(Vs + (ry * KS + xc % KS) * VROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)xc * p.vs[3] + c * 8);
+            lds_off = NSLOT * KROW + (ry * KS + xc % KS) * VROW + c * 8;
+            return vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)xc * p.vs[3] + c * 8;
+        };
+#pragma unroll
+        for (int j0 = 0; j0 < KIT + VIT; j0 += BATCH) {
+            u32x4_t val[BATCH];
+            int off[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (j0 + u < KIT + VIT) {
+                    const bf16_t* src = chunk_of(j0 + u, off[u]);
+                    val[u] = (ABL & 8) ? u32x4_t{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(src);
+                }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int j = j0 + u;
+                if (j < KIT + VIT) {
+                    const int i = (j < KIT ? j : j - KIT) * NT + tid;      // clamped duplicates rewrite the last chunk: harmless
+                    (void)i;
+                    *reinterpret_cast<u32x4_t*>(Ks + off[u]) = val[u];
+                }
+            }
         }
     }
     if constexpr (ROPE) {
@@ -148,6 +186,19 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
         return Vs + row * VROW + (col & 3) * 4;
     };
 
+    // staged stores: 16-byte chunk i = it*64 + lane of the wave's [16 px][DVT] tile (see xna_mfma_kernel.h)
+    constexpr int NCH = 16 * VCH;
+    constexpr int NIT = STG ? (NCH + 63) / 64 : 1;
+    int st_lds[NIT];
+    uint32_t st_goff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(it * 64 + lane, NCH - 1);
+        const int pp = i / VCH, ch = i - pp * VCH;
+        st_lds[it] = ST::offset(pp, ch);
+        st_goff[it] = (uint32_t)(pp * (int)p.os[3] + ch * 8) * (uint32_t)sizeof(OutT);
+    }
+
     const int pass_tiles = NW * TPW;
     const int npass = (ntile + pass_tiles - 1) / pass_tiles;
     for (int cx = cx_lo; cx < cx_hi; ++cx) {
@@ -166,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 const int slot = ry * KS + xn % KS;
                 const bf16_t* src = (c < 8) ? kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)xn * p.ks[3] + c * 8
                                             : vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)xn * p.vs[3] + (c - 8) * 8;
-                dl[n] = *reinterpret_cast<const u32x4_t*>(src);
+                dl[n] = (ABL & 8) ? u32x4_t{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(src);
                 dl_lds[n] = (i < DCH) ? ((c < 8) ? slot * KROW + c * 8 : NSLOT * KROW + slot * VROW + (c - 8) * 8) : -1;
             }
         }
@@ -181,8 +232,12 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 const bf16_t* qp = q_ptr(gnext + u);
-                qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
-                qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+                if (!(ABL & 4)) {
+                    qn[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                    qn[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+                } else {
+                    qn[u][0] = qn[u][1] = bf16x8_t{};
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 
@@ -268,6 +323,38 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
             };
             constexpr bool kWide = sizeof(OutT) == 2;
             constexpr int CTP = kWide ? (CT & ~1) : 0;
+            if constexpr (STG) {
+                bf16_t* ow = Os + wave * 16 * OROW;
+                const int ochunk = (grp & 1) * 2 + (grp >> 1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ct += 2) {
+                    f32x4_t a[TPW], bq[TPW];
+                    pv_tile(ct, a);
+                    pv_tile(ct + 1, bq);
+                    bf16x4_t ab, bb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ab[i] = (bf16_t)a[0][i];
+                        bb[i] = (bf16_t)bq[0][i];
+                    }
+                    const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    *reinterpret_cast<u32x4_t*>(ow + ST::offset(col, ct * 2 + ochunk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                }
+                char* otile = reinterpret_cast<char*>(opv[0]) - o_lane;      // first pixel of the tile (wave-uniform)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
+                        const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
+                        if (ABL & 1) {
+                            asm volatile("" ::"v"(wv));
+                        } else if (okv[0]) {
+                            *reinterpret_cast<u32x4_t*>(otile + st_goff[it]) = wv;
+                        }
+                    }
+                }
+            } else {
             if constexpr (kWide) {
 #pragma unroll
                 for (int ct = 0; ct < CTP; ct += 2) {
@@ -285,7 +372,12 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                         const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
                         const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                         const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                        if (okv[u]) *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                        const u32x4_t wv = {r0[0], r1[0], r0[1], r1[1]};
+                        if (ABL & 1) {
+                            asm volatile("" ::"v"(wv));
+                        } else if (okv[u]) {
+                            *reinterpret_cast<u32x4_t*>(opv[u] + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = wv;
+                        }
                     }
                 }
             }
@@ -294,8 +386,14 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 f32x4_t acc[TPW];
                 pv_tile(ct, acc);
 #pragma unroll
-                for (int u = 0; u < TPW; ++u)
-                    if (okv[u]) xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
+                for (int u = 0; u < TPW; ++u) {
+                    if (ABL & 1) {
+                        asm volatile("" ::"v"(acc[u]));
+                    } else if (okv[u]) {
+                        xna_store4(opv[u] + grp * 4 + ct * 16, acc[u]);
+                    }
+                }
+            }
             }
 
             // consume the prefetch below the stores (exact vmcnt waits: the stores stay in flight)
@@ -322,11 +420,11 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
     for (int u = 0; u < TPW; ++u) asm volatile("; xna slide loop drained" ::"v"(qf[u][0]), "v"(qf[u][1]));
 }
 
-template <int KS, int DVT, typename OutT, int NW, bool ROPE>
+template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false>
 static int xna_slide_launch_one(const XnaSlideParams& sp, hipStream_t s) {
-    constexpr size_t lds = xna_mfma_lds_bytes<KS, 1, DVT, false, NW>();
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, 1, DVT, STG, NW>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_slide_kernel<KS, DVT, OutT, NW, ROPE>;
+    auto kern = xna_slide_kernel<KS, DVT, OutT, NW, ROPE, TPWV, STG>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

@@ -878,18 +878,24 @@ def test_heads_rope_differs_from_heads_attn(dev):
 
 # ---- BASELINE full sizes: size-independent properties + sampled rows vs the oracle ----------------------
 FULL = [
-    ("G1", 1, 768, 64, 1024, 7),
-    ("G2-k7", 1, 1024, 32, 512, 7),
-    ("G2-k11", 1, 1024, 32, 512, 11),
-    ("G2-k15", 1, 1024, 32, 512, 15),
-    ("G4", 1, 768, 128, 2048, 7),
+    ("G1", 1, 768, 64, 1024, 7, "f32"),
+    ("G2-k7", 1, 1024, 32, 512, 7, "f32"),
+    ("G2-k11", 1, 1024, 32, 512, 11, "f32"),
+    ("G2-k15", 1, 1024, 32, 512, 15, "f32"),
+    ("G4", 1, 768, 128, 2048, 7, "f32"),
+    # BASELINE.json configs[3]: the 8-images-per-GPU shard of the B = 64, C = 1024 batch, in the dtype it runs in (bf16 out:
+    # 17 GB per result instead of 34 GB)
+    ("G3", 8, 1024, 64, 1024, 7, "bf16"),
 ]
 
 
-@pytest.mark.parametrize("name,B,C,lr,out_sz,ksz", FULL)
-def test_full_size_properties(dev, name, B, C, lr, out_sz, ksz):
+@pytest.mark.parametrize("name,B,C,lr,out_sz,ksz,odt", FULL)
+def test_full_size_properties(dev, name, B, C, lr, out_sz, ksz, odt):
     from naf_amd import ops
     heads = 4
+    out_dtype = torch.float32 if odt == "f32" else torch.bfloat16
+    # bf16 results carry one more rounding (2^-9 relative, values up to ~4)
+    tol_lin_max, tol_lin_mean, tol_rows = (6e-2, 4e-3, 6e-3) if odt == "f32" else (1.2e-1, 8e-3, 1.2e-2)
     gen = torch.Generator(device="cpu").manual_seed(1234)
     k = torch.randn(B, 256, lr, lr, generator=gen)
     v1 = torch.randn(B, C, lr, lr, generator=gen)
@@ -898,32 +904,37 @@ def test_full_size_properties(dev, name, B, C, lr, out_sz, ksz):
                      dtype=torch.float32).to(torch.bfloat16)
     k5 = to5(k, heads).to(dev)
 
-    def run(v, dtype=torch.float32):
+    def run(v):
         vp = ops.pack_values(v.to(dev))
         v5 = vp.view(B, lr, lr, heads, C // heads).permute(0, 3, 1, 2, 4)
-        assert ops.xna_select(q5, k5, v5, ksz, out_dtype=dtype) == "mfma"
-        return ops.xna_forward(q5, k5, v5, ksz, out_dtype=dtype, path="mfma")
+        assert ops.xna_select(q5, k5, v5, ksz, out_dtype=out_dtype) == "mfma"
+        return ops.xna_forward(q5, k5, v5, ksz, out_dtype=out_dtype, path="mfma")
 
     # (1) partition of unity: constant values pass through
     ones = run(torch.full((B, C, lr, lr), 0.5))
-    assert float((ones - 0.5).abs().max()) <= 2e-3
+    assert float((ones.float() - 0.5).abs().max()) <= (2e-3 if odt == "f32" else 4e-3)
     del ones
     # (2) linearity in V: f(v1) + f(v2) == f(v1 + v2) up to bf16 rounding of the packed values
     o1, o2 = run(bf16r(v1)), run(bf16r(v2))
     o12 = run(bf16r(bf16r(v1) + bf16r(v2)))
-    lin = (o1 + o2 - o12).abs()
-    assert float(lin.max()) <= 6e-2 and float(lin.mean()) <= 4e-3
+    lmax, lsum = 0.0, 0.0
+    for b in range(B):                                   # per image: bounds the fp32 temporaries at B = 8
+        lin = (o1[b].float() + o2[b].float() - o12[b].float()).abs()
+        lmax, lsum = max(lmax, float(lin.max())), lsum + float(lin.double().sum())
+        del lin
+    assert lmax <= tol_lin_max and lsum / o1.numel() <= tol_lin_mean, (lmax, lsum / o1.numel())
     # (3) convexity: outputs stay inside [min, max] of the values
-    assert float(o1.max()) <= float(bf16r(v1).max()) + 1e-3 and float(o1.min()) >= float(bf16r(v1).min()) - 1e-3
-    del o2, o12, lin
-    # (4) sampled rows against the oracle at full size (interior, top border, bottom border)
+    slack = 1e-3 if odt == "f32" else 3.2e-2
+    assert float(o1.max()) <= float(bf16r(v1).max()) + slack and float(o1.min()) >= float(bf16r(v1).min()) - slack
+    del o2, o12
+    # (4) sampled rows against the oracle at full size (interior, top border, bottom border), every image of the batch
     rows = sorted({0, 1, out_sz // 2 - 1, out_sz // 2, out_sz - 17, out_sz - 1})
     iy = O.axis_index_table(out_sz, lr, ksz)[rows]
     ix = O.axis_index_table(out_sz, lr, ksz)
     q_rows = q5[:, :, rows].float().cpu().permute(0, 1, 4, 2, 3).reshape(B, 256, len(rows), out_sz)
     ref = O.xna_tables(q_rows, bf16r(k), bf16r(v1), iy, ix, heads)
     got = o1[:, :, rows].permute(0, 1, 4, 2, 3).reshape(B, C, len(rows), out_sz).float().cpu()
-    assert_close(got, ref, 6e-3, 6e-3, f"{name} sampled rows")
+    assert_close(got, ref, tol_rows, tol_rows, f"{name} sampled rows")
 
 
 def test_rccl_single_rank_sharded_forward(dev):

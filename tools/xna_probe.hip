@@ -1,12 +1,14 @@
 // Stand-alone ablation / timing probe for the MFMA cell kernel (not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inaf_amd/csrc tools/xna_probe.hip -o tools/bin/xna_probe
 //   tools/bin/xna_probe [C=768] [lr=64] [d=16] [reps=20]
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
-#include "xna_mfma_kernel.h"
+#include "xna_slide_kernel.h"
 
 void naf_set_error(const char* fmt, ...) { (void)fmt; }
 int naf_check_launch(const char* what) {
@@ -117,9 +119,39 @@ float run(XnaMfmaParams p, int reps, const char* name, double bytes) {
     return ms;
 }
 
+template <int NW, int TPW, bool STG, int ABL = 0>
+float run_slide(XnaMfmaParams p, int seg_len, int reps, const char* name, double bytes) {
+    constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, 1, PROBE_DVT, STG, NW>();
+    auto kern = xna_slide_kernel<PROBE_KS, PROBE_DVT, bf16_t, NW, false, TPW, STG, ABL>;
+    XnaSlideParams sp;
+    sp.m = p;
+    sp.seg_len = seg_len;
+    sp.nseg = (p.w + seg_len - 1) / seg_len;
+    sp.m.nblocks = (uint32_t)(p.B * p.h * sp.nseg * p.heads * p.nchunk);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(sp.m.nblocks), dim3(NW * 64), lds, 0, sp);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(sp.m.nblocks), dim3(NW * 64), lds, 0, sp);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    printf("slide seg %2d %-34s %8.4f ms  %8.1f GB/s (algorithmic)\n", seg_len, name, ms, bytes / ms / 1e6);
+    return ms;
+}
+
 int main(int argc, char** argv) {
     const int C = argc > 1 ? atoi(argv[1]) : 768, lr = argc > 2 ? atoi(argv[2]) : 64, d = argc > 3 ? atoi(argv[3]) : 16;
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
+    const int order = argc > 5 ? atoi(argv[5]) : 0;
+    // NAF_PROBE_QCL=1: queries as a [B, Ho, Wo, heads*64] channels-last tensor (what the forward hands over: the stem's
+    // guidance buffer); NAF_PROBE_ROPE=1: rotate on load (tables of cos / sin values)
+    const bool q_cl = getenv("NAF_PROBE_QCL") && atoi(getenv("NAF_PROBE_QCL"));
+    const bool q_rope = getenv("NAF_PROBE_ROPE") && atoi(getenv("NAF_PROBE_ROPE"));
     const int heads = 4, Dq = 64, Dv = C / heads, Ho = lr * d, Wo = lr * d, B = 1;
     if (Dv % PROBE_DVT) { printf("Dv %d not a multiple of DVT %d\n", Dv, PROBE_DVT); return 1; }
     const size_t nq = (size_t)B * heads * Ho * Wo * Dq, nk = (size_t)B * lr * lr * heads * Dq, nv = (size_t)B * lr * lr * C;
@@ -139,9 +171,21 @@ int main(int argc, char** argv) {
     p.q = q; p.k = k; p.v = v; p.out = o;
     p.B = B; p.heads = heads; p.Ho = Ho; p.Wo = Wo; p.h = lr; p.w = lr; p.dy = d; p.dx = d; p.nchunk = Dv / PROBE_DVT;
     p.nblocks = (uint32_t)(B * lr * lr * heads * p.nchunk);
+    p.order = order;
+    p.rope_lds = getenv("NAF_PROBE_ROPE_LDS") ? atoi(getenv("NAF_PROBE_ROPE_LDS")) : 1;
     p.scale_log2e = 0.125f * 1.4426950408889634f;
     // q head-major [B, heads, Ho, Wo, 64]; k [B, h, w, heads*64]; v [B, h, w, C]; out [B, Ho, Wo, C]
     p.qs[0] = (int64_t)heads * Ho * Wo * Dq; p.qs[1] = (int64_t)Ho * Wo * Dq; p.qs[2] = (int64_t)Wo * Dq; p.qs[3] = Dq;
+    if (q_cl) { p.qs[1] = Dq; p.qs[2] = (int64_t)Wo * heads * Dq; p.qs[3] = heads * Dq; }
+    if (q_rope) {
+        std::vector<float> tab((size_t)(Ho + Wo) * 32);
+        for (size_t i = 0; i < tab.size(); ++i) tab[i] = ((i >> 4) & 1) ? sinf(0.37f * (float)(i % 977)) : cosf(0.37f * (float)(i % 977));
+        float* dt;
+        CK(hipMalloc(&dt, tab.size() * 4));
+        CK(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        p.tab_y = dt; p.tab_x = dt + (size_t)Ho * 32;
+    }
+    printf("queries: %s, %s\n", q_cl ? "channels-last [B,Ho,Wo,256]" : "head-major [B,heads,Ho,Wo,64]", q_rope ? "rotate on load" : "already rotated");
     p.ks[0] = (int64_t)lr * lr * heads * Dq; p.ks[1] = Dq; p.ks[2] = (int64_t)lr * heads * Dq; p.ks[3] = heads * Dq;
     p.vs[0] = (int64_t)lr * lr * C; p.vs[1] = Dv; p.vs[2] = (int64_t)lr * C; p.vs[3] = C;
     p.os[0] = (int64_t)Ho * Wo * C; p.os[1] = Dv; p.os[2] = (int64_t)Wo * C; p.os[3] = C;
@@ -197,6 +241,125 @@ int main(int argc, char** argv) {
         run<0, false, 1, 4, 2>(p, reps, "4 waves, 2 tiles per wave", bytes);
         return 0;
     }
+    if (argc > 6 && !strcmp(argv[6], "ab")) {
+        // interleaved A/B: every variant gets `reps` launches per round, rounds alternate between the variants (clock / thermal
+        // drift over a process is larger than the differences of interest), median and min of the per-round means
+        struct Var { const char* name; int nw; int order; int rl; int pf1; };
+        const Var vars[] = {{"4w band pf1              ", 4, 0, 0, 1},  {"4w g16 pf1               ", 4, 16, 0, 1}, {"4w g16 rope-lds pf1      ", 4, 16, 1, 1},
+                            {"4w g16 rope-lds pf2      ", 4, 16, 1, 0}, {"8w g16 rope-lds pf1      ", 8, 16, 1, 1}, {"8w g16 rope-lds pf2      ", 8, 16, 1, 0},
+                            {"8w dispatch rope-lds pf2 ", 8, 1, 1, 0},  {"8w g4 rope-lds pf2       ", 8, 4, 1, 0}};
+        constexpr int NV = sizeof(vars) / sizeof(vars[0]);
+        const int rounds = 12;
+        std::vector<std::vector<float>> t(NV);
+        hipEvent_t ea, eb;
+        CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+        auto launch = [&](const Var& v) {
+            XnaMfmaParams pv = p;
+            pv.order = v.order; pv.rope_lds = v.rl;
+            auto go = [&](auto nwc, auto ablc) {
+                constexpr int NWV = decltype(nwc)::value, AB = decltype(ablc)::value;
+                constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, 1, PROBE_DVT, true, NWV>();
+                auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, true, 1, AB, NWV, 1>;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(pv.nblocks), dim3(NWV * 64), lds, 0, pv);
+            };
+            if (v.nw == 8) { if (v.pf1) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 1024>{}); else go(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}); }
+            else { if (v.pf1) go(std::integral_constant<int, 4>{}, std::integral_constant<int, 1024>{}); else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}); }
+        };
+        for (int w = 0; w < 3; ++w) for (const Var& v : vars) launch(v);
+        for (int r = 0; r < rounds; ++r)
+            for (int i = 0; i < NV; ++i) {
+                CK(hipEventRecord(ea));
+                for (int k = 0; k < reps; ++k) launch(vars[i]);
+                CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb));
+                float ms; CK(hipEventElapsedTime(&ms, ea, eb));
+                t[i].push_back(ms / reps);
+            }
+        for (int i = 0; i < NV; ++i) {
+            std::sort(t[i].begin(), t[i].end());
+            printf("ab %-26s median %.4f ms  min %.4f  max %.4f   (%.0f GB/s at the median)\n", vars[i].name, t[i][rounds / 2], t[i][0], t[i][rounds - 1],
+                   bytes / t[i][rounds / 2] / 1e6);
+        }
+        return 0;
+    }
+    if (argc > 7) {   // sliding-window kernel: argv[6] = waves (4 | 8), argv[7] = cells per segment
+        const int sl = atoi(argv[7]);
+        printf("-- sliding-window kernel, %s waves, order %d --\n", argv[6], order);
+        if (atoi(argv[6]) == 8) {
+            run_slide<8, 1, true>(p, sl, reps, "8w staged", bytes);
+            run_slide<8, 1, true, 1>(p, sl, reps, "8w staged, no stores", bytes);
+            run_slide<8, 1, true, 8>(p, sl, reps, "8w staged, no column loads", bytes);
+            run_slide<8, 2, false>(p, sl, reps, "8w unstaged 2 tiles/wave", bytes);
+        } else {
+            run_slide<4, 1, true>(p, sl, reps, "4w staged", bytes);
+            run_slide<4, 1, true, 1>(p, sl, reps, "4w staged, no stores", bytes);
+            run_slide<4, 1, true, 4>(p, sl, reps, "4w staged, no Q loads", bytes);
+            run_slide<4, 1, true, 8>(p, sl, reps, "4w staged, no column loads", bytes);
+            run_slide<4, 1, false>(p, sl, reps, "4w unstaged 1 tile/wave", bytes);
+            run_slide<4, 2, false>(p, sl, reps, "4w unstaged 2 tiles/wave", bytes);
+            run_slide<4, 1, true>(p, sl, reps, "4w staged (again)", bytes);
+        }
+        return 0;
+    }
+    if (argc > 6 && atoi(argv[6]) < 0) {   // phase timing: argv[6] = -4 | -8 waves
+        unsigned long long* tm;
+        const size_t nrec = (size_t)p.nblocks * 8;      // one 64-byte record per wave
+        CK(hipMalloc(&tm, nrec * 64));
+        auto timing = [&](auto nwc) {
+            constexpr int NW = decltype(nwc)::value;
+            CK(hipMemset(tm, 0, nrec * 64));
+            XnaMfmaParams pt = p;
+            pt.logits = reinterpret_cast<float*>(tm);
+            constexpr size_t lds = xna_mfma_lds_bytes<PROBE_KS, 1, PROBE_DVT, true, NW>();
+            auto kern = xna_mfma_kernel<PROBE_KS, PROBE_DVT, bf16_t, true, 1, 128, NW, 1>;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(pt.nblocks), dim3(NW * 64), lds, 0, pt);
+            CK(hipDeviceSynchronize());
+            CK(hipMemset(tm, 0, nrec * 64));
+            hipEvent_t ea, eb;
+            CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+            CK(hipEventRecord(ea));
+            hipLaunchKernelGGL(kern, dim3(pt.nblocks), dim3(NW * 64), lds, 0, pt);
+            CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb));
+            float kms = 0; CK(hipEventElapsedTime(&kms, ea, eb));
+            printf("   instrumented kernel: %.4f ms\n", kms);
+            std::vector<unsigned long long> hr(nrec * 8);
+            CK(hipMemcpy(hr.data(), tm, nrec * 64, hipMemcpyDeviceToHost));
+            unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t r = 0; r < nrec; ++r)
+                for (int i = 0; i < 8; ++i) h[i] += hr[r * 8 + i];
+            const double nw = (double)h[7], nt = (double)h[5];
+            printf("-- phase timing, %d waves / workgroup, order %d: %.0f waves, %.0f tiles --\n", NW, order, nw, nt);
+            printf("   per wave : staging %.0f cycles, whole workgroup lifetime %.0f cycles\n", h[0] / nw, h[6] / nw);
+            printf("   per tile : QK+softmax %.0f, PV+LDS tile %.0f, store issue %.0f, prefetch wait+rope %.0f  (sum %.0f)\n", h[1] / nt, h[2] / nt, h[3] / nt,
+                   h[4] / nt, (h[1] + h[2] + h[3] + h[4]) / nt);
+        };
+        if (atoi(argv[6]) == -8) timing(std::integral_constant<int, 8>{});
+        else timing(std::integral_constant<int, 4>{});
+        return 0;
+    }
+    if (argc > 6) {   // ablation suite at NW waves per workgroup (argv[6] = 4 | 8), staged stores
+        auto suite = [&](auto nwc) {
+            constexpr int NW = decltype(nwc)::value;
+            printf("-- %d waves per workgroup, order %d --\n", NW, order);
+            run<0, true, 1, NW>(p, reps, "full kernel", bytes);
+            run<1, true, 1, NW>(p, reps, "no output stores", bytes);
+            run<4, true, 1, NW>(p, reps, "no Q loads", bytes);
+            run<8, true, 1, NW>(p, reps, "no K/V staging loads", bytes);
+            run<2 | 16, true, 1, NW>(p, reps, "no mfma at all (loads+softmax+stores)", bytes);
+            run<1 | 4, true, 1, NW>(p, reps, "no Q loads, no stores (compute only)", bytes);
+            run<0, true, 1, NW>(p, reps, "full kernel (again)", bytes);
+            if (p.tab_y != nullptr) {
+                run<256, true, 1, NW>(p, reps, "rope: no table loads (constants)", bytes);
+                run<512, true, 1, NW>(p, reps, "rope: tables loaded, not applied", bytes);
+                run<256 | 512, true, 1, NW>(p, reps, "rope: neither", bytes);
+                run<0, true, 1, NW>(p, reps, "full kernel (3rd)", bytes);
+            }
+        };
+        if (atoi(argv[6]) == 8) suite(std::integral_constant<int, 8>{});
+        else suite(std::integral_constant<int, 4>{});
+        return 0;
+    }
     run<0>(p, reps, "full kernel", bytes);
     run<1>(p, reps, "no output stores", bytes);
     run<2>(p, reps, "no PV mfma / V reads", bytes);
@@ -216,5 +379,7 @@ int main(int argc, char** argv) {
     run<0, false, 2, 8>(p, reps, "2x2 cells, 8 waves, unstaged", bytes);
     run<64, false>(p, reps, "unstaged narrow 8 B stores", bytes);
     run<0>(p, reps, "full kernel (again)", bytes);
+    run<0, true, 1, 16>(p, reps, "16 waves, staged stores (1 wg / CU)", bytes);
+    run<0, true, 1, 8>(p, reps, "8 waves, staged stores (again)", bytes);
     return 0;
 }
