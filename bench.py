@@ -8,10 +8,14 @@
 A "step" is one whole NAF forward (conv stem -> RoPE + key pooling -> cross-scale neighbourhood
 attention) over one batch of synthetic inputs that are resident in HBM before the timed region.
 Workload at N=1 = BASELINE.json configs[1] ("G1"): 1x3x1024x1024 guidance, 1x768x64x64 features ->
-1024x1024, window 7, bf16, random-init default-dim weights.  For N>1 every rank runs the same
-per-GPU workload on its own images (weak scaling, no data-path collective: the path is
-embarrassingly parallel over the batch; RCCL is used for the parameter broadcast and the timing
-reduction only).  Rank 0 prints ONE JSON line.
+1024x1024, window 7, bf16, random-init default-dim weights.
+For N>1 the workload is BASELINE.json configs[3] ("G3"): ONE batch of 64 images of 3x1024x1024 with
+1024x64x64 features (DINOv3-ViT-L width) -> 1024x1024, sharded 64/N images per rank (strong scaling: the
+total work is fixed).  Rank 0 creates the whole batch; the parameters travel by one flat RCCL broadcast
+and the inputs by one RCCL scatter each (naf_amd.dist), both BEFORE the timed region; inside it every rank
+runs its shard through naf_amd.dist.ShardedNAF (micro-batches of 2) with no data-path collective -- the
+path is embarrassingly parallel over the batch.  After the timed region rank 0 alone runs the same 64
+images on its one GPU to report `speedup_vs_1`.  Rank 0 prints ONE JSON line.
 
 value     = total output pixels of all ranks / max-over-ranks time           [Mpix/s]
 roofline  = the attention kernel (naf_xna_fwd, MFMA cell kernel): algorithmic bytes per launch
@@ -84,27 +88,56 @@ def algorithmic_bytes(B, C, lr, out, elt=2, cq=256):
     return elt * B * (cq * out * out + (cq + C) * lr * lr + C * out * out)
 
 
-def cpu_baseline(C, ksz, budget_s=20.0):
-    """Oracle timed on host cores on a crop of the workload (same channels, same window, 256^2 output
-    from a 16^2 feature grid = same ratio 16); cost per output pixel is size-independent."""
+def cpu_baseline(C, ksz, lr, out, budget_s=25.0):
+    """The CPU oracle (oracle/naf_oracle.py: a port -- the reference's own CPU path needs NATTEN, which cannot be installed)
+    timed on this host's cores, SURVEY.md section 8d: (1) BASELINE configs[0] "P1" in full (1x3x224^2, 384x14^2 -> 224^2,
+    window 7, fp32), (2) a 256^2 crop of the benched workload (same channels, window and ratio 16: cost per output pixel
+    is size-independent), (3) the benched workload in full, once, when (2) predicts it fits the budget.  `value` is (3)
+    when it ran, else (2)."""
     from oracle import naf_oracle as O
-    crop, lr = 256, 16
+    cores = torch.get_num_threads()
     p = O.make_params(seed=0)
-    img = O.hash_normal((1, 3, crop, crop), 1)
-    ft = O.hash_normal((1, C, lr, lr), 2)
+
+    def timed(img, ft, size, k, max_s, max_reps):
+        with torch.no_grad():
+            reps, t0 = 0, time.perf_counter()
+            while True:
+                O.naf_forward_fast(p, img, ft, size, kernel_size=k)
+                reps += 1
+                el = time.perf_counter() - t0
+                if el > max_s or reps >= max_reps:
+                    return reps, el
+
     with torch.no_grad():
-        O.naf_forward_fast(p, img, ft, (crop, crop), kernel_size=ksz)      # warm-up (thread pool, allocator)
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            O.naf_forward_fast(p, img, ft, (crop, crop), kernel_size=ksz)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or reps >= 50:
-                break
-    return {"value": round(crop * crop * reps / el / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{reps} x oracle.naf_forward_fast fp32 on a 1x3x{crop}x{crop} crop, 1x{C}x{lr}x{lr} features, "
-                      f"window {ksz} ({el:.1f} s; host has {os.cpu_count()} logical cpus)"}
+        O.naf_forward_fast(p, O.hash_normal((1, 3, 64, 64), 3), O.hash_normal((1, 64, 4, 4), 4), (64, 64), kernel_size=3)   # thread pool
+    res = {"unit": "Mpix/s", "cores": cores, "kind": "port", "host_logical_cpus": os.cpu_count()}
+    # (1) P1 in full
+    img, ft = O.hash_normal((1, 3, 224, 224), 1), O.hash_normal((1, 384, 14, 14), 2)
+    timed(img, ft, (224, 224), 7, 0.0, 1)
+    reps, el = timed(img, ft, (224, 224), 7, budget_s * 0.2, 50)
+    res["p1_full"] = {"value": round(224 * 224 * reps / el / 1e6, 4), "sample": f"{reps} x P1 (1x3x224x224, 1x384x14x14 -> 224x224, window 7, fp32) in {el:.1f} s"}
+    # (2) crop of the benched workload
+    crop, clr = 256, 16
+    img, ft = O.hash_normal((1, 3, crop, crop), 1), O.hash_normal((1, C, clr, clr), 2)
+    timed(img, ft, (crop, crop), ksz, 0.0, 1)
+    reps, el = timed(img, ft, (crop, crop), ksz, budget_s * 0.3, 50)
+    crop_rate = crop * crop * reps / el / 1e6
+    res["crop"] = {"value": round(crop_rate, 4), "sample": f"{reps} x 1x3x{crop}x{crop} crop, 1x{C}x{clr}x{clr} features, window {ksz}, fp32 in {el:.1f} s"}
+    res["value"], res["sample"] = res["crop"]["value"], res["crop"]["sample"]
+    # (3) the benched workload in full, once
+    predicted = out * out / 1e6 / max(crop_rate, 1e-9)
+    if predicted <= budget_s * 1.8:
+        try:
+            img, ft = O.hash_normal((1, 3, out, out), 1), O.hash_normal((1, C, lr, lr), 2)
+            reps, el = timed(img, ft, (out, out), ksz, 0.0, 1)
+            res["full"] = {"value": round(out * out * reps / el / 1e6, 4),
+                           "sample": f"1 x the benched workload in full (1x3x{out}x{out}, 1x{C}x{lr}x{lr} -> {out}x{out}, window {ksz}, fp32) in {el:.1f} s"}
+            res["value"], res["sample"] = res["full"]["value"], res["full"]["sample"]
+        except (RuntimeError, MemoryError) as e:            # host memory
+            res["full"] = {"value": None, "sample": f"failed: {type(e).__name__}"}
+    else:
+        res["full"] = {"value": None, "sample": f"skipped: predicted {predicted:.0f} s > budget"}
+    return res
 
 
 def main():
@@ -112,8 +145,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="G1", choices=sorted(WORKLOADS))
-    ap.add_argument("--per-gpu-batch", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: G1 on one GPU, G3 on several")
+    ap.add_argument("--per-gpu-batch", type=int, default=1, help="single-GPU runs: images per step")
+    ap.add_argument("--total-batch", type=int, default=64, help="multi-GPU runs: images of the whole job, sharded over the ranks")
+    ap.add_argument("--micro-batch", type=int, default=2, help="multi-GPU runs: images per forward inside a rank's shard")
+    ap.add_argument("--no-single-gpu-reference", action="store_true", help="multi-GPU runs: skip rank 0's solo run of the whole batch")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=25.0, help="seconds of host time for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
     ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
@@ -151,19 +188,40 @@ def main():
     from naf_amd import NAF, ops
     from naf_amd import dist as nd
 
+    if args.workload is None:
+        args.workload = "G1" if world == 1 else "G3"
     C, lr, out, ksz = WORKLOADS[args.workload]
-    B = args.per_gpu_batch
-    torch.manual_seed(0)                                        # same random-init weights on every rank...
+    torch.manual_seed(100 + rank)                               # ranks start with DIFFERENT random-init weights...
     model = NAF(kernel_size=ksz).to(dev).eval()
     model.fuse_rope = not args.no_fuse_rope
     model.single_call = not args.multi_call
     model.image_encoder.fuse_conv0 = not args.no_fuse_conv0
-    if world > 1:
-        nd.broadcast_parameters(model, src=0)                   # ...and made identical by one RCCL broadcast
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)    # each rank owns different images
-    image = torch.randn(B, 3, out, out, device=dev, generator=g)
-    feats = torch.randn(B, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
     size = (out, out)
+    scatter_ms = None
+    if world > 1:
+        nd.broadcast_parameters(model, src=0)                   # ...made identical by one flat RCCL broadcast (2.65 MB)
+        total = args.total_batch
+        lo, hi = nd.shard_range(total, rank, world)
+        B = hi - lo
+        full_img = full_ft = None
+        if rank == 0:                                           # rank 0 owns the batch (north_star: "batched images shard ... via RCCL")
+            g = torch.Generator(device=dev).manual_seed(1000)
+            full_img = torch.randn(total, 3, out, out, device=dev, generator=g).to(torch.bfloat16)
+            full_ft = torch.randn(total, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_sc = time.perf_counter()
+        image = nd.scatter_batch(full_img, (total, 3, out, out), torch.bfloat16, dev, src=0)
+        feats = nd.scatter_batch(full_ft, (total, C, lr, lr), torch.bfloat16, dev, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        scatter_ms = (time.perf_counter() - t_sc) * 1e3
+    else:
+        B = args.per_gpu_batch
+        total = B
+        g = torch.Generator(device=dev).manual_seed(1000)
+        image = torch.randn(B, 3, out, out, device=dev, generator=g)
+        feats = torch.randn(B, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
 
     timer = EventTimer()
     ops.KERNEL_TIMER = timer
@@ -179,11 +237,17 @@ def main():
 
         def step():
             return graphed()
+    elif world > 1:
+        sharded = nd.ShardedNAF(model, micro_batch=args.micro_batch, concat=False)
+
+        def step():
+            return sharded(image, feats, size)      # list of micro-batch outputs: the rank's shard stays resident
     else:
         def step():
             return model(image, feats, size)
 
     with torch.no_grad():
+        o = None
         for _ in range(args.warmup):
             o = step()
         del o
@@ -207,11 +271,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    one_gpu_ms = None
+    if world > 1 and not args.no_single_gpu_reference:
+        # the same `total` images on ONE GPU (rank 0 alone, outputs dropped as it goes: 64 outputs are 137 GB)
+        del o
+        torch.cuda.empty_cache()
+        if rank == 0:
+            solo = nd.ShardedNAF(model, micro_batch=args.micro_batch, keep_outputs=False)
+            with torch.no_grad():
+                solo(full_img[: 2 * args.micro_batch], full_ft[: 2 * args.micro_batch], size)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                solo(full_img, full_ft, size)
+                torch.cuda.synchronize()
+                one_gpu_ms = (time.perf_counter() - t1) * 1e3
+        dist.barrier()
+
     if rank == 0:
         ms_step = el * 1e3 / args.steps
-        value = world * B * out * out / (el / args.steps) / 1e6
+        value = total * out * out / (el / args.steps) / 1e6
         xna_ms = timer.mean_ms("xna_mfma")
-        alg = algorithmic_bytes(B, C, lr, out)
+        mb = min(args.micro_batch, B) if world > 1 else B          # images per attention launch
+        alg = algorithmic_bytes(mb, C, lr, out)
         roof = None
         if xna_ms:
             ach = alg / (xna_ms * 1e-3) / 1e9
@@ -227,18 +308,22 @@ def main():
                     "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
                     # the same kernel against the matrix pipe (large windows approach the MFMA ridge):
                     # 2 * k^2 * (256 + C) FLOP per output pixel, dense bf16 MFMA peak 2.5 PFLOP/s
-                    "mfma_tflops": round(2.0 * ksz * ksz * (256 + C) * B * out * out / (xna_ms * 1e-3) / 1e12, 1),
-                    "mfma_frac": round(2.0 * ksz * ksz * (256 + C) * B * out * out / (xna_ms * 1e-3) / 2.5e15, 4)}
+                    "mfma_tflops": round(2.0 * ksz * ksz * (256 + C) * mb * out * out / (xna_ms * 1e-3) / 1e12, 1),
+                    "mfma_frac": round(2.0 * ksz * ksz * (256 + C) * mb * out * out / (xna_ms * 1e-3) / 2.5e15, 4)}
         line = {
             "metric": "upsampled Mpixels/sec (NAF forward)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": (round(value / PUBLISHED_MPIX[args.workload], 2) if (args.workload in PUBLISHED_MPIX and world == 1 and B == 1
                                                                                   and not args.attention_only) else None),
             "dtype": "bf16",
             "data": "synthetic" if backend == "nccl" else f"synthetic (DRY RUN over {backend}, ranks share GPUs: not a measurement)",
-            "config": {"workload": f"{args.workload}: {B}x3x{out}x{out} guidance, {B}x{C}x{lr}x{lr} features -> "
-                                   f"{out}x{out}, window {ksz}, per GPU", "per_gpu_batch": B, "parallelism": f"batch-shard x{world}",
+            "config": {"workload": (f"{args.workload}: {B}x3x{out}x{out} guidance, {B}x{C}x{lr}x{lr} features -> {out}x{out}, window {ksz}, per GPU"
+                                    if world == 1 else
+                                    f"{args.workload}: batch of {total} x 3x{out}x{out} guidance, {total} x {C}x{lr}x{lr} features -> {out}x{out}, "
+                                    f"window {ksz}, {B} images per GPU in micro-batches of {args.micro_batch}"),
+                       "per_gpu_batch": B, "global_batch": total, "parallelism": f"batch-shard x{world}",
+                       "input_distribution": (None if world == 1 else "rank 0 -> RCCL scatter (naf_amd.dist.scatter_batch), before the timed region"),
                        "scope": ("attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)")
                                 + (", hipGraph replay" if args.graph else ""),
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
@@ -247,8 +332,12 @@ def main():
                           for k in ("stem", "stem_conv0", "stem_conv1", "stem_conv3", "rope_pool", "attention", "xna_mfma")},
             "launches_per_step": {k: timer.count(k) // max(1, args.steps) for k in ("stem_conv0", "stem_conv1", "stem_conv3")},
         }
+        if world > 1:
+            line["scatter_ms"] = round(scatter_ms, 3)
+            line["one_gpu_ms"] = round(one_gpu_ms, 3) if one_gpu_ms else None
+            line["speedup_vs_1"] = round(one_gpu_ms / ms_step, 3) if one_gpu_ms else None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(C, ksz)
+            line["cpu_baseline"] = cpu_baseline(C, ksz, lr, out, budget_s=args.cpu_baseline_budget)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

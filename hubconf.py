@@ -17,10 +17,11 @@ def naf(pretrained: bool = True, device="cpu"):
 
     Builds the default model (dim 256, 4 heads, kernel 9) and, if ``pretrained``, loads the reference's
     released weights (identical ``state_dict`` keys, strict).  The model can be constructed and
-    loaded on any device; its forward needs a ROCm device.
+    loaded on any device; its forward needs a ROCm device.  Like the reference the module comes back in training
+    mode: call ``.eval()`` (README usage) or run under ``torch.no_grad()`` for the fused inference path.
     """
     model = NAF().to(device)
     if pretrained:
         state = torch.hub.load_state_dict_from_url(CHECKPOINT_URL, progress=True, map_location=device)
         model.load_state_dict(state)
-    return model.eval()
+    return model          # like the reference (hubconf.py:20-24): the caller decides on .eval(), README usage calls it

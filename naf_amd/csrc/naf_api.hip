@@ -203,7 +203,7 @@ int naf_xna_select(const naf_xna_args* a) {
     // AUTO: the cell kernels for integer ratios with cells of 100+ queries (10x10 and up); smaller cells,
     // non-integer ratios and ratio 1 go to the table-driven MFMA kernel (one staged window per BLOCK of queries,
     // measured faster up to 8x8 cells), the rest (odd head dims, return_weights off the cell path) to the generic one
-    static const bool no_union = [] { const char* e = getenv("NAF_XNA_UNION"); return e && atoi(e) == 0; }();   // A/B knob
+    static const bool no_union = [] { const char* e = naf_knob("NAF_XNA_UNION"); return e && atoi(e) == 0; }();   // A/B knob
     const int64_t cell_px = (int64_t)(a->Ho / a->h) * (a->Wo / a->w);
     if (ok && (cell_px >= 100 || a->logits != nullptr || no_union) && cell_px >= 8) return NAF_XNA_MFMA;
     if (!no_union && a->logits == nullptr && naf_xna_union_eligible(a)) return NAF_XNA_UNION;

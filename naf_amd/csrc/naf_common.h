@@ -1,5 +1,6 @@
 // Shared device/host helpers for libnaf_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,6 +93,34 @@ __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) { return __uint_
 __device__ __forceinline__ void naf_rope_rotate(float a, float b, float c, float s, float& o1, float& o2) {
     o1 = __builtin_fmaf(a, c, -(b * s));
     o2 = __builtin_fmaf(b, c, a * s);
+}
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the
+// odd rows of one register with the even rows of the other, v_permlane32_swap the upper half of one with the lower half of
+// the other -- with both operands the same value, the two results hold "mine" and "my partner's".  (__shfl_xor goes through
+// ds_bpermute: an LDS round trip of 100+ cycles on the softmax's critical path, four times per tile.)
+__device__ __forceinline__ float naf_rows_max(float v) {
+    const uint32_t b = __float_as_uint(v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    const float m16 = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    const uint32_t c = __float_as_uint(m16);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+__device__ __forceinline__ float naf_rows_sum(float v) {
+    const uint32_t b = __float_as_uint(v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    const float s16 = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const uint32_t c = __float_as_uint(s16);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
+// A/B tuning knobs (NAF_XNA_ORDER, NAF_XNA_STAGE, NAF_UNION_PLAN, ...) are measurement tools: they are honoured only when the
+// process also sets NAF_HIP_KNOBS=1, so that a stray environment variable cannot change kernel selection in production.
+inline const char* naf_knob(const char* name) {
+    static const bool on = [] { const char* e = getenv("NAF_HIP_KNOBS"); return e != nullptr && atoi(e) != 0; }();
+    return on ? getenv(name) : nullptr;
 }
 
 // Bijective XCD-aware remap: hardware places block b on XCD b % 8; give every XCD one contiguous

@@ -78,9 +78,9 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     p.nblocks = (uint32_t)nb;
     // dispatch order in groups of 16 workgroups per XCD turn (xna_block_order; profiles/r02_hbm_ceiling.txt: all XCDs
     // sweep the same cell rows, +5..9 % over one band of cell rows per XCD); NAF_XNA_ORDER=0 restores the bands (A/B knob)
-    static const int order = [] { const char* e = getenv("NAF_XNA_ORDER"); return e ? atoi(e) : 16; }();
+    static const int order = [] { const char* e = naf_knob("NAF_XNA_ORDER"); return e ? atoi(e) : 16; }();
     p.order = order;
-    static const int rope_lds = [] { const char* e = getenv("NAF_XNA_ROPE_LDS"); return e ? atoi(e) : 1; }();   // A/B knob
+    static const int rope_lds = [] { const char* e = naf_knob("NAF_XNA_ROPE_LDS"); return e ? atoi(e) : 1; }();   // A/B knob
     p.rope_lds = rope_lds;
     p.scale_log2e = scale * 1.4426950408889634f;
     p.scale = scale;
@@ -90,7 +90,7 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
     // Whenever the plan has no staged stores (windows of 11x11 and up, fp32 output, windows + staging tiles that would
     // leave fewer than 3 workgroups per CU) and the geometry has row tiles: persistent sliding-window kernel
     // (xna_slide_kernel.h).  return_weights needs the window's row-major slot order and stays on the cell kernel.
-    static const bool no_slide = [] { const char* e = getenv("NAF_XNA_SLIDE"); return e && atoi(e) == 0; }();   // A/B knob
+    static const bool no_slide = [] { const char* e = naf_knob("NAF_XNA_SLIDE"); return e && atoi(e) == 0; }();   // A/B knob
     if (a->ky >= 7 && !pl.staged && !no_slide && a->logits == nullptr && (p.dx % 16) == 0 && (int64_t)p.dy * p.dx / 16 <= 1024) {
         XnaSlideParams sp;
         sp.m = p;

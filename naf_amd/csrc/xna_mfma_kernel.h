@@ -214,6 +214,42 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         return reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(q_cell + (int64_t)ty * p.qs[2]) + (xl * (uint32_t)p.qs[3] + (uint32_t)grp * 8u) * 2u);
     };
 
+    // FAST (CB == 1, dx a multiple of 16, the usual integer ratios): a tile is 16 consecutive pixels of one
+    // cell row, every per-tile quantity (row, first column, base pointers) is wave-uniform scalar work and a
+    // lane only adds constant 32-bit offsets.  Otherwise tiles straddle rows and each lane divides.
+    // rotate-on-load: RoPE on a tile's queries.  The lane holds head dims [grp*8, +8) (qf[0]) and their partners
+    // +32 (qf[1]); dims < 16 turn with the row angle, dims >= 16 with the column angle.  The table values of the
+    // NEXT tile are fetched from LDS at the top of an iteration and applied at its bottom, when the prefetched
+    // queries have landed, so neither latency sits on the tile's critical path.
+    auto rope_fetch = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 256) != 0) {   // probe: no table loads
+            cs[0] = cs[1] = f32x4_t{0.6f, 0.6f, 0.6f, 0.6f};
+            cs[2] = cs[3] = f32x4_t{0.8f, 0.8f, 0.8f, 0.8f};
+            return;
+        }
+        const int ttc = min(tt, ttot - 1);
+        const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
+        // straight from the tables (128 KB each, L1/L2-resident): an LDS copy would cost the third resident workgroup
+        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx0 * p.dx + min(tx0 + col, p.dx - 1)) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
+        cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
+        cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
+        cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
+        cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
+    };
+    auto rope_apply = [&](bf16x8_t (&qv)[2], const f32x4_t (&cs)[4]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 512) != 0) {   // probe: tables fetched but not applied
+            asm volatile("" ::"v"(cs[0]), "v"(cs[1]), "v"(cs[2]), "v"(cs[3]));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float o1, o2;
+            naf_rope_rotate((float)qv[0][i], (float)qv[1][i], cs[i >> 2][i & 3], cs[2 + (i >> 2)][i & 3], o1, o2);
+            qv[0][i] = (bf16_t)o1;
+            qv[1][i] = (bf16_t)o2;
+        }
+    };
+
     // first tile's queries: issued before the window staging so their HBM latency hides under it
     // TPW tiles (16 queries each) are processed together by a wave: the K and V^T fragments read from LDS
     // feed TPW MFMAs each, halving LDS traffic per FLOP at TPW = 2 (large windows are LDS/MFMA-bound).
@@ -311,42 +347,6 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     }
     const uint32_t o_lane = (uint32_t)(col * (int)p.os[3]) * (uint32_t)sizeof(OutT);   // unstaged: this lane's pixel
 
-    // FAST (CB == 1, dx a multiple of 16, the usual integer ratios): a tile is 16 consecutive pixels of one
-    // cell row, every per-tile quantity (row, first column, base pointers) is wave-uniform scalar work and a
-    // lane only adds constant 32-bit offsets.  Otherwise tiles straddle rows and each lane divides.
-    // rotate-on-load: RoPE on a tile's queries.  The lane holds head dims [grp*8, +8) (qf[0]) and their partners
-    // +32 (qf[1]); dims < 16 turn with the row angle, dims >= 16 with the column angle.  The table values of the
-    // NEXT tile are fetched from LDS at the top of an iteration and applied at its bottom, when the prefetched
-    // queries have landed, so neither latency sits on the tile's critical path.
-    auto rope_fetch = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {
-        if constexpr ((ABL & 256) != 0) {   // probe: no table loads
-            cs[0] = cs[1] = f32x4_t{0.6f, 0.6f, 0.6f, 0.6f};
-            cs[2] = cs[3] = f32x4_t{0.8f, 0.8f, 0.8f, 0.8f};
-            return;
-        }
-        const int ttc = min(tt, ttot - 1);
-        const int ty = (int)(((uint32_t)ttc * tmagic) >> 20), tx0 = (ttc - ty * tpr) * 16;
-        // straight from the tables (128 KB each, L1/L2-resident): an LDS copy would cost the third resident workgroup
-        const float* tr = ((grp >> 1) ? p.tab_x + (int64_t)(cx0 * p.dx + min(tx0 + col, p.dx - 1)) * 32 : p.tab_y + (int64_t)(cy0 * p.dy + ty) * 32) + (grp & 1) * 8;
-        cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
-        cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
-        cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
-        cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
-    };
-    auto rope_apply = [&](bf16x8_t (&qv)[2], const f32x4_t (&cs)[4]) __attribute__((always_inline)) {
-        if constexpr ((ABL & 512) != 0) {   // probe: tables fetched but not applied
-            asm volatile("" ::"v"(cs[0]), "v"(cs[1]), "v"(cs[2]), "v"(cs[3]));
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float o1, o2;
-            naf_rope_rotate((float)qv[0][i], (float)qv[1][i], cs[i >> 2][i & 3], cs[2 + (i >> 2)][i & 3], o1, o2);
-            qv[0][i] = (bf16_t)o1;
-            qv[1][i] = (bf16_t)o2;
-        }
-    };
-
     auto tile_loop = [&](auto fastc, auto ropec, auto rlc) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fastc)::value && (CB == 1);
         constexpr bool ROPE = FAST && decltype(ropec)::value;
@@ -386,6 +386,8 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         // have been in flight for two tile times (one is not enough behind a CU's queue of row stores: the wave sat
         // 1.8 k of its 6.3 k cycles per tile waiting for them, profiles/r02_xna_phase_timing.txt).  Needs tables that do not
         // travel with the queries (no rope, or the LDS / register tables).
+        // (Requesting ALL of a wave's queries ahead of the window staging -- two tiles per wave at 8 waves -- was measured
+        // too and loses 3-5 %: the query reads then bunch at workgroup start instead of mixing with the stores.)
         // Measured (interleaved A/B, tools/xna_probe ... ab): 4-wave workgroups (4 tiles per wave at 16 x 16 cells) gain 5 %
         // with rotate-on-load and nothing without; 8-wave workgroups have two tiles per wave and lose.
         constexpr bool PF2 = FAST && TPW == 1 && NW == 4 && (!ROPE || RL) && !(ABL & 1024);
@@ -432,21 +434,30 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 oxv[u] = (CB == 1) ? 0 : min(max(cxv[u] - KS / 2, 0), p.w - KS) - x0;
             }
 
-            // ---- S^T = K . Q^T ----
+            // ---- S^T = K . Q^T ----  (all K fragments are requested before the first MFMA: read -> wait -> MFMA pairs in
+            // program order cost one LDS round trip each on a wave's critical path, eight times per tile)
             f32x4_t s[TPW][MT];
+            {
+                bf16x8_t ka[MT][2];
+                if (!(ABL & 16)) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        for (int ks = 0; ks < 2; ++ks) ka[mt][ks] = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
+                }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (!(ABL & 16)) {
-                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                        for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[u][mt], 0, 0, 0);
-                    } else {
+                    for (int u = 0; u < TPW; ++u) s[u][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
+                    for (int ks = 0; ks < 2; ++ks) {
+                        if (!(ABL & 16)) {
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) s[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[mt][ks], qf[u][ks], s[u][mt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) s[u][mt][ks] += (float)qf[u][ks][mt & 7];
+                        }
                     }
                 }
             }
@@ -514,8 +525,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                         }
                         m = fmaxf(m, s[u][mt][r]);
                     }
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
+                m = naf_rows_max(m);
                 float sum = 0.f;
                 const float mc = m * p.scale_log2e;
 #pragma unroll
@@ -526,8 +536,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                         s[u][mt][r] = e;
                         sum += e;
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                sum = naf_rows_sum(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);   // sum >= 1 (the max slot contributes exp2(0))
                 // pack P to bf16 B-fragments: k index (g, j) <-> slot ks*32 + (j>>2)*16 + g*4 + (j&3)
 #pragma unroll
@@ -543,6 +552,14 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 for (int u = 0; u < TPW; ++u) asm volatile("" ::"v"(pf[u][0]), "v"(pf[u][KST - 1]));
             }
             XNA_TSTAMP(t_b)
+            // PF2 + RL: the NEXT tile's queries landed a tile ago -- rotate them here, in the shadow of the PV MFMAs, instead
+            // of on the wave's critical path between the stores and the next tile's QK^T (ABL 4096: keep it at the bottom)
+            constexpr bool EARLY_ROPE = PF2 && RL && !(ABL & 4096);
+            if constexpr (EARLY_ROPE) {
+                f32x4_t cse[4];
+                rope_tab(tb + NW, cse);
+                rope_apply(q2, cse);
+            }
             // ---- O^T = V^T . P^T, store ----
             // FAST: o_tile = first pixel of the tile (uniform); generic: per-lane pixel pointer
             OutT* obv[TPW];      // cell origin (generic) / tile origin (FAST)
@@ -595,11 +612,43 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 static_assert(sizeof(OutT) == 2 && (CT % 2) == 0 && TPW == 1, "staged stores: bf16, even tile count, one tile");
                 bf16_t* ow = Os + wave * 16 * OROW;
                 const int ochunk = (grp & 1) * 2 + (grp >> 1);   // this lane's 16-byte chunk inside a pair of channel tiles
+                // V^T fragments of the NEXT pair of channel tiles are requested before the MFMAs of the current pair
+                // (double-buffered registers): in program order "8 reads, wait, 4 MFMAs, convert, write" pays the LDS
+                // latency six times per tile on the wave's critical path
+                auto vt_frag = [&](int ct, bf16x8_t (&fa)[KST]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks) {
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
+                        fa[ks][0] = lo[0]; fa[ks][1] = lo[1]; fa[ks][2] = lo[2]; fa[ks][3] = lo[3];
+                        fa[ks][4] = hi[0]; fa[ks][5] = hi[1]; fa[ks][6] = hi[2]; fa[ks][7] = hi[3];
+                    }
+                };
+                bf16x8_t vf[2][2][KST];
+                if (!(ABL & 2)) {
+                    vt_frag(0, vf[0][0]);
+                    vt_frag(1, vf[0][1]);
+                }
 #pragma unroll
                 for (int ct = 0; ct < CT; ct += 2) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int cur = (ct >> 1) & 1;
+                    if (!(ABL & 2) && ct + 2 < CT) {
+                        vt_frag(ct + 2, vf[cur ^ 1][0]);
+                        vt_frag(ct + 3, vf[cur ^ 1][1]);
+                    }
                     f32x4_t a[TPW], bq[TPW];
-                    pv_tile(ct, a);
-                    pv_tile(ct + 1, bq);
+                    if (ABL & 2) {
+                        pv_tile(ct, a);
+                        pv_tile(ct + 1, bq);
+                    } else {
+                        a[0] = bq[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KST; ++ks) {
+                            a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][0][ks], pf[0][ks], a[0], 0, 0, 0);
+                            bq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cur][1][ks], pf[0][ks], bq[0], 0, 0, 0);
+                        }
+                    }
                     bf16x4_t ab, bb;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -613,6 +662,16 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 }
                 const int t0 = tv[0] * 16;
                 XNA_TSTAMP(t_c)
+                // Whole tiles (cell width a multiple of 16: every BASELINE shape): all LDS reads are issued, then all stores.
+                // Behind a per-store predicate each store sits in its own exec-masked block -- ds_read, s_waitcnt lgkmcnt(0),
+                // store, six times in a row (1.8 k of the 6 k cycles a tile takes, profiles/r02_xna_phase_timing.txt).
+                if (FAST && (NCH % 64 == 0) && !(ABL & (1 | 8192)) && (p.dx & 15) == 0) {   // (ABL 8192: probe keeps the predicated form)
+                    u32x4_t wv[NIT];
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) wv[it] = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv[it];
+                } else
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
@@ -691,7 +750,9 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     qf[u][1] = qn[u][1];
                 }
             }
-            if constexpr (RL) {
+            if constexpr (EARLY_ROPE) {
+                // (qf was rotated above, while it was still q2)
+            } else if constexpr (RL) {
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     rope_tab(tb + NW * TPW + u, csn[u]);
@@ -790,20 +851,21 @@ constexpr int xna_mfma_nw(int ks, int cb, int dvt, bool staged) {
 inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
     static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
     // tuning knob for A/B runs: NAF_XNA_STAGE=0 never stages, =1 stages whenever it fits
-    static const int force = [] { const char* e = getenv("NAF_XNA_STAGE"); return e ? atoi(e) : -1; }();
+    static const int force = [] { const char* e = naf_knob("NAF_XNA_STAGE"); return e ? atoi(e) : -1; }();
+    static const int dvt_cap = [] { const char* e = naf_knob("NAF_XNA_DVT"); return e ? atoi(e) : 1 << 30; }();   // A/B knob
     for (int c : cand) {
-        if (Dv % c) continue;
+        if (Dv % c || c > dvt_cap) continue;
         const int tpw = xna_mfma_tpw(ks);
         const bool can_stage = (out_dtype == NAF_BF16) && (c % 32 == 0) && tpw == 1;
         for (int cb = xna_mfma_cb(ks); cb >= 1; --cb) {
             for (int st = can_stage ? 1 : 0; st >= 0; --st) {
                 const size_t lds = xna_mfma_lds_for(ks, cb, c, st != 0);
-                // Staged whole-row stores pay off while >= 3 workgroups stay resident per CU; below that the
-                // unstaged plan is taken, which the launcher serves with the sliding-window kernel on the row-tile
-                // geometry (tools/xna_stage_sweep.py, tools/f32out_probe.py: k7 Dv 256 staged 0.58 ms, sliding 0.55 ms;
-                // k9 Dv 256 cell 0.67 ms, sliding 0.58 ms).
+                // Staged whole-row stores pay off while >= 2 workgroups stay resident per CU; below that the unstaged plan
+                // is taken, which the launcher serves with the sliding-window kernel on the row-tile geometry.  (r01 asked
+                // for 3: with the window staging batched and dispatch-order workgroups, two staged 4-wave workgroups beat
+                // the sliding kernel at k = 7, Dv = 256: G3 0.565 -> 0.530 ms, G2-k7 0.157 -> 0.139 ms, gpurun r2w.)
                 if (st && force == 0) continue;
-                if (st && force != 1 && (int)(160 * 1024 / lds) < 3) continue;
+                if (st && force != 1 && (int)(160 * 1024 / lds) < 2) continue;
                 if (lds <= 160 * 1024) {
                     pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->tpw = tpw; pl->lds = lds;
                     return true;

@@ -66,7 +66,7 @@ UnionPlan make_plan(int Ho, int h, int Wo, int w, int k, int Dv, int64_t groups)
     static const int segs[] = {16, 32, 64, 128, 256, 512};
     // experiments: NAF_UNION_PLAN="ry,seg,dvt" pins the plan (0 = free)
     int pin[3] = {0, 0, 0};
-    if (const char* e = getenv("NAF_UNION_PLAN")) sscanf(e, "%d,%d,%d", &pin[0], &pin[1], &pin[2]);
+    if (const char* e = naf_knob("NAF_UNION_PLAN")) sscanf(e, "%d,%d,%d", &pin[0], &pin[1], &pin[2]);
     for (int dvt = 256; dvt >= 16; dvt -= 16) {
         if (Dv % dvt || (pin[2] && dvt != pin[2])) continue;
         const int nchunk = Dv / dvt;
@@ -109,7 +109,7 @@ UnionPlan plan_for(const naf_xna_args* a) {
     static std::map<Key, UnionPlan> cache;
     const Key key(a->Ho, a->h, a->Wo, a->w, a->ky, a->Dv, (int64_t)a->B * a->heads);
     std::lock_guard<std::mutex> lock(mu);
-    if (getenv("NAF_UNION_PLAN")) cache.erase(key);   // experiments: the pinned plan may change between calls
+    if (naf_knob("NAF_UNION_PLAN")) cache.erase(key);   // experiments: the pinned plan may change between calls
     auto it = cache.find(key);
     if (it == cache.end()) {
         if (cache.size() > 256) cache.clear();

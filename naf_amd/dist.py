@@ -43,23 +43,46 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
 
 
 def scatter_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, device, src: int = 0) -> torch.Tensor:
-    """Rank ``src`` owns ``full`` [N, ...]; every rank receives its ``shard_range`` slice."""
+    """Rank ``src`` owns ``full`` [N, ...]; every rank receives its ``shard_range`` slice through ONE collective
+    (``torch.distributed.scatter`` = ncclScatter on RCCL: rank ``src`` pushes each slice over its own xGMI link, the
+    point-to-point topology's best case).  Slices are padded to the largest shard when N % world != 0 (the collective
+    needs equal counts); the pad rows are dropped on arrival."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    lo, hi = shard_range(shape[0], rank, world)
-    out = torch.empty((hi - lo, *shape[1:]), dtype=dtype, device=device)
+    n = int(shape[0])
+    spans = [shard_range(n, r, world) for r in range(world)]
+    mx = max(b - a for a, b in spans)
+    lo, hi = spans[rank]
+    if mx == 0:
+        return torch.empty((0, *shape[1:]), dtype=dtype, device=device)
+    # gloo (CPU tests, and bench.py's dry run with ranks sharing one GPU) scatters host tensors; RCCL device tensors
+    via_host = dist.get_backend() == "gloo" and torch.device(device).type != "cpu"
+    final_device, device = device, ("cpu" if via_host else device)
+    recv = torch.empty((mx, *shape[1:]), dtype=dtype, device=device)
+    chunks = None
     if rank == src:
+        if full is None or tuple(full.shape) != tuple(shape):
+            raise ValueError(f"scatter_batch: rank {src} must pass the full tensor of shape {tuple(shape)}")
         chunks = []
-        for r in range(world):
-            a, b = shard_range(shape[0], r, world)
-            chunks.append(full[a:b].contiguous())
-        for r in range(world):
-            if r == src:
-                out.copy_(chunks[r])
-            elif chunks[r].numel():
-                dist.send(chunks[r], dst=r)
-    elif out.numel():
-        dist.recv(out, src=src)
-    return out
+        for a, b in spans:
+            if b - a == mx:
+                chunks.append(full[a:b].contiguous().to(device))
+            else:
+                c = torch.zeros((mx, *shape[1:]), dtype=dtype, device=device)
+                c[: b - a] = full[a:b]
+                chunks.append(c)
+    dist.scatter(recv, scatter_list=chunks, src=src)
+    return recv[: hi - lo].to(final_device)
+
+
+def broadcast_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, device, src: int = 0) -> torch.Tensor:
+    """Alternative input distribution: ONE ncclBroadcast of the whole batch, every rank keeps its ``shard_range`` slice
+    (world x the bytes of ``scatter_batch`` on the wire, but a single ring-pipelined collective; useful when every rank
+    needs the whole batch anyway, e.g. for a later gather-free evaluation)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    buf = full.contiguous() if rank == src else torch.empty(tuple(shape), dtype=dtype, device=device)
+    dist.broadcast(buf, src=src)
+    lo, hi = shard_range(int(shape[0]), rank, world)
+    return buf[lo:hi]
 
 
 def gather_scalars(values: Sequence[float], device) -> List[List[float]]:
@@ -84,15 +107,25 @@ def gather_outputs(local: torch.Tensor, n_total: int) -> torch.Tensor:
 
 
 class ShardedNAF:
-    """Runs ``model`` on this rank's slice of a batch, in micro-batches to bound the encoder's
-    activations (fp32/bf16 guidance at full resolution)."""
+    """Runs ``model`` on this rank's slice of a batch, in micro-batches to bound the encoder's activations (bf16 guidance
+    at full resolution: 1 GB per image in flight).  ``concat=False`` returns the list of micro-batch outputs instead of
+    one concatenated tensor (no second copy of a shard that is tens of GB at G3); ``keep_outputs=False`` drops every
+    micro-batch's output as soon as the next one is issued (a consumer that reduces the features on the fly, or a
+    benchmark leg whose whole batch would not fit) and returns None."""
 
-    def __init__(self, model: torch.nn.Module, micro_batch: int = 2):
+    def __init__(self, model: torch.nn.Module, micro_batch: int = 2, concat: bool = True, keep_outputs: bool = True):
         self.model = model
         self.micro_batch = max(1, int(micro_batch))
+        self.concat, self.keep_outputs = concat, keep_outputs
 
-    def __call__(self, image: torch.Tensor, features: torch.Tensor, output_size) -> torch.Tensor:
+    def __call__(self, image: torch.Tensor, features: torch.Tensor, output_size):
         outs = []
         for i in range(0, image.shape[0], self.micro_batch):
-            outs.append(self.model(image[i:i + self.micro_batch], features[i:i + self.micro_batch], output_size))
+            o = self.model(image[i:i + self.micro_batch], features[i:i + self.micro_batch], output_size)
+            if self.keep_outputs:
+                outs.append(o)
+        if not self.keep_outputs:
+            return None
+        if not self.concat:
+            return outs
         return torch.cat(outs, dim=0) if len(outs) != 1 else outs[0]

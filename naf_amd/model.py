@@ -74,6 +74,11 @@ class RoPE(nn.Module):
         self.register_buffer("periods", periods, persistent=True)
         self._tables = None
         self._tables_key = None
+        # train-time coordinate augmentation (rope.py:107-124): the reference caches the coordinates per (H, W)
+        # (rope.py:159-161), so its augmentation is drawn ONCE per resolution and even survives .eval(); the default here
+        # redraws it on every training step (what the augmentation is for).  Set True to reproduce the reference's caching.
+        self.cache_train_coords = False
+        self._train_tables = {}
 
     def tables(self, Ho: int, Wo: int):
         p = self.periods
@@ -121,16 +126,19 @@ class _GroupNormTrain(torch.autograd.Function):
         HW = H * W                                                                    # for channels-last input), fp32 statistics
         S = next((d for d in (512, 256, 128, 64, 32, 16) if HW % d == 0 and HW // d >= 8), 0)
         if C >= 96 or S == 0:
-            var_c, mean_c = torch.var_mean(xv, dim=1, unbiased=False)                 # [B, C]
-            ex2_c = var_c + mean_c * mean_c
+            var_c, mean_c = torch.var_mean(xv, dim=1, unbiased=False)                 # [B, C], Welford
         else:
             # few channels = few outputs: ATen's column reduction then runs on a handful of workgroups (0.3 ms for 48
-            # channels at 256^2); reduce in two stages, S partial sums per channel first
+            # channels at 256^2); reduce in two stages, S partial sums per channel first -- mean, then CENTRED squares
             mean_c = xv.view(B, S, HW // S, C).sum(2).sum(1) / HW
-            ex2_c = (xv * xv).view(B, S, HW // S, C).sum(2).sum(1) / HW
-        mean = mean_c.view(B, groups, -1).mean(-1)                                     # [B, G]
-        ex2 = ex2_c.view(B, groups, -1).mean(-1)
-        rstd = torch.rsqrt((ex2 - mean * mean).clamp_min(0.0) + eps)
+            dc = xv - mean_c.unsqueeze(1)
+            var_c = (dc * dc).view(B, S, HW // S, C).sum(2).sum(1) / HW
+        # fold channels into groups without E[x^2] - mean^2 (activations with |mean| >> std would lose every variance
+        # bit): var_g = mean_c(var_c) + mean_c((mean_c - mean_g)^2), both terms non-negative
+        mean_cg = mean_c.view(B, groups, -1)
+        mean = mean_cg.mean(-1)                                                        # [B, G]
+        var = var_c.view(B, groups, -1).mean(-1) + ((mean_cg - mean.unsqueeze(-1)) ** 2).mean(-1)
+        rstd = torch.rsqrt(var + eps)
         scale = (rstd.unsqueeze(-1) * weight.float().view(groups, -1)).reshape(B, C)
         shift = bias.float().unsqueeze(0) - (mean.unsqueeze(-1) * scale.view(B, groups, -1)).reshape(B, C)
         ctx.save_for_backward(x, mean, rstd, weight)
@@ -309,10 +317,16 @@ class QueryEncoder(nn.Module):
 
 
 class KeyEncoder(nn.Module):
-    """Parameter-free; the pooling itself happens inside the fused rope+pool kernel (naf.py:63-69)."""
+    """``adaptive_avg_pool2d`` of the RoPE'd guidance to the feature grid (naf.py:63-69).  ``NAF.forward`` never calls it
+    -- the pooling is fused into naf_rope_pool_fwd / naf_forward -- but callers that use the sub-module directly (as the
+    reference allows) get the same result: HIP pooling kernel for channels-last bf16 device tensors, ATen otherwise."""
 
-    def forward(self, x, features):  # pragma: no cover - kept for API shape only
-        raise RuntimeError("naf_amd: KeyEncoder pooling is fused into naf_rope_pool_fwd; call NAF.forward")
+    def forward(self, x, features):
+        size = tuple(int(v) for v in features.shape[-2:])
+        if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            return ops.pool_guidance(x, size)
+        return F.adaptive_avg_pool2d(x, output_size=size)
 
 
 class CrossAttention(nn.Module):
@@ -370,6 +384,15 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = model(self.image, self.features, self.output_size)
+        # The captured launches dereference device memory the graph does not own: the forward plan's workspace and
+        # argument block, the RoPE tables, the packed bf16 weights.  They live in single-slot caches of the model that a
+        # later eager call with other shapes (or a parameter update) replaces; hold them here so that a replay never
+        # reads freed or recycled memory.
+        enc = model.image_encoder
+        plan_slot = model.__dict__.get("_plan_cache")
+        plan = plan_slot[1] if plan_slot else None
+        self._keep = [plan_slot, plan, getattr(plan, "_ws", None), getattr(plan, "_keep", None), enc.rope._tables,
+                      dict(enc.__dict__.get("_wcache", {}))]
 
     def __call__(self, image: Optional[torch.Tensor] = None, features: Optional[torch.Tensor] = None) -> torch.Tensor:
         if image is not None:
@@ -417,8 +440,7 @@ class NAF(nn.Module):
                                         out_dtype=fuse_for[1], path=self.xna_path):
                     _, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, write_q=False)
                     return q5, k5, (tab_y, tab_x)
-        import os as _os
-        q5, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, q_layout="head_major" if (same and not _os.environ.get("NAF_QL")) else "channels_last")
+        q5, k5 = ops.rope_pool(x, tab_y, tab_x, heads_rope, lr_size, q_layout="head_major" if same else "channels_last")
         if not same:        # re-split the channel axis for attention: pure views of channels-last buffers
             B, _, Ho, Wo, _ = q5.shape
             dim = enc.out_channels
@@ -502,7 +524,12 @@ class NAF(nn.Module):
             x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
         # [Ho, 2, P], [Wo, 2, P]; in training mode with the reference's coordinate augmentation (rope.py:107-124)
-        tab_y, tab_x = _rope_train_tables(enc.rope, ho, wo) if enc.rope.training else enc.rope.tables(ho, wo)
+        if enc.rope.training and enc.rope.cache_train_coords:
+            if (ho, wo) not in enc.rope._train_tables:
+                enc.rope._train_tables[(ho, wo)] = _rope_train_tables(enc.rope, ho, wo)
+            tab_y, tab_x = enc.rope._train_tables[(ho, wo)]
+        else:
+            tab_y, tab_x = _rope_train_tables(enc.rope, ho, wo) if enc.rope.training else enc.rope.tables(ho, wo)
         B, Cq = x.shape[:2]
         D = Cq // heads_rope
         cos = torch.cat([tab_y[:, 0, None, :].expand(ho, wo, -1), tab_x[None, :, 0, :].expand(ho, wo, -1)], dim=-1)
@@ -522,8 +549,23 @@ class NAF(nn.Module):
         out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
         return out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
 
-    @torch.no_grad()
     def forward(self, image, features, output_size, return_weights=False, *args, **kwargs):
+        """``naf(image, lr_features, target_size)`` (naf.py:104-116).  The reference's forward is always differentiable;
+        here the fused inference kernels run unless a gradient is actually wanted: autograd enabled AND (an input requires
+        grad, or the module is in ``.train()`` mode with trainable parameters) -- then the call is ``forward_train``
+        (train.py:127-137, denoising.py:213 work unchanged).  README usage (``naf.eval()`` then ``naf(...)``) and any call
+        under ``torch.no_grad()`` take the inference path; that path always uses the deterministic eval-mode RoPE
+        coordinates (the reference's train-mode coordinate jitter only exists on the differentiable path here)."""
+        if torch.is_grad_enabled() and (image.requires_grad or features.requires_grad or
+                                        (self.training and any(p.requires_grad for p in self.parameters()))):
+            if return_weights:
+                raise NotImplementedError("naf_amd: return_weights is an inference feature (notebooks/attention_maps.ipynb); "
+                                          "call under torch.no_grad() or after .eval()")
+            return self.forward_train(image, features, output_size)
+        with torch.no_grad():
+            return self._forward_inference(image, features, output_size, return_weights)
+
+    def _forward_inference(self, image, features, output_size, return_weights=False):
         if not (image.is_cuda and features.is_cuda):
             raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback); got "
                                f"image on {image.device}, features on {features.device}")

@@ -175,7 +175,7 @@ def test_product_never_imports_oracle():
 def test_hubconf_entry_point():
     import hubconf
     m = hubconf.naf(pretrained=False, device="cpu")
-    assert not m.training and type(m).__name__ == "NAF"
+    assert m.training and type(m).__name__ == "NAF"          # the reference does not call .eval() either (hubconf.py:20-24)
     assert "naf" in dir(hubconf) and hubconf.dependencies == ["torch"]
 
 

@@ -50,6 +50,10 @@ def _worker(rank, world, port, ret):
         lo, hi = nd.shard_range(N, rank, world)
         expect = torch.arange(N * 3 * 4 * 4, dtype=torch.float32).view(N, 3, 4, 4)[lo:hi]
         assert torch.equal(img, expect)
+        img_b = nd.broadcast_batch(full_img, (N, 3, 4, 4), torch.float32, "cpu", src=0)
+        assert torch.equal(img_b, expect)
+        empty = nd.scatter_batch(torch.zeros(0, 2) if rank == 0 else None, (0, 2), torch.float32, "cpu", src=0)
+        assert empty.shape == (0, 2)
 
         class Fake(torch.nn.Module):                         # per-image op: no cross-sample term
             def forward(self, image, feats, size):
@@ -57,6 +61,9 @@ def _worker(rank, world, port, ret):
         feats = torch.ones(hi - lo, 1, 1, 1) * (rank + 1)
         out = nd.ShardedNAF(Fake(), micro_batch=2)(img, feats, (4, 4))
         assert out.shape[0] == hi - lo
+        parts = nd.ShardedNAF(Fake(), micro_batch=2, concat=False)(img, feats, (4, 4))
+        assert isinstance(parts, list) and torch.equal(torch.cat(parts), out)
+        assert nd.ShardedNAF(Fake(), micro_batch=2, keep_outputs=False)(img, feats, (4, 4)) is None
         allout = nd.gather_outputs(out, N)
         ref = torch.arange(N * 48, dtype=torch.float32).view(N, 48).mean(dim=1).view(N, 1, 1, 1)
         owner = torch.tensor([1.0 if i < nd.shard_range(N, 0, world)[1] else 2.0 for i in range(N)]).view(N, 1, 1, 1)

@@ -1,5 +1,6 @@
 """Plan sweep of the table-driven MFMA attention kernel: one process per pinned plan (NAF_UNION_PLAN=ry,seg,dvt)."""
 import os, sys, subprocess
+os.environ.setdefault("NAF_HIP_KNOBS", "1")   # the A/B knobs below are honoured only with this set
 CASES = {"r13.8": (37, 37, 512, 512, 768, 9), "d1k7": (256, 256, 256, 256, 384, 7), "d4": (64, 64, 256, 256, 768, 7), "d8": (64, 64, 512, 512, 768, 7)}
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 """Staged (whole-row) vs unstaged stores of the MFMA attention kernel across window / Dv combinations.
 Run under NAF_XNA_STAGE=0 and =1 (planner override) and compare."""
 import os, sys, torch
+os.environ.setdefault("NAF_HIP_KNOBS", "1")   # the A/B knobs below are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from naf_amd import ops
 
