@@ -296,15 +296,21 @@ def main():
         roof = None
         if xna_ms:
             ach = alg / (xna_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, kname = None, "xna_mfma_kernel"
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(args.workload)
+                    ent = json.load(open(tpath)).get(args.workload)
+                    if isinstance(ent, dict):        # PMC bytes of ONE image's launch (profiles/r02_pmc_hbm_traffic.txt) x images per launch
+                        traffic, kname = int(ent["bytes"]) * mb, ent.get("kernel", kname)
+                    elif ent is not None:
+                        traffic = int(ent) * mb
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "xna_mfma_kernel",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r02_pmc_hbm_traffic.txt" if traffic else None,
+                    "kernel": kname,
                     "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
                     # the same kernel against the matrix pipe (large windows approach the MFMA ridge):
                     # 2 * k^2 * (256 + C) FLOP per output pixel, dense bf16 MFMA peak 2.5 PFLOP/s

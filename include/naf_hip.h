@@ -82,6 +82,9 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   stats_out accumulates sum / sum^2 of y per GroupNorm group (zeroed by the caller).  y may be NULL: statistics only
  *   (for naf_stem_conv_args.first below); with ksize 1 they are then computed from the image's first and second
  *   moments (y is linear in the image), which agrees with the sums of the stored pass to ~1e-7 relative.
+ * Both entries take `channels` = the hidden width C (convolutions.py:67-92 with dim / 2 channels per branch; the
+ *   reference's denoising models use dim 96 ... 512, denoising.py:213): 128 (or 0) selects the hand-scheduled kernels of
+ *   the default model, any other multiple of 16 up to 256 the general kernels of stem_generic.hip; "128" below reads C.
  * naf_stem_conv_fwd  : GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, ksize 1 or 3, reflect) + bias
  *   (one norm/act/conv triple of EncBlock.forward, convolutions.py:52-61).  x device bf16 with its
  *   stats_in; gn_weight/gn_bias f32 [128]; w_packed device bf16 [k*k][128 oc][128 ic]
@@ -89,6 +92,7 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   `first` (optional, ksize 1 only): the layer is the FIRST residual-block convolution of the 1x1 branch and
  *   recomputes its input bf16(conv0(image)) from `first` (image, weight, bias of the 1x1 conv0; first->y and
  *   first->stats_out are ignored) instead of reading x, so that the conv0 activation never exists in memory;
+ *   128 channels only;
  *   stats_in then are the sums a naf_stem_conv0_fwd(y = NULL) call produced.  Given the same stats_in the results
  *   are bit-identical to the two-call sequence. */
 typedef struct naf_stem_conv0_args {
@@ -100,7 +104,7 @@ typedef struct naf_stem_conv0_args {
     int32_t image_dtype; /* naf_dtype */
     int32_t ksize;       /* 1 or 3 */
     int32_t B, H, W;
-    int32_t reserved;
+    int32_t channels;    /* output channels: 0 or 128 = the default width's kernels; any multiple of 16 in [16, 256] otherwise */
     int64_t image_stride[4];
     int64_t y_stride[3];
 } naf_stem_conv0_args;
@@ -118,7 +122,7 @@ typedef struct naf_stem_conv_args {
     int32_t ksize; /* 1 or 3 */
     int32_t B, H, W;
     float eps;
-    int32_t reserved;
+    int32_t channels;    /* channels of x and y: 0 or 128 = the default width's kernels; any multiple of 16 in [16, 256] otherwise */
     int64_t x_stride[3];
     int64_t y_stride[3];
     const naf_stem_conv0_args* first; /* optional, see above */

@@ -48,7 +48,7 @@ class StemConv0Args(C.Structure):
     _fields_ = [
         ("image", C.c_void_p), ("y", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_out", C.c_void_p),
         ("image_dtype", C.c_int32), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("reserved", C.c_int32), ("image_stride", I64x4), ("y_stride", I64x3),
+        ("channels", C.c_int32), ("image_stride", I64x4), ("y_stride", I64x3),
     ]
 
 
@@ -57,7 +57,7 @@ class StemConvArgs(C.Structure):
         ("x", C.c_void_p), ("y", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("gn_weight", C.c_void_p),
         ("gn_bias", C.c_void_p), ("stats_in", C.c_void_p), ("stats_out", C.c_void_p),
         ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("eps", C.c_float),
-        ("reserved", C.c_int32), ("x_stride", I64x3), ("y_stride", I64x3), ("first", C.POINTER(StemConv0Args)),
+        ("channels", C.c_int32), ("x_stride", I64x3), ("y_stride", I64x3), ("first", C.POINTER(StemConv0Args)),
     ]
 
 

@@ -123,6 +123,7 @@ int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv0_fwd: reflect padding needs H, W >= 2");
     NAF_REQUIRE(a->y == nullptr || (al16(a->y) && a->y_stride[0] % 8 == 0 && a->y_stride[1] % 8 == 0 && a->y_stride[2] % 8 == 0),
                 "naf_stem_conv0_fwd: output must be 16-byte aligned with strides multiple of 8");
+    if (a->channels != 0 && a->channels != 128) return naf_launch_stem_conv0_generic(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_conv0(a, static_cast<hipStream_t>(stream));
 }
 
@@ -143,6 +144,7 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     NAF_REQUIRE((a->first || al16(a->x)) && al16(a->y) && al16(a->w_packed), "naf_stem_conv_fwd: tensors must be 16-byte aligned");
     for (int i = 0; i < 3; ++i)
         NAF_REQUIRE((a->first || a->x_stride[i] % 8 == 0) && a->y_stride[i] % 8 == 0, "naf_stem_conv_fwd: strides must be multiples of 8 elements");
+    if (a->channels != 0 && a->channels != 128) return naf_launch_stem_conv_generic(a, static_cast<hipStream_t>(stream));
     // 1x1 layers are HBM-bound (independent-wave kernel); 3x3 layers are MFMA-bound (weight-stationary strips)
     if (a->ksize == 1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream));

@@ -179,10 +179,12 @@ class _ReflectPad(torch.autograd.Function):
 
 
 class ImageEncoder(nn.Module):
-    """Guidance encoder (naf.py:11-52).  At the default width (dim 256 -> 128 hidden channels) both
-    conv branches run through the library's fused HIP stem (naf_stem_conv0_fwd / naf_stem_conv_fwd:
-    GroupNorm+SiLU+conv in one weight-stationary MFMA pass per layer).  Other widths use torch/MIOpen ops in
-    ``stem_dtype`` (bf16, channels-last).  RoPE is applied by the caller's fused rope+pool kernel."""
+    """Guidance encoder (naf.py:11-52).  Both conv branches run through the library's fused HIP stem
+    (naf_stem_conv0_fwd / naf_stem_conv_fwd: GroupNorm+SiLU+conv in one MFMA pass per layer): the hand-scheduled
+    weight-stationary kernels at the default width (dim 256 -> 128 hidden channels), the general kernels of
+    stem_generic.hip at any other width that is a multiple of 16 up to 256 (the reference's denoising models, dim 96 ... 512).
+    ``stem_impl = "torch"`` (MIOpen ops in ``stem_dtype``) is an explicit A/B switch, never a silent fallback.
+    RoPE is applied by the caller's fused rope+pool kernel."""
 
     def __init__(self, in_channels=3, out_channels=256, heads_rope=1, use_encoder=True, rope_base=None,
                  rope_rescale=None, img_layers=2):
@@ -193,7 +195,7 @@ class ImageEncoder(nn.Module):
         self.sem_encoder = make_branch(in_channels, out_channels // 2, 3, 3, img_layers)
         self.rope = RoPE(out_channels, num_heads=heads_rope, base=rope_base, rescale_coords=rope_rescale)
         self.stem_dtype = torch.bfloat16
-        self.stem_impl = "hip"      # "hip": fused HIP stem (hidden width 128); "torch": MIOpen ops (any width)
+        self.stem_impl = "hip"      # "hip": fused HIP stem; "torch": MIOpen ops (A/B only)
         self.fuse_conv0 = True      # 1x1 branch: first block layer recomputes conv0 instead of reading it
 
     @staticmethod
@@ -235,11 +237,14 @@ class ImageEncoder(nn.Module):
             x = self._conv_train(F.silu(self._group_norm_train(x, blk.norm2)), blk.conv2)
         return x
 
-    # ---- fused HIP stem (default width: 128 hidden channels, GroupNorm(8)) -------------------------
+    # ---- fused HIP stem (hidden width a multiple of 16 up to 256, GroupNorm(8)) --------------------
     def _hip_stem_ok(self) -> bool:
         c0 = self.encoder[0]
-        return (self.use_encoder and c0.out_channels == 128 and c0.in_channels == 3
+        return (self.use_encoder and c0.out_channels % 16 == 0 and 16 <= c0.out_channels <= 256 and c0.in_channels == 3
                 and all(b.norm1.num_groups == 8 for b in list(self.encoder)[1:]))
+
+    def _hip_stem_default_width(self) -> bool:
+        return self._hip_stem_ok() and self.encoder[0].out_channels == 128
 
     def _packed(self, conv: nn.Conv2d) -> torch.Tensor:
         """bf16 [k*k, oc, ic] copy of a conv weight, cached until the parameter changes."""
@@ -259,25 +264,27 @@ class ImageEncoder(nn.Module):
         B, _, H, W = image.shape
         dev = image.device
         branches = (self.encoder, self.sem_encoder)
+        hid = self.encoder[0].out_channels
         nstage = 1 + 2 * (len(self.encoder) - 1)
         stats = torch.zeros((2, nstage, B, 8, 2), dtype=torch.float64, device=dev)      # one memset for all sums
-        cat = torch.empty((B, H, W, 256), dtype=torch.bfloat16, device=dev)
-        bufs = [torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+        cat = torch.empty((B, H, W, 2 * hid), dtype=torch.bfloat16, device=dev)
+        bufs = [torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev) for _ in range(2)]
         for br, seq in enumerate(branches):
             conv0 = seq[0]
             w0, b0 = conv0.weight.detach().float().contiguous(), conv0.bias.detach().float()
             # 1x1 branch: the conv0 activation is never stored -- one statistics-only pass, then the first
             # GroupNorm/SiLU/conv layer recomputes it from the image (bit-identical, 0.5 GB less traffic)
-            recompute = self.fuse_conv0 and conv0.kernel_size[0] == 1 and nstage > 1 and seq[1].conv1.kernel_size[0] == 1
+            recompute = (self.fuse_conv0 and hid == 128 and conv0.kernel_size[0] == 1 and nstage > 1
+                         and seq[1].conv1.kernel_size[0] == 1)
             last = nstage == 1
-            dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[0]
+            dst = cat[..., br * hid:(br + 1) * hid] if last else bufs[0]
             ops.stem_conv0(image, w0, b0, None if recompute else dst, stats[br, 0])
             cur, st = dst, 0
             for blk in list(seq)[1:]:
                 for norm, conv in ((blk.norm1, blk.conv1), (blk.norm2, blk.conv2)):
                     st += 1
                     last = st == nstage - 1
-                    dst = cat[..., br * 128:(br + 1) * 128] if last else bufs[st % 2]
+                    dst = cat[..., br * hid:(br + 1) * hid] if last else bufs[st % 2]
                     ops.stem_conv(None if (recompute and st == 1) else cur, stats[br, st - 1], norm.weight.detach().float(),
                                   norm.bias.detach().float(), norm.eps, self._packed(conv), conv.bias.detach().float(), dst,
                                   None if last else stats[br, st], first=(image, w0, b0) if (recompute and st == 1) else None)
@@ -294,7 +301,11 @@ class ImageEncoder(nn.Module):
                 x = ops.preshrink_image(x, size)                               # the kernel naf_forward uses as well
             else:
                 x = F.interpolate(x.float(), size=size, mode="bilinear", align_corners=False)
-        if self.use_encoder and self.stem_impl == "hip" and self._hip_stem_ok():
+        if self.use_encoder and self.stem_impl == "hip":
+            if not self._hip_stem_ok():
+                raise RuntimeError(f"naf_amd: the HIP conv stem serves hidden widths that are multiples of 16 up to 256 with "
+                                   f"GroupNorm(8) (got {self.encoder[0].out_channels}); there is no silent torch fallback -- set "
+                                   f"image_encoder.stem_impl = 'torch' explicitly to run MIOpen ops")
             x = self._stem_hip(x)
         elif self.use_encoder:
             dt = self.stem_dtype
@@ -455,7 +466,7 @@ class NAF(nn.Module):
         Cached until a parameter, the shapes, strides or dtypes change."""
         enc = self.image_encoder
         ho, wo = int(output_size[0]), int(output_size[1])
-        if not (enc.use_encoder and enc.stem_impl == "hip" and enc._hip_stem_ok() and enc.fuse_conv0 and self.fuse_rope):
+        if not (enc.use_encoder and enc.stem_impl == "hip" and enc._hip_stem_default_width() and enc.fuse_conv0 and self.fuse_rope):
             return None
         if image.shape[1] != 3 or self.xna_path != "auto":
             return None

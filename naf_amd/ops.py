@@ -86,9 +86,12 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 def _fill_stem_conv0(image, weight, bias, y, stats_out) -> StemConv0Args:
     B, Cin, H, W = image.shape
-    if Cin != 3 or tuple(weight.shape[:2]) != (128, 3) or weight.dtype != torch.float32 or not weight.is_contiguous():
-        raise ValueError(f"stem_conv0: expected a 3-channel image and an f32 [128,3,k,k] weight, got {tuple(image.shape)} / {tuple(weight.shape)}")
+    Cout = int(weight.shape[0])
+    if Cin != 3 or weight.shape[1] != 3 or Cout % 16 or not (16 <= Cout <= 256) or weight.dtype != torch.float32 or not weight.is_contiguous():
+        raise ValueError(f"stem_conv0: expected a 3-channel image and an f32 [C,3,k,k] weight with C a multiple of 16 up to 256, "
+                         f"got {tuple(image.shape)} / {tuple(weight.shape)}")
     a = StemConv0Args()
+    a.channels = Cout
     a.image, a.weight, a.bias = image.data_ptr(), weight.data_ptr(), bias.data_ptr()
     a.y = y.data_ptr() if y is not None else None
     a.stats_out = stats_out.data_ptr() if stats_out is not None else None
@@ -131,8 +134,10 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
         x = y                                                        # shape / device donor only
     _gpu(x, "x")
     B, H, W, Cc = x.shape
-    if Cc != 128 or x.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
-        raise ValueError("stem_conv: activations must be bf16 [B,H,W,128] with channels contiguous")
+    if Cc % 16 or not (16 <= Cc <= 256) or x.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
+        raise ValueError("stem_conv: activations must be bf16 [B,H,W,C] with channels contiguous, C a multiple of 16 up to 256")
+    if tuple(w_packed.shape[1:]) != (Cc, Cc):
+        raise ValueError(f"stem_conv: packed weight {tuple(w_packed.shape)} does not match {Cc} channels")
     taps = w_packed.shape[0]
     a = StemConvArgs()
     a.x, a.y, a.w_packed, a.bias = (None if first is not None else x.data_ptr()), y.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
@@ -141,6 +146,7 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
     a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
     a.stats_out = stats_out.data_ptr() if stats_out is not None else None
     a.ksize = {1: 1, 9: 3}[int(taps)]
+    a.channels = Cc
     a.B, a.H, a.W, a.eps = B, H, W, float(eps)
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
     a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
