@@ -10,8 +10,10 @@ attention is compared on sampled rows (every column, so every 32-pixel strip bor
 stem itself is compared on EVERY pixel).
 
 Tolerances (fp, stated as the prompt asks): the bf16-activation stem against the fp32 oracle stem: mean |err| <= 8e-3,
-max <= 2.5e-1 over 268 M values (profiles/r02_stem_error_budget.txt: per-layer error growth); whole forward
-|err| <= 6e-2 + 3e-2 |ref| elementwise and mean |err| <= 6e-3 (outputs are O(1)).
+max <= 2.5e-1 over 268 M values (profiles/r02_stem_error_budget.txt: every layer adds 2.9e-3 of its output RMS -- one bf16
+rounding of the activated input and one of the output -- 6.9e-3 after five layers); whole forward: SURVEY.md section 8c's
+|err| <= 2e-2 + 1e-2 |ref| elementwise (bf16 features and output where the workload says so) and mean |err| <= 6e-3.  The
+attention averages the guidance error over its window, so the output error is an order of magnitude below the stem's.
 """
 import os
 
@@ -81,7 +83,7 @@ def test_whole_forward_G1_full_size(dev):
     out = m(img.to(dev), ft.to(dev).to(torch.bfloat16), (out_sz, out_sz))
     assert out.shape == (1, C, out_sz, out_sz) and out.dtype == torch.bfloat16
     got = out[:, :, rows].float().cpu()
-    _assert_close(got, ref, 6e-2, 3e-2, "G1 whole forward, sampled rows")
+    _assert_close(got, ref, 2e-2, 1e-2, "G1 whole forward, sampled rows")
     assert float((got - ref).abs().mean()) <= 6e-3
 
 
@@ -100,7 +102,7 @@ def test_whole_forward_G3_shard_through_the_sharded_driver(dev):
     for b in (0, 7):
         _, ref = _oracle_rows(p, img[b:b + 1], ft[b:b + 1], out_sz, ksz, rows)
         got = out[b:b + 1, :, rows].float().cpu()
-        _assert_close(got, ref, 6e-2, 3e-2, f"G3 shard image {b}, sampled rows")
+        _assert_close(got, ref, 2e-2, 1e-2, f"G3 shard image {b}, sampled rows")
         assert float((got - ref).abs().mean()) <= 6e-3
     # micro-batching is invisible up to the order of the GroupNorm partial sums (the stem's per-workgroup fp32 partials are
     # cut differently for 1 and 2 images per launch, the fp64 atomics land in any order): a handful of bf16 roundings flip
@@ -127,7 +129,7 @@ def test_hub_entry_forward_on_gpu(dev):
     out = naf(img.to(dev), ft.to(dev), (144, 176))
     ref = O.naf_forward(p, img, ft, (144, 176), kernel_size=9)
     got = out.float().cpu()
-    _assert_close(got, ref, 6e-2, 3e-2, "hub entry forward")
+    _assert_close(got, ref, 2e-2, 1e-2, "hub entry forward")
     assert float((got - ref).abs().mean()) <= 6e-3
 
 
@@ -148,7 +150,7 @@ def test_hub_pretrained_checkpoint_from_a_local_url(dev, tmp_path, monkeypatch):
     ft = O.hash_normal((2, 192, 12, 12), 2402)           # 9 x 9 window at dilation 8: 72 <= 96 (NATTEN's precondition)
     out = naf(img.to(dev), ft.to(dev), [96, 96])
     ref = O.naf_forward(p, img, ft, (96, 96), kernel_size=9)
-    _assert_close(out.float().cpu(), ref, 6e-2, 3e-2, "pretrained-from-file forward")
+    _assert_close(out.float().cpu(), ref, 2e-2, 1e-2, "pretrained-from-file forward")
     # a checkpoint with a missing key must fail loudly (strict load, as the reference's load_state_dict does)
     bad = {k: v for k, v in p.items() if not k.endswith("rope.periods")}
     torch.save(bad, tmp_path / "bad.pth")
@@ -176,7 +178,7 @@ def test_feature_provider_hook_feeds_vit_shaped_tokens(dev):
     m = _load_model(dev, p, kernel_size=9)
     out = m(img, lr, (hp * 14, wp * 14))
     ref = O.naf_forward(p, img.cpu(), lr.float().cpu(), (hp * 14, wp * 14), kernel_size=9)
-    _assert_close(out.float().cpu(), ref, 6e-2, 3e-2, "ViT-token features through the forward")
+    _assert_close(out.float().cpu(), ref, 2e-2, 1e-2, "ViT-token features through the forward")
 
 
 def test_captured_forward_survives_other_shapes_and_cache_turnover(dev):

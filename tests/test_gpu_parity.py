@@ -5,9 +5,12 @@ Tolerances (fp, stated here as the prompt asks):
   * kernels fed bf16-rounded inputs vs the fp32 oracle on the SAME rounded inputs:
       fp32 output  : |err| <= 6e-3 + 6e-3*|ref|   (P is rounded to bf16 before the PV MFMA: rel 2^-9 per weight)
       bf16 output  : |err| <= 1.2e-2 + 1.2e-2*|ref|  (+ one bf16 rounding of the result)
-  * whole forward (bf16 conv stem through MIOpen, bf16 Q/K/V) vs the fp32 reference golden vectors:
-      |err| <= 6e-2 + 3e-2*|ref| elementwise (1e-1 for the one-head k=5 denoising case F6, whose softmax is
-      the most peaked) and mean |err| <= 6e-3 (outputs are O(1)).
+  * whole forward (bf16-activation HIP conv stem, bf16 Q/K/V) vs the fp32 reference golden vectors / the oracle:
+      SURVEY.md section 8c's |err| <= 2e-2 + 1e-2*|ref| elementwise and mean |err| <= 6e-3 (outputs are O(1));
+      looser where the softmax is peaked and the output follows single keys instead of averaging them (the stem's bf16
+      error, 6.9e-3 of the guidance RMS after five layers -- profiles/r02_stem_error_budget.txt -- then shows undamped):
+      6e-2 + 3e-2*|ref| for cells of 1-2 pixels, 1e-1 + 3e-2*|ref| for the one-head k=5 denoising case F6, and for the
+      bf16-output variants one more output rounding (8e-2 + 4e-2*|ref| kept from round 1 where not re-measured).
 """
 import os
 
@@ -546,10 +549,10 @@ def test_golden_F5_full_forward_P1(dev, golden_dir):
     st = int(g["stride"])
     ref = torch.from_numpy(g["sample"])
     got = out[:, :, oy::st, ox::st]
-    assert_close(got, ref, 6e-2, 3e-2, "F5 strided sample")
+    assert_close(got, ref, 2e-2, 1e-2, "F5 strided sample")
     assert _forward_stats(got, ref)[1] <= 6e-3
-    assert_close(out[:, ::48, :2, :], torch.from_numpy(g["top_rows"]), 6e-2, 3e-2, "F5 top rows")
-    assert_close(out[:, ::48, :, -2:], torch.from_numpy(g["left_cols"]), 6e-2, 3e-2, "F5 right cols")
+    assert_close(out[:, ::48, :2, :], torch.from_numpy(g["top_rows"]), 2e-2, 1e-2, "F5 top rows")
+    assert_close(out[:, ::48, :, -2:], torch.from_numpy(g["left_cols"]), 2e-2, 1e-2, "F5 right cols")
     assert (out.mean(dim=(0, 2, 3)) - torch.from_numpy(g["ch_mean"])).abs().max() <= 5e-3
     # bf16 features -> bf16 output, same values within one more rounding
     out_b = m(img.to(dev), ft.to(dev).to(torch.bfloat16), [224, 224])
@@ -576,7 +579,7 @@ def test_golden_F9_noninteger_ratio(dev, golden_dir, tag):
     out = m(img, ft, (H, W)).float().cpu()
     got = out[:, :, 1::2, ::2] if tag == "a" else out[:, ::4, 1::2, ::3]
     ref = torch.from_numpy(g[f"{tag}_sample"])
-    assert_close(got, ref, 6e-2, 3e-2, f"F9{tag} strided sample vs reference")
+    assert_close(got, ref, 2e-2, 1e-2, f"F9{tag} strided sample vs reference")
     assert _forward_stats(got, ref)[1] <= 6e-3
 
 
@@ -623,7 +626,7 @@ def test_golden_F7_preshrink_and_pool(dev, golden_dir):
     for tag in ("a", "b"):
         img = O.hash_normal(tuple(g[f"image_shape_{tag}"]), int(g[f"image_seed_{tag}"]))
         out = m(img.to(dev), ft.to(dev), tuple(int(s) for s in g[f"out_size_{tag}"]))
-        assert_close(out.float().cpu(), torch.from_numpy(g[f"out_{tag}"]), 6e-2, 3e-2, f"F7{tag}")
+        assert_close(out.float().cpu(), torch.from_numpy(g[f"out_{tag}"]), 2e-2, 1e-2, f"F7{tag}")
 
 
 @pytest.mark.parametrize("B,C,lr,out_sz,ksz,out_dtype", [
@@ -797,7 +800,7 @@ def test_forward_train_gradients_match_oracle(dev):
     out = m.forward_train(img.to(dev), fd, (48, 48))
     (out.float() * wgt.to(dev)).sum().backward()
     ref_out = O.naf_forward(p, img, ft, (48, 48), kernel_size=3)
-    assert_close(out.float().cpu(), ref_out, 6e-2, 3e-2, "forward_train output")
+    assert_close(out.float().cpu(), ref_out, 2e-2, 1e-2, "forward_train output")
     checked = 0
     for name, prm in m.named_parameters():
         ref = po[name].grad
@@ -873,7 +876,7 @@ def test_heads_rope_differs_from_heads_attn(dev):
     img = O.hash_normal((1, 3, 16, 16), 81)
     ft = O.hash_normal((1, 8, 4, 4), 82)
     ref = O.naf_forward(p, img, ft, (16, 16), kernel_size=3, heads_attn=4, heads_rope=1)
-    assert_close(m(img.to(dev), ft.to(dev), (16, 16)).float().cpu(), ref, 6e-2, 3e-2, "heads 1/4")
+    assert_close(m(img.to(dev), ft.to(dev), (16, 16)).float().cpu(), ref, 2e-2, 1e-2, "heads 1/4")
 
 
 # ---- BASELINE full sizes: size-independent properties + sampled rows vs the oracle ----------------------
@@ -1000,7 +1003,7 @@ def test_full_forward_odd_shapes_match_oracle(dev, img_hw, lr, C, ksz):
     out = m(img.to(dev), ft.to(dev), img_hw).float().cpu()
     assert out.shape == ref.shape
     err = (out - ref).abs()
-    assert float(err.max()) <= 6e-2 + 3e-2 * float(ref.abs().max()) and float(err.mean()) <= 6e-3, \
+    assert float(err.max()) <= 2e-2 + 1e-2 * float(ref.abs().max()) and float(err.mean()) <= 6e-3, \
         f"max {float(err.max()):.3e} mean {float(err.mean()):.3e}"
 
 
@@ -1036,7 +1039,7 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     m.single_call = True
     assert a.dtype == b.dtype and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "single-call forward vs oracle")
+    assert_close(a.float().cpu(), ref, 2e-2, 1e-2, "single-call forward vs oracle")
     # a different architecture (other window per axis) falls back to the composed path
     m.upsampler.kernel_size = (5, 3)
     assert m._forward_plan(img, ft, (96, 128)) is None
@@ -1081,7 +1084,10 @@ def test_single_call_forward_other_geometries(dev, hw, lr, C, ksz, path):
     assert ("xna_" + path) in rec.seen, sorted(rec.seen)
     assert torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), hw, kernel_size=ksz)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"single-call forward vs oracle {hw} {lr}")
+    # cells of 1 or 2 pixels: each query's own cell dominates its window (q.k of the cell it was pooled from), the softmax is
+    # peaked and the output follows single keys instead of averaging them -- the stem's bf16 error shows undamped
+    small_cells = hw[0] // lr[0] <= 2
+    assert_close(a.float().cpu(), ref, *((6e-2, 3e-2) if small_cells else (2e-2, 1e-2)), f"single-call forward vs oracle {hw} {lr}")
 
 
 @pytest.mark.parametrize("L_out,L_in,k", [(64, 28, 9), (512, 37, 9), (518, 37, 15), (23, 5, 3), (30, 7, 5), (256, 256, 15),
@@ -1127,7 +1133,7 @@ def test_single_call_forward_with_pooled_guidance(dev, img_hw, out_hw, lr, C, ks
     m.single_call = True
     assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pooled forward vs oracle {img_hw} -> {out_hw}")
+    assert_close(a.float().cpu(), ref, 2e-2, 1e-2, f"pooled forward vs oracle {img_hw} -> {out_hw}")
 
 
 @pytest.mark.parametrize("shape,size,fmt", [((2, 3, 97, 130), (24, 32), "f32"), ((1, 3, 64, 200), (40, 40), "bf16_nhwc"), ((1, 3, 33, 33), (32, 8), "f32")])
@@ -1158,7 +1164,7 @@ def test_single_call_forward_with_preshrunk_image(dev, img_hw, out_hw, lr, C, ks
     m.single_call = True
     assert a.shape == (1, C, *out_hw) and torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), out_hw, kernel_size=ksz)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"pre-shrunk forward vs oracle {img_hw} -> {out_hw}")
+    assert_close(a.float().cpu(), ref, 2e-2, 1e-2, f"pre-shrunk forward vs oracle {img_hw} -> {out_hw}")
 
 
 @pytest.mark.parametrize("img_hw,lr,C,ksz", [((64, 64), (4, 4), 128, 3),       # rotate-on-load cell kernel writes the logits
@@ -1176,7 +1182,7 @@ def test_single_call_forward_return_weights(dev, img_hw, lr, C, ksz):
     m.single_call = True
     assert torch.equal(a, b) and torch.equal(wa, wb) and wa.shape == (1, 4, *img_hw, ksz * ksz)
     ref, ref_w = O.naf_forward(p, img.cpu(), ft.float().cpu(), img_hw, kernel_size=ksz, return_weights=True)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, "out with return_weights")
+    assert_close(a.float().cpu(), ref, 2e-2, 1e-2, "out with return_weights")
     assert float((wa.cpu() - ref_w).abs().mean()) <= 2e-2
 
 
@@ -1195,7 +1201,7 @@ def test_single_call_forward_with_different_rope_heads(dev, heads_rope, heads_at
     m.single_call = True
     assert torch.equal(a, b)
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (64, 64), kernel_size=3, heads_attn=heads_attn, heads_rope=heads_rope)
-    assert_close(a.float().cpu(), ref, 6e-2, 3e-2, f"heads_rope {heads_rope} heads_attn {heads_attn}")
+    assert_close(a.float().cpu(), ref, 2e-2, 1e-2, f"heads_rope {heads_rope} heads_attn {heads_attn}")
 
 
 @pytest.mark.parametrize("img_hw,out_hw,lr,C,ksz", [((64, 64), (64, 64), (4, 4), 128, 3), ((96, 80), (48, 40), (6, 5), 64, 5)])
