@@ -28,6 +28,7 @@ struct StemConv1Params {
     double* stats_out;
     int32_t B, H, W;
     int32_t groups_per_image;  // ceil(H*W / 32)
+    int32_t groups_per_block;  // > 0: a workgroup owns this many CONSECUTIVE groups (its waves interleave inside that range)
     float eps;
     int64_t xs[3], ys[3];
     // IMG variant: the input is bf16(conv0_1x1(image)) recomputed per 32-pixel group
@@ -83,8 +84,12 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     }
     __syncthreads();
 
-    const int ngroups = p.groups_per_image;
-    const int gstride = gridDim.x * NW1;
+    // Work -> memory map.  Round 1: group g = blockIdx.x * NW1 + wave, then += gridDim.x * NW1 (a persistent grid-stride walk).
+    // Persistent grid-stride loops stream at 4.2-4.9 TB/s on these boxes, block-contiguous ranges handed out in dispatch order at
+    // 5.3-6.2 (profiles/r02_hbm_ceiling.txt): a workgroup now owns `groups_per_block` consecutive groups.
+    const int gbase = blockIdx.x * p.groups_per_block;
+    const int ngroups = min(p.groups_per_image, gbase + p.groups_per_block);
+    const int gstride = NW1;
     const int npx = p.H * p.W;
     bf16_t* otw = ot + wave * 32 * OROW1;
 
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
 
     u32x4_t raw[8];
     float sv[2] = {0.f, 0.f};
-    int g = blockIdx.x * NW1 + wave;
+    int g = gbase + wave;
     if constexpr (IMG) load_taps(g, sv);
     else load_group(g, raw);
     // First group landed BEFORE the loop is entered: otherwise the loop header inherits "8 loads in flight, nothing
@@ -359,9 +364,11 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
     const int64_t slots = (int64_t)naf_cu_count() * (NW1 <= 4 ? 2 : 1) * NW1;                 // resident waves
     const int64_t total = (int64_t)p.groups_per_image * a->B;
     const int64_t gpw = (total + slots - 1) / slots;                                          // groups per wave
-    int64_t nbx = (p.groups_per_image + gpw * NW1 - 1) / (gpw * NW1);
-    const int64_t maxb = (p.groups_per_image + NW1 - 1) / NW1;
-    if (nbx > maxb) nbx = maxb;
+    // groups per workgroup: the round-1 share (one residency round, ~16 groups per wave), or fewer when NAF_C1X1_GPW pins it
+    static const int gpw_knob = [] { const char* e = naf_knob("NAF_C1X1_GPW"); return e ? atoi(e) : 0; }();
+    const int64_t gpw_eff = gpw_knob > 0 ? gpw_knob : gpw;
+    p.groups_per_block = (int32_t)(gpw_eff * NW1);
+    int64_t nbx = (p.groups_per_image + p.groups_per_block - 1) / p.groups_per_block;
     if (nbx < 1) nbx = 1;
     if (a->B > 65535) {
         naf_set_error("naf_stem_conv_fwd: batch %d out of range", a->B);

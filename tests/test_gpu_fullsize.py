@@ -313,3 +313,41 @@ def test_denoising_configuration_runs_entirely_on_hip(dev):
     ref = O.naf_forward(p, img, noisy, (S, S), kernel_size=15, heads_attn=1, heads_rope=1)
     _assert_close(out, ref, 1e-1, 4e-2, "denoising configuration")
     assert float((out - ref).abs().mean()) <= 8e-3
+
+
+def test_attention_G3_whole_batch_of_64_in_one_launch(dev):
+    """BASELINE configs[3]'s whole batch on ONE GPU in ONE launch (maximum size: 64 images, C = 1024, 1024^2: 34 GB of queries,
+    137 GB of bf16 output, 2^36 output elements -- every offset past 2^31 elements is exercised): partition of unity on
+    every image, sampled rows of the first, a middle and the last image against the oracle."""
+    from naf_amd import ops
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 200 * 2 ** 30:
+        pytest.skip(f"needs ~175 GB of free device memory, {free / 2 ** 30:.0f} GB available")
+    torch.cuda.empty_cache()
+    B, C, lr, out_sz, ksz, heads = 64, 1024, 64, 1024, 7, 4
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    k = torch.randn(B, 256, lr, lr, generator=gen)
+    v = torch.randn(B, C, lr, lr, generator=gen).to(torch.bfloat16).float()
+    q5 = torch.empty((B, heads, out_sz, out_sz, 64), dtype=torch.bfloat16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(6)
+    for b in range(B):                                    # per image: no 68 GB fp32 temporary
+        q5[b] = torch.randn(heads, out_sz, out_sz, 64, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    k5 = k.view(B, heads, 64, lr, lr).permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16).to(dev)
+    vp = ops.pack_values(v.to(dev))
+    v5 = vp.view(B, lr, lr, heads, C // heads).permute(0, 3, 1, 2, 4)
+    out = ops.xna_forward(q5, k5, v5, ksz, out_dtype=torch.bfloat16, path="mfma")
+    torch.cuda.synchronize()
+    assert out.shape == (B, heads, out_sz, out_sz, C // heads)
+    rows = [0, 17, 511, 1023]
+    iy = O.axis_index_table(out_sz, lr, ksz)[rows]
+    ix = O.axis_index_table(out_sz, lr, ksz)
+    kb = k.to(torch.bfloat16).float()
+    for b in (0, 31, 63):
+        q_rows = q5[b:b + 1, :, rows].float().cpu().permute(0, 1, 4, 2, 3).reshape(1, 256, len(rows), out_sz)
+        ref = O.xna_tables(q_rows, kb[b:b + 1], v[b:b + 1], iy, ix, heads)
+        got = out[b:b + 1, :, rows].permute(0, 1, 4, 2, 3).reshape(1, C, len(rows), out_sz).float().cpu()
+        _assert_close(got, ref, 1.2e-2, 1.2e-2, f"B=64 launch, image {b}")
+    del out
+    ones = ops.xna_forward(q5, k5, torch.full_like(v5, 0.5), ksz, out_dtype=torch.bfloat16, path="mfma")
+    for b in range(0, B, 7):
+        assert float((ones[b].float() - 0.5).abs().max()) <= 4e-3
