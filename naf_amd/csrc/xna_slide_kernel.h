@@ -28,7 +28,8 @@ struct XnaSlideParams {
 
 // TPWV = tiles a wave processes together (2: large windows, every K / V^T fragment feeds two MFMAs; 1: HBM-bound small
 // windows).  STG (bf16 output, TPWV == 1): whole-row stores through a per-wave LDS tile, as in xna_mfma_kernel.
-// ABL: ablation bits for tools/xna_probe.hip (1 no output stores, 4 no query loads, 8 no window column loads).
+// ABL: ablation bits for tools/xna_probe.hip (1 no output stores, 2 no PV MFMAs / V reads, 4 no query loads, 8 no window
+// column loads, 16 no QK MFMAs / K reads).
 template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams sp) {
     const XnaMfmaParams& p = sp.m;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                     s[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
+                        if (ABL & 16) { s[mt][ks] += (float)qf[u][ks][mt & 7]; continue; }     // probe: no QK MFMAs / K reads
                         const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ka_of(mt) + ks * 32);
                         s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[mt], 0, 0, 0);
                     }
@@ -312,6 +314,11 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 for (int u = 0; u < TPW; ++u) acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KST; ++ks) {
+                    if (ABL & 2) {                                                              // probe: no PV MFMAs / V reads
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) acc[u][ks & 3] += (float)pf[u][ks][ct & 7];
+                        continue;
+                    }
                     const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2) + ct * 16));
                     const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(va_of(ks * 2 + 1) + ct * 16));
                     bf16x8_t a;

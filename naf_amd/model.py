@@ -582,6 +582,17 @@ class NAF(nn.Module):
                                f"image on {image.device}, features on {features.device}")
         if image.dim() != 4 or features.dim() != 4 or image.shape[0] != features.shape[0]:
             raise ValueError(f"expected image [B,3,H,W] and features [B,C,h,w], got {tuple(image.shape)} / {tuple(features.shape)}")
+        if image.shape[0] == 0:
+            # an empty batch flows through the reference's torch ops as empty tensors; there is nothing to launch here
+            ho, wo = int(output_size[0]), int(output_size[1])
+            odt = features.dtype if features.dtype in (torch.bfloat16, torch.float32) else torch.float32
+            out = torch.empty((0, ho, wo, features.shape[1]), dtype=odt, device=features.device).permute(0, 3, 1, 2)
+            if out.dtype != features.dtype:
+                out = out.to(features.dtype)
+            if return_weights:
+                k = self.upsampler.kernel_size
+                return out, torch.empty((0, self.upsampler.num_heads, ho, wo, k[0] * k[1]), dtype=torch.float32, device=features.device)
+            return out
         if self.single_call:
             plan = self._forward_plan(image, features, output_size)
             if plan is not None:

@@ -351,3 +351,35 @@ def test_attention_G3_whole_batch_of_64_in_one_launch(dev):
     ones = ops.xna_forward(q5, k5, torch.full_like(v5, 0.5), ksz, out_dtype=torch.bfloat16, path="mfma")
     for b in range(0, B, 7):
         assert float((ones[b].float() - 0.5).abs().max()) <= 4e-3
+
+
+def test_edge_inputs_empty_batch_dtypes_and_strides(dev):
+    """Edge cases at the operator boundary: an empty batch (empty tensors in, empty tensors out, as through the reference's torch
+    ops), fp16 / fp64 features (computed through the bf16 / fp32 contract, returned in the caller's dtype), a non-contiguous
+    image view and channels-last features, batch elements that are views of a larger tensor."""
+    p = O.make_params(seed=81)
+    m = _load_model(dev, p, kernel_size=3)
+    out = m(torch.empty(0, 3, 32, 32, device=dev), torch.empty(0, 64, 2, 2, device=dev), (32, 32))
+    assert out.shape == (0, 64, 32, 32)
+    o2, lg = m(torch.empty(0, 3, 32, 32, device=dev), torch.empty(0, 64, 2, 2, device=dev, dtype=torch.bfloat16), (32, 32), return_weights=True)
+    assert o2.shape == (0, 64, 32, 32) and o2.dtype == torch.bfloat16 and lg.shape == (0, 4, 32, 32, 9)
+    img = O.hash_normal((2, 3, 48, 64), 8101)
+    ft = O.hash_normal((2, 64, 3, 4), 8102)
+    ref = O.naf_forward(p, img, ft, (48, 64), kernel_size=3)
+    base = m(img.to(dev), ft.to(dev), (48, 64)).float().cpu()
+    _assert_close(base, ref, 2e-2, 1e-2, "contiguous fp32 inputs")
+    for dt in (torch.float16, torch.float64):
+        o = m(img.to(dev), ft.to(dev).to(dt), (48, 64))
+        assert o.dtype == dt
+        _assert_close(o.float().cpu(), ref, 2e-2, 1e-2, f"{dt} features")
+    # strided views: the image as a crop of a larger canvas, the features channels-last, both as slices of a bigger batch
+    canvas = torch.zeros(4, 3, 60, 80, device=dev)
+    canvas[1:3, :, 5:53, 7:71] = img.to(dev)
+    fcl = torch.zeros(4, 3, 4, 64, device=dev)
+    fcl[1:3] = ft.to(dev).permute(0, 2, 3, 1)
+    o = m(canvas[1:3, :, 5:53, 7:71], fcl[1:3].permute(0, 3, 1, 2), (48, 64)).float().cpu()
+    assert float((o - base).abs().max()) <= 1e-6, "strided inputs must give the contiguous result"
+    with pytest.raises(ValueError):
+        m(img.to(dev), ft[:1].to(dev), (48, 64))                       # batch mismatch
+    with pytest.raises(ValueError):
+        m(img.to(dev), ft.to(dev), (2, 64))                            # output smaller than the feature grid (dilation 0)

@@ -226,6 +226,21 @@ int main(int argc, char** argv) {
         run_pattern<1>(p, reps, "pattern: 384 B contiguous pieces", bytes);
         run_pattern<0>(p, reps, "pattern: 16 px x 64 B pieces (again)", bytes);
     }
+    if (PROBE_KS >= 11 && argc > 7) {   // large windows, sliding kernel (the library's choice): argv[7] = cells per segment
+        const int sl = atoi(argv[7]);
+        printf("-- sliding-window kernel k=%d Dv tile %d, 8 waves x 2 tiles, order %d --\n", PROBE_KS, PROBE_DVT, order);
+        run_slide<8, 2, false>(p, sl, reps, "full", bytes);
+        run_slide<8, 2, false, 1>(p, sl, reps, "no stores", bytes);
+        run_slide<8, 2, false, 2>(p, sl, reps, "no PV mfma / V reads", bytes);
+        run_slide<8, 2, false, 4>(p, sl, reps, "no Q loads", bytes);
+        run_slide<8, 2, false, 8>(p, sl, reps, "no column loads", bytes);
+        run_slide<8, 2, false, 16>(p, sl, reps, "no QK mfma / K reads", bytes);
+        run_slide<8, 2, false, 2 | 16>(p, sl, reps, "no mfma at all", bytes);
+        run_slide<8, 2, false, 1 | 4 | 8>(p, sl, reps, "compute only", bytes);
+        run_slide<8, 2, false, 1 | 2 | 4 | 8 | 16>(p, sl, reps, "softmax only", bytes);
+        run_slide<8, 2, false>(p, sl, reps, "full (again)", bytes);
+        return 0;
+    }
     if (PROBE_KS >= 11) {
         // large windows: the library's configuration is unstaged, 8 waves, 2 tiles per wave
         run<0, false, 1, 8, 2>(p, reps, "full kernel (8 waves, 2 tiles/wave)", bytes);
