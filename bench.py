@@ -13,7 +13,7 @@ For N>1 the workload is BASELINE.json configs[3] ("G3"): ONE batch of 64 images 
 1024x64x64 features (DINOv3-ViT-L width) -> 1024x1024, sharded 64/N images per rank (strong scaling: the
 total work is fixed).  Rank 0 creates the whole batch; the parameters travel by one flat RCCL broadcast
 and the inputs by one RCCL scatter each (naf_amd.dist), both BEFORE the timed region; inside it every rank
-runs its shard through naf_amd.dist.ShardedNAF (micro-batches of 2) with no data-path collective -- the
+runs its shard through naf_amd.dist.ShardedNAF (micro-batches of 8) with no data-path collective -- the
 path is embarrassingly parallel over the batch.  After the timed region rank 0 alone runs the same 64
 images on its one GPU to report `speedup_vs_1`.  Rank 0 prints ONE JSON line.
 
@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: G1 on one GPU, G3 on several")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="single-GPU runs: images per step")
     ap.add_argument("--total-batch", type=int, default=64, help="multi-GPU runs: images of the whole job, sharded over the ranks")
-    ap.add_argument("--micro-batch", type=int, default=2, help="multi-GPU runs: images per forward inside a rank's shard")
+    ap.add_argument("--micro-batch", type=int, default=8, help="multi-GPU runs: images per forward inside a rank's shard "
+                    "(G3 on one GPU: 449 / 461 / 465 Mpix/s at 2 / 4 / 8 images per call; 8 images hold 25 GB of activations and output)")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="multi-GPU runs: skip rank 0's solo run of the whole batch")
     ap.add_argument("--cpu-baseline-budget", type=float, default=25.0, help="seconds of host time for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
