@@ -236,6 +236,187 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
     }
 }
 
+// ---- 3x3 first layer on the bf16 matrix pipe: three-way split of image and weights ---------------------------------------
+// stem_conv0_kernel<3> is bound by the fp32 matrix pipe (56 v_mfma_f32_32x32x2_f32 of 64 cycles per 32-pixel segment: 49 % MFMA
+// busy, profiles/r02_pmc_mfma_util.txt) although the layer only has 268 MB to write.  An fp32 number is the exact sum of three
+// bf16 numbers (8 + 8 + 8 mantissa bits): x = xh + xm + xl, w = wh + wm + wl, and
+//     x w = xh wh + (xh wm + xm wh) + (xh wl + xl wh + xm wm) + O(2^-24 |x w|)
+// so six bf16 products accumulated in fp32 reproduce the fp32 product to its own rounding error.  As a GEMM: K = 6 terms x 32
+// tap slots (27 taps + 5 zero weights) = 12 k-steps of v_mfma_f32_32x32x16_bf16 per oc-tile -- 48 MFMAs of 32 cycles per
+// segment instead of 56 of 64 (2.3x less matrix time).  The k-axis is laid out so that a lane (pixel n32, k-group kg) needs only
+// ITS 16 taps (slots s*16 + kg*8 + j): it splits them once into three pairs of bf16x8 fragments, and every term re-uses one of
+// those six B fragments; the A fragments (weight parts, [12 k-steps][128 oc][16 k] bf16 = 48 KB) are split once per workgroup
+// into LDS and read with ds_read_b128.  Terms are accumulated smallest first.  Epilogue / stores / statistics as above.
+// Not bit-equal to an fmaf chain any more (the 1x1 layer, whose recompute relies on that, keeps the fp32 kernel): agrees with it
+// to ~1e-7 relative before the bf16 rounding of the output (tests/test_gpu_parity.py::test_stem_conv0).
+namespace {
+constexpr int NWS = 8;                                   // waves per workgroup (the 48 KB of split weights are shared by 8 waves)
+// term t = (image part, weight part), smallest products first;  parts: 0 = high, 1 = middle, 2 = low
+__device__ __forceinline__ constexpr int split_xpart(int t) { return t == 0 ? 1 : t == 1 ? 2 : t == 2 ? 0 : t == 3 ? 1 : t == 4 ? 0 : 0; }
+__device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 1 : t == 1 ? 0 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const StemConv0Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem0);                       // [12][128][16]
+    bf16_t* otile = wl + 12 * C0 * 16;                                    // [NWS][32][OPX]
+    float* biasv = reinterpret_cast<float*>(otile + NWS * 32 * OPX);      // [128]
+    float* red = biasv + C0;                                              // [NWS][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    const T* ib = reinterpret_cast<const T*>(p.img) + (int64_t)b * p.ibs;
+
+    // split weights -> LDS: element (kstep = term*2 + s, oc, k = kg*8 + j) = part wpart(term) of W[oc][tap = s*16 + k] (0 past 27)
+    for (int i = tid; i < C0 * 32; i += NWS * 64) {
+        const int oc = i >> 5, tap = i & 31;
+        const float w = tap < 27 ? p.w[oc * 27 + tap] : 0.f;
+        const bf16_t w0 = (bf16_t)w;
+        const float r1 = w - (float)w0;
+        const bf16_t w1 = (bf16_t)r1;
+        const bf16_t w2 = (bf16_t)(r1 - (float)w1);
+        const int s = tap >> 4, k = tap & 15;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int wp = split_wpart(t);
+            wl[((t * 2 + s) * C0 + oc) * 16 + k] = wp == 0 ? w0 : wp == 1 ? w1 : w2;
+        }
+    }
+    if (tid < C0) biasv[tid] = p.bias[tid];
+    __syncthreads();
+
+    // this lane's 16 taps of segment g: slot (s, j) -> tap s*16 + half*8 + j -> (c, dy, dx); slots past 27 re-read tap 26 (weight 0)
+    auto load_taps = [&](int g, float (&sv)[16]) __attribute__((always_inline)) {
+        const int gc = min(g, p.ngroups - 1);
+        const int y = gc / p.gpr, x0 = (gc - y * p.gpr) * 32;
+        int ro[3], xo[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ro[d] = reflect0(y + d - 1, p.H) * p.is[2];
+            xo[d] = reflect0(x0 + n32 + d - 1, p.W) * p.is[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ta = min((q >> 3) * 16 + (q & 7), 26), tb = min((q >> 3) * 16 + 8 + (q & 7), 26);   // half = 0 / 1
+            const int oa = (ta / 9) * p.is[1] + ro[(ta / 3) % 3] + xo[ta % 3], ob = (tb / 9) * p.is[1] + ro[(tb / 3) % 3] + xo[tb % 3];
+            sv[q] = (float)ib[half ? ob : oa];
+        }
+    };
+    // three bf16 parts of the 16 taps as B fragments: xb[part][s]
+    auto split_taps = [&](const float (&sv)[16], bf16x8_t (&xb)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float x = sv[q];
+            const bf16_t x0 = (bf16_t)x;
+            const float r1 = x - (float)x0;
+            const bf16_t x1 = (bf16_t)r1;
+            const bf16_t x2 = (bf16_t)(r1 - (float)x1);
+            xb[0][q >> 3][q & 7] = x0;
+            xb[1][q >> 3][q & 7] = x1;
+            xb[2][q >> 3][q & 7] = x2;
+        }
+    };
+
+    f32x2_t s1p[8], s2p[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s1p[g] = s2p[g] = f32x2_t{0.f, 0.f};
+    bf16_t* yb = p.y + (int64_t)b * p.ys[0];
+    bf16_t* otw = otile + wave * 32 * OPX;
+    const int chk = lane & 15, psub = lane >> 4;
+    const int gstride = gridDim.x * NWS;
+    const uint32_t st_lane = (uint32_t)(psub * (int)p.ys[2] + chk * 8) * 2u;
+    const bf16_t* wa = wl + n32 * 16 + half * 8;           // + (kstep * 128 + 32 m) * 16
+
+    float sv[16], nx[16];
+    int g = blockIdx.x * NWS + wave;
+    load_taps(g, sv);
+    for (; g < p.ngroups; g += gstride) {
+        bf16x8_t xb[3][2];
+        split_taps(sv, xb);
+        load_taps(g + gstride, nx);                          // next segment's taps are in flight during this one's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
+        const float vmask = (x0 + n32 < p.W) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            f32x16_t acc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(wa + ((t * 2 + s) * C0 + 32 * (2 * mp + q)) * 16);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[split_xpart(t)][s], acc[q], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 2 * mp + q;
+                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(&biasv[32 * m + 8 * j + 4 * half]);
+                    const f32x2_t v0 = f32x2_t{acc[q][j * 4], acc[q][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
+                    const f32x2_t v1 = f32x2_t{acc[q][j * 4 + 2], acc[q][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+                    bf16x4_t o;
+                    o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
+                    const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
+                    s1p[m * 2 + (j >> 1)] += w0 + w1;
+                    s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
+                    if (p.y != nullptr) *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
+                }
+        }
+        if (p.y != nullptr) {
+            char* yr = reinterpret_cast<char*>(yb + (int64_t)y * p.ys[1] + (int64_t)x0 * p.ys[2]);
+            if (x0 + 32 <= p.W) {                            // whole segment: 8 reads, then 8 stores, no per-store predicate
+                u32x4_t v[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const u32x4_t*>(otw + (it * 4 + psub) * OPX + chk * 8);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4_t*>(yr + (int64_t)it * 8 * p.ys[2] + st_lane) = v[it];
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int pp = it * 4 + psub;
+                    if (x0 + pp < p.W) {
+                        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + pp * OPX + chk * 8);
+                        *reinterpret_cast<u32x4_t*>(yr + (int64_t)it * 8 * p.ys[2] + st_lane) = v;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sv[q] = nx[q];
+    }
+
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        float a = s1p[gq][0] + s1p[gq][1], q = s2p[gq][0] + s2p[gq][1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            q += __shfl_xor(q, o);
+        }
+        if (lane == 0) {
+            red[wave * 16 + gq] = a;
+            red[wave * 16 + 8 + gq] = q;
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NWS; ++wv) a += red[wv * 16 + tid];
+        atomicAdd(&p.stats_out[(b * 8 + (tid & 7)) * 2 + (tid >> 3)], (double)a);
+    }
+}
+
 // ---- statistics of the 1x1 layer without running it -------------------------------------------------------------
 // y = W x + b is linear in the 3-channel image, so the GroupNorm sums of y follow from the image's first and second
 // moments: sum_px y_c = W_c . S1 + N b_c,  sum_px y_c^2 = W_c^T S2 W_c + 2 b_c W_c . S1 + N b_c^2  with S1 = sum_px x,
@@ -335,6 +516,25 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     if (nbx > maxb) nbx = maxb;
     if (nbx < 1) nbx = 1;
     const dim3 g((uint32_t)nbx, (uint32_t)a->B), blk(256);
+    static const bool fp32_3x3 = [] { const char* e = naf_knob("NAF_CONV0_FP32"); return e && atoi(e) != 0; }();   // A/B knob
+    if (a->ksize == 3 && !fp32_3x3) {
+        // three-way bf16 split on the bf16 matrix pipe: one workgroup of 8 waves per CU, the same number of segments per wave
+        const int64_t slots8 = (int64_t)naf_cu_count() * NWS;
+        const int64_t gpw8 = (ng * a->B + slots8 - 1) / slots8;
+        int64_t nb8 = (ng + gpw8 * NWS - 1) / (gpw8 * NWS);
+        if (nb8 < 1) nb8 = 1;
+        const size_t lds = (size_t)(12 * C0 * 16 + NWS * 32 * OPX) * 2 + (size_t)(C0 + NWS * 16) * sizeof(float);
+        const dim3 g8((uint32_t)nb8, (uint32_t)a->B), blk8(NWS * 64);
+        auto launch = [&](auto kern) -> int {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                naf_set_error("naf_stem_conv0_fwd: cannot reserve %zu bytes of LDS", lds);
+                return NAF_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(kern, g8, blk8, lds, s, p);
+            return naf_check_launch("stem_conv0_split_kernel");
+        };
+        return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t>) : launch(stem_conv0_split_kernel<float>);
+    }
     if (a->ksize == 3) {
         if (a->image_dtype == NAF_BF16) hipLaunchKernelGGL((stem_conv0_kernel<3, bf16_t>), g, blk, 0, s, p);
         else hipLaunchKernelGGL((stem_conv0_kernel<3, float>), g, blk, 0, s, p);
