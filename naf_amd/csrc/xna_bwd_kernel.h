@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, grp = lane >> 4;
 
-    uint32_t L = naf_xcd_remap(blockIdx.x, p.nblocks);
+    // dispatch order in groups of 16 (xna_block_order in xna_mfma_kernel.h: all XCDs sweep the same cell rows)
+    uint32_t L = blockIdx.x;
+    if ((p.nblocks % 128u) == 0u) { const uint32_t xcd = L & 7u, idx = L >> 3; L = ((idx / 16u) * 8u + xcd) * 16u + idx % 16u; }
     const int head = L % p.heads;
     L /= p.heads;
     const int cx0 = L % p.w;
@@ -86,22 +88,40 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
     const int b = L / p.h;
     const int y0 = min(max(cy0 - KS / 2, 0), p.h - KS), x0 = min(max(cx0 - KS / 2, 0), p.w - KS);
 
-    // ---- stage the K and V windows ----
+    // ---- stage the K and V windows: all loads of a batch are issued before the first LDS write (behind a per-chunk loop
+    // iteration every load is followed by its own s_waitcnt vmcnt(0): one L2 round trip per 16-byte chunk per thread, which was
+    // 45 % of a forward workgroup's lifetime, profiles/r02_xna_phase_timing.txt) ----
     {
         const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
-        for (int i = tid; i < NSLOT * 8; i += 256) {
-            const int key = i >> 3, c = i & 7;
-            const int ry = key / KS, rx = key - ry * KS;
-            *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)(x0 + rx) * p.ks[3] + c * 8);
-        }
         const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1];
         constexpr int VCH = DV / 8;
-        for (int i = tid; i < NSLOT * VCH; i += 256) {
+        constexpr int KTOT = NSLOT * 8, VTOT = NSLOT * VCH;
+        constexpr int KIT = (KTOT + 255) / 256, VIT = (VTOT + 255) / 256;
+        constexpr int BATCH = 12;
+        auto chunk = [&](int j, int& off) __attribute__((always_inline)) -> const bf16_t* {
+            if (j < KIT) {
+                const int i = min(j * 256 + tid, KTOT - 1);
+                const int key = i >> 3, c = i & 7;
+                const int ry = key / KS, rx = key - ry * KS;
+                off = key * KROW + c * 8;
+                return kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)(x0 + rx) * p.ks[3] + c * 8;
+            }
+            const int i = min((j - KIT) * 256 + tid, VTOT - 1);
             const int key = i / VCH, c = i - key * VCH;
             const int ry = key / KS, rx = key - ry * KS;
-            *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)(x0 + rx) * p.vs[3] + c * 8);
+            off = NSLOT * KROW + key * VROW + c * 8;
+            return vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)(x0 + rx) * p.vs[3] + c * 8;
+        };
+#pragma unroll
+        for (int j0 = 0; j0 < KIT + VIT; j0 += BATCH) {
+            u32x4_t val[BATCH];
+            int off[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (j0 + u < KIT + VIT) val[u] = *reinterpret_cast<const u32x4_t*>(chunk(j0 + u, off[u]));
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (j0 + u < KIT + VIT) *reinterpret_cast<u32x4_t*>(Ks + off[u]) = val[u];     // clamped duplicates rewrite the last chunk
         }
     }
     __syncthreads();
