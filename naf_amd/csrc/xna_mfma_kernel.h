@@ -82,10 +82,10 @@ constexpr int XNA_ROPE_ROWS = 16;   // cell rows whose RoPE row tables ride in L
 
 // LDS bytes: K window [NSLOT][64+8] + V window [NSLOT][dvt+16] (pad key slots are NOT stored: their reads are
 // clamped to the last real row, P is exactly 0 there) + optional per-wave output staging tiles + (staged) the cell's
-// RoPE row tables [16][32] fp32.
+// RoPE row tables [16][32] fp32 and, in 8-wave workgroups (two of which share a CU: LDS to spare), its column tables too.
 constexpr size_t xna_mfma_lds_for(int ks, int cb, int dvt, bool staged, int nw = 4) {
     return (size_t)((ks + cb - 1) * (ks + cb - 1)) * (72 + dvt + 16) * 2 +
-           (staged ? (size_t)nw * 16 * xna_stage_row(dvt) * 2 + (size_t)XNA_ROPE_ROWS * 32 * 4 : 0);
+           (staged ? (size_t)nw * 16 * xna_stage_row(dvt) * 2 + (size_t)(nw >= 8 ? 2 : 1) * XNA_ROPE_ROWS * 32 * 4 : 0);
 }
 template <int KS, int CB, int DVT, bool STG, int NW = 4>
 constexpr size_t xna_mfma_lds_bytes() {
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     bf16_t* Vs = Ks + NSLOT * KROW;
     bf16_t* Os = Vs + NSLOT * VROW;  // [NW waves][16][OROW] when STG
     float* Ty = reinterpret_cast<float*>(Os + NW * 16 * OROW);   // STG: RoPE row tables of the cell [XNA_ROPE_ROWS][2][16]
+    float* Tx = Ty + XNA_ROPE_ROWS * 32;                         // NW >= 8: and its column tables (else registers)
+    constexpr bool TXL = STG && NW >= 8;
 
     uint64_t ts_in = 0, ts_staged = 0, ts_acc[5] = {0, 0, 0, 0, 0};
     XNA_TSTAMP(ts_in)
@@ -281,6 +283,8 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         const bool rope_lds = STG && CB == 1 && p.rope_lds && p.tab_y != nullptr && p.dy <= XNA_ROPE_ROWS && p.dx <= 16;
         f32x4_t tyv = {0.f, 0.f, 0.f, 0.f};
         if (rope_lds && tid < p.dy * 8) tyv = *reinterpret_cast<const f32x4_t*>(p.tab_y + (int64_t)(cy0 * p.dy + (tid >> 3)) * 32 + (tid & 7) * 4);
+        if (TXL && rope_lds && tid >= 128 && tid < 128 + p.dx * 8)
+            tyv = *reinterpret_cast<const f32x4_t*>(p.tab_x + (int64_t)(cx0 * p.dx + ((tid - 128) >> 3)) * 32 + (tid & 7) * 4);
         auto src_of = [&](int j) __attribute__((always_inline)) -> const bf16_t* {   // j < KIT: K chunk, else V chunk
             if (j < KIT) {
                 const int i = min(j * NT + tid, KTOT - 1);
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
             }
         }
         if (rope_lds && tid < p.dy * 8) *reinterpret_cast<f32x4_t*>(Ty + (tid >> 3) * 32 + (tid & 7) * 4) = tyv;
+        if (TXL && rope_lds && tid >= 128 && tid < 128 + p.dx * 8) *reinterpret_cast<f32x4_t*>(Tx + ((tid - 128) >> 3) * 32 + (tid & 7) * 4) = tyv;
     }
     const bool rope = p.tab_y != nullptr;   // rotate-on-load (host guarantees the FAST path then)
     __syncthreads();
@@ -353,14 +358,25 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
         constexpr bool RL = ROPE && STG && decltype(rlc)::value;    // tables from LDS (rows) / registers (columns)
         // RL: one tile per cell row (dx <= 16): the column angles of this lane's pixel are the same for every tile
         f32x4_t csx[4] = {};
-        if constexpr (RL) {
+        if constexpr (RL && !TXL) {
             const float* tr = p.tab_x + (int64_t)(cx0 * p.dx + min(col, p.dx - 1)) * 32 + (grp & 1) * 8;
             csx[0] = *reinterpret_cast<const f32x4_t*>(tr);
             csx[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
             csx[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
             csx[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
         }
+        // per-lane LDS address of the column-part tables (lanes grp >= 2); the row part adds the tile's row
+        const float* tx_lane = Tx + min(col, p.dx - 1) * 32 + (grp & 1) * 8;
         auto rope_tab = [&](int tt, f32x4_t (&cs)[4]) __attribute__((always_inline)) {   // RL: tile tt = cell row tt
+            if constexpr (TXL) {
+                // both tables in LDS: every lane reads ITS table row (row part: the tile's row, column part: its pixel's column)
+                const float* tr = (grp < 2) ? Ty + min(tt, ttot - 1) * 32 + (grp & 1) * 8 : tx_lane;
+                cs[0] = *reinterpret_cast<const f32x4_t*>(tr);
+                cs[1] = *reinterpret_cast<const f32x4_t*>(tr + 4);
+                cs[2] = *reinterpret_cast<const f32x4_t*>(tr + 16);
+                cs[3] = *reinterpret_cast<const f32x4_t*>(tr + 20);
+                return;
+            }
             const float* tr = Ty + min(tt, ttot - 1) * 32 + (grp & 1) * 8;
             const f32x4_t l0 = *reinterpret_cast<const f32x4_t*>(tr), l1 = *reinterpret_cast<const f32x4_t*>(tr + 4);
             const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(tr + 16), l3 = *reinterpret_cast<const f32x4_t*>(tr + 20);
