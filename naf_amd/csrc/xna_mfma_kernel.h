@@ -389,6 +389,8 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                 cs[3][i] = rowpart ? l3[i] : csx[3][i];
             }
         };
+        // (rotating the first tile BEFORE the barrier, with table rows fetched from memory beside the queries, was measured:
+        // -6 %, the wait for them delays the window's LDS writes)
         if constexpr (ROPE) {
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
