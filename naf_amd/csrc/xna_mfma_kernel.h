@@ -255,17 +255,24 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     // first tile's queries: issued before the window staging so their HBM latency hides under it
     // TPW tiles (16 queries each) are processed together by a wave: the K and V^T fragments read from LDS
     // feed TPW MFMAs each, halving LDS traffic per FLOP at TPW = 2 (large windows are LDS/MFMA-bound).
+    // (Loads return in order: requested AHEAD of the window chunks -- round 1 -- the queries' HBM latency also delays the
+    // chunks' L2 hits, i.e. the LDS writes and the barrier.  They are now requested right behind the window's last batch of
+    // loads: the writes wait for the chunks only, the queries land during the writes and the barrier.  ABL 32768: old order.)
     bf16x8_t qf[TPW][2];
+    auto load_first_queries = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const bf16_t* qp = fast ? q_ptr_fast(wave * TPW + u) : q_ptr(wave * TPW + u);
-        if (!(ABL & 4)) {
-            qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
-            qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-        } else {
-            qf[u][0] = qf[u][1] = bf16x8_t{};
+        for (int u = 0; u < TPW; ++u) {
+            const bf16_t* qp = fast ? q_ptr_fast(wave * TPW + u) : q_ptr(wave * TPW + u);
+            if (!(ABL & 4)) {
+                qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+            } else {
+                qf[u][0] = qf[u][1] = bf16x8_t{};
+            }
         }
-    }
+    };
+    constexpr bool Q_AFTER_WINDOW = !(ABL & 32768);
+    if constexpr (!Q_AFTER_WINDOW) load_first_queries();
 
     // ---- stage the K and V windows (L2 -> registers -> LDS).  Slots outside the grid (only possible for the
     // extra row / column of a CB = 2 window at the border) load a clamped cell; no query attends to them.
@@ -305,6 +312,9 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 if (j0 + u < KIT + VIT) val[u] = (ABL & 8) ? u32x4_t{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(src_of(j0 + u));
+            }
+            if constexpr (Q_AFTER_WINDOW) {
+                if (j0 + BATCH >= KIT + VIT) load_first_queries();      // behind the LAST batch of window loads
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {

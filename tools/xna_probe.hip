@@ -262,7 +262,7 @@ int main(int argc, char** argv) {
         struct Var { const char* name; int nw; int order; int rl; int pf1; };
         // pf1 field: ABL bits (1024 = single prefetch, 2048 = no preload of both tiles)
         const Var vars[] = {{"4w g16 rl predicated st  ", 4, 16, 1, 8192}, {"4w g16 rl                ", 4, 16, 1, 0},
-                            {"8w g16 rl predicated st  ", 8, 16, 1, 8192}, {"8w g16 rl                ", 8, 16, 1, 0}, {"8w g4 rl                 ", 8, 4, 1, 0},
+                            {"8w g16 rl q before window", 8, 16, 1, 32768}, {"8w g16 rl                ", 8, 16, 1, 0}, {"8w g4 rl                 ", 8, 4, 1, 0},
                             {"8w g32 rl                ", 8, 32, 1, 0},  {"8w dispatch rl           ", 8, 1, 1, 0}, {"8w band rl               ", 8, 0, 1, 0}};
         constexpr int NV = sizeof(vars) / sizeof(vars[0]);
         const int rounds = 12;
@@ -279,7 +279,7 @@ int main(int argc, char** argv) {
                 CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3(pv.nblocks), dim3(NWV * 64), lds, 0, pv);
             };
-            if (v.nw == 8) { if (v.pf1 == 8192) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 8192>{}); else go(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}); }
+            if (v.nw == 8) { if (v.pf1 == 32768) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 32768>{}); else go(std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}); }
             else { if (v.pf1 == 8192) go(std::integral_constant<int, 4>{}, std::integral_constant<int, 8192>{}); else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 0>{}); }
         };
         for (int w = 0; w < 3; ++w) for (const Var& v : vars) launch(v);
