@@ -106,18 +106,21 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
         }
     };
 
-    // queries of this wave's first pair of tiles: in flight during the window staging
+    // queries of this wave's first pair of tiles: requested right BEHIND the window's last batch of loads (loads return in
+    // order: ahead of them, the queries' HBM latency would delay the chunks' LDS writes and the barrier, see xna_mfma_kernel.h)
     bf16x8_t qf[TPW][2];
+    auto load_first_queries = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const bf16_t* qp = q_ptr(wave * TPW + u);
-        if (!(ABL & 4)) {
-            qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
-            qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-        } else {
-            qf[u][0] = qf[u][1] = bf16x8_t{};
+        for (int u = 0; u < TPW; ++u) {
+            const bf16_t* qp = q_ptr(wave * TPW + u);
+            if (!(ABL & 4)) {
+                qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+                qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+            } else {
+                qf[u][0] = qf[u][1] = bf16x8_t{};
+            }
         }
-    }
+    };
 
     // ---- full window of the segment's first cell; low-res column x -> column slot x % KS ----
     const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                     const bf16_t* src = chunk_of(j0 + u, off[u]);
                     val[u] = (ABL & 8) ? u32x4_t{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(src);
                 }
+            if (j0 + BATCH >= KIT + VIT) load_first_queries();
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int j = j0 + u;
