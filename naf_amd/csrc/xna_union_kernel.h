@@ -133,20 +133,34 @@ __global__ __launch_bounds__(NW * 64) void xna_union_kernel(const XnaUnionParams
     {
         const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
         const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * p.dvt;
-        for (int i = tid; i < nst * 8; i += NT) {
-            const int key = i >> 3, c = i & 7;
-            const int a = key / WUA, bc = key - a * WUA;
-            const int yy = min(ymin + a, p.h - 1), xx = min(xmin + bc, p.w - 1);
-            *reinterpret_cast<u32x4_t*>(Ks + key * KROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(kb + (int64_t)yy * p.ks[2] + (int64_t)xx * p.ks[3] + c * 8);
-        }
-        for (int i = tid; i < nst * VCH; i += NT) {
-            const int key = i / VCH, c = i - key * VCH;
-            const int a = key / WUA, bc = key - a * WUA;
-            const int yy = min(ymin + a, p.h - 1), xx = min(xmin + bc, p.w - 1);
-            *reinterpret_cast<u32x4_t*>(Vs + key * VROW + c * 8) =
-                *reinterpret_cast<const u32x4_t*>(vb + (int64_t)yy * p.vs[2] + (int64_t)xx * p.vs[3] + c * 8);
-        }
+        // four chunks per thread per trip, all four loads issued before the first LDS write (one load per trip is one L2
+        // round trip per 16-byte chunk: see the window staging of xna_mfma_kernel.h)
+        auto stage4 = [&](int total, auto src_of, auto dst_of) __attribute__((always_inline)) {
+            for (int i0 = tid; i0 < total; i0 += 4 * NT) {
+                u32x4_t val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) val[u] = *reinterpret_cast<const u32x4_t*>(src_of(min(i0 + u * NT, total - 1)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * NT < total) *reinterpret_cast<u32x4_t*>(dst_of(i0 + u * NT)) = val[u];
+            }
+        };
+        stage4(nst * 8,
+               [&](int i) __attribute__((always_inline)) {
+                   const int key = i >> 3, c = i & 7;
+                   const int a = key / WUA, bc = key - a * WUA;
+                   const int yy = min(ymin + a, p.h - 1), xx = min(xmin + bc, p.w - 1);
+                   return kb + (int64_t)yy * p.ks[2] + (int64_t)xx * p.ks[3] + c * 8;
+               },
+               [&](int i) __attribute__((always_inline)) { return Ks + (i >> 3) * KROW + (i & 7) * 8; });
+        stage4(nst * VCH,
+               [&](int i) __attribute__((always_inline)) {
+                   const int key = i / VCH, c = i - key * VCH;
+                   const int a = key / WUA, bc = key - a * WUA;
+                   const int yy = min(ymin + a, p.h - 1), xx = min(xmin + bc, p.w - 1);
+                   return vb + (int64_t)yy * p.vs[2] + (int64_t)xx * p.vs[3] + c * 8;
+               },
+               [&](int i) __attribute__((always_inline)) { const int key = i / VCH, c = i - key * VCH; return Vs + key * VROW + c * 8; });
         // rows past the rectangle are read (with weight 0) by tiles at its right edge: finite values only
         for (int i = tid; i < 32 * VCH; i += NT) {
             const int key = nst + i / VCH, c = i % VCH;
