@@ -3,6 +3,9 @@
 #pragma once
 #include <type_traits>
 
+#ifndef NAF_STEM_CARRY
+#define NAF_STEM_CARRY 1   // B-fragment sets of the next step requested before the barrier (must match tools/gen_stem_sched.py)
+#endif
 #ifndef NAF_STEM_SLOT_PINS
 #define NAF_STEM_SLOT_PINS 1
 #endif
@@ -219,20 +222,32 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
     // step 1 rewrites (same lanes, same addresses, program order), so the body has no "is there a
     // previous / next step" branches: ONE basic block, one instance (a separate first-step instance of
     // this body used to spill ~240 registers per lane).
+    // B fragments: a rolling window of two sets (8 fragments); a step is entered with its sets 0, 1 already requested (by
+    // the tail of the step before, or here for step 0)
+    bf16x8_t bb[2][KH] = {};
+    if (!(ABL & 4)) {
+#pragma unroll
+        for (int f = 0; f < NAF_STEM_CARRY * KH; ++f) bb[f / KH][f % KH] = *reinterpret_cast<const bf16x8_t*>(ring + lane_b + f * 16);
+    }
+    // Row 1's accumulator starts as the conv bias (row 4j + r of the 32x32 tile = output channel 32 wave + 8 j + 4 half + r): the
+    // schedule re-initialises it at the top of a step, straight from the LDS into the accumulator registers.  Row 0 starts at 0.
+    f32x16_t acc[RS];
+    auto acc_init = [&](int g, int j) __attribute__((always_inline)) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[g][j * 4 + r] = bv[r];
+    };
     auto step_body = [&](int step, auto edge) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge)::value;
         const int pst = max(step - 1, 0);   // tile whose rows leave during this step
-        f32x16_t acc[RS];
-#pragma unroll
-        for (int g = 0; g < RS; ++g) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-        }
         int slot_off[NROW];
 #pragma unroll
         for (int i = 0; i < NROW; ++i) slot_off[i] = ((step * RS + i) % RING) * ROWE;
 
         bf16_t* ot = otile + (step & 1) * (RS * TW * PXE);
+        f32x4_t bj[4];   // the lane's 16 bias values for row 0's epilogue, read a few slots ahead by the schedule
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
         // epilogue slice: accumulator rows 4j..4j+3 of output row g -> bias, GroupNorm sums, bf16, LDS tile
         auto epi = [&](int g, int j) __attribute__((always_inline)) {
             if (ABL & 2) {
@@ -241,9 +256,11 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
             }
             const int orow = sy + step * RS + g;
             const float vmask = (!EDGE || ((orow < sy_end) && (sx + n32 < p.W))) ? 1.0f : 0.0f;
-            const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
-            f32x2_t v0 = f32x2_t{acc[g][j * 4], acc[g][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
-            f32x2_t v1 = f32x2_t{acc[g][j * 4 + 2], acc[g][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+            f32x2_t v0 = f32x2_t{acc[g][j * 4], acc[g][j * 4 + 1]}, v1 = f32x2_t{acc[g][j * 4 + 2], acc[g][j * 4 + 3]};
+            if (g == 0) {   // row 1's accumulator started as the bias
+                v0 += f32x2_t{bj[j][0], bj[j][1]};
+                v1 += f32x2_t{bj[j][2], bj[j][3]};
+            }
             bf16x4_t o;
             o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
             if constexpr (EDGE) {
@@ -255,16 +272,17 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
             *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
         };
 
-        bf16x8_t bb[2][KH] = {};
-        auto load_set = [&](int sidx, bf16x8_t (&dst)[KH]) __attribute__((always_inline)) {
-            const int rt = sidx / (8 / KH), kh = sidx - rt * (8 / KH);
-            const int i = rt / KS, dx = rt - i * KS;
-            const bf16_t* bp = ring + slot_off[i] + dx * PXE + lane_b + kh * KH * 16;
+        // fragment ks of set sidx = (input row i, tap column dx, k half kh); sets NSETS, NSETS + 1 are sets 0, 1 of the step after
+        // this one (its input row 0 = this step's input row RS, in the ring since the step before)
+        auto load_frag = [&](int sidx, int ks, bf16x8_t& dst) __attribute__((always_inline)) {
             if (ABL & 4) return;
-#pragma unroll
-            for (int ks = 0; ks < KH; ++ks) dst[ks] = *reinterpret_cast<const bf16x8_t*>(bp + ks * 16);
+            const int nxt = sidx >= NSETS ? 1 : 0;
+            const int sx_ = sidx - nxt * NSETS;
+            const int rt = sx_ / (8 / KH), kh = sx_ - rt * (8 / KH);
+            const int i = rt / KS, dx = rt - i * KS;
+            const int row_off = nxt ? (((step + 1) * RS + i) % RING) * ROWE : slot_off[i];
+            dst = *reinterpret_cast<const bf16x8_t*>(ring + row_off + dx * PXE + lane_b + (kh * KH + ks) * 16);
         };
-        load_set(0, bb[0]);
         long long tm0 = 0;
         if constexpr ((ABL & 128) != 0) tm0 = __builtin_readcyclecounter();
         {

@@ -80,47 +80,73 @@ last_a = max(r for r, names in enumerate(PIECE_PLAN) if any(x.startswith("A") fo
 last_commit_read = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + last_a      # last A-stage of the last piece
 last_commit = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + len(PIECE_PLAN) - 1
 
-# Row stores of the previous output tile, then the global loads for the step after next.  Loads and stores share vmcnt and
-# retire in order, so a wait for a load also waits for the stores issued before it; issuing the loads first
-# (NAF_STEM_ORDER=loads_first) makes those waits exact but measures the same (0.346-0.356 vs 0.348-0.367 ms in the probe):
-# the stores have long reached L2 when the next step's GroupNorm micro-ops ask for their loads.
-LOADS_FIRST = os.environ.get("NAF_STEM_ORDER", "stores_first") == "loads_first"
+# Row stores of the previous output tile and the global loads for the step after next.  Loads and stores share vmcnt and
+# retire in order; either order measures the same (the stores have long reached L2 when the next step's GroupNorm micro-ops
+# ask for their loads).
 FIRST_BASE = max(60, last_commit + 1)      # ld[n] was consumed by A-stages before this slot
 assert FIRST_BASE > last_commit_read
-if LOADS_FIRST:
-    LD_BASE = FIRST_BASE
-    ST_BASE = LD_BASE + 2 * NLD + 1
-else:
-    ST_BASE = FIRST_BASE
-    LD_BASE = ST_BASE + 3 * NST + 2
-for n in range(NST):
-    ops[ST_BASE + 3 * n].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
-    ops[ST_BASE + 3 * n + 2].append(("store", f"if (!EDGE || st_ok(pst, {n})) *reinterpret_cast<u32x4_t*>(prev_row{16 * n // TW} + st_goff[{n}]) = stv;"))
-for n in range(NLD):
+# The LDS answers in order, so a wait for ONE value is a wait for every read issued before it.  A row store's tile read
+# therefore goes BEFORE the B-fragment reads of a set (first slot of a set, ahead of load_set): its wait is then lgkmcnt(4),
+# not lgkmcnt(0) -- waiting for the freshly issued fragment set idles the MFMA pipe ~100+ cycles per store.
+pre = [[] for _ in range(NSLOT)]            # micro-ops emitted before load_set at the first slot of a set
+set_starts = [k for k, sl in enumerate(slots) if sl[6]]
+st_slots = [k for k in set_starts if k >= FIRST_BASE][:NST]
+assert len(st_slots) == NST and st_slots[-1] + 2 < 112
+for n, k in enumerate(st_slots):
+    pre[k].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
+    ops[k + 2].append(("store", f"if (!EDGE || st_ok(pst, {n})) *reinterpret_cast<u32x4_t*>(prev_row{16 * n // TW} + st_goff[{n}]) = stv;"))
+ld_slots = [k for k in range(st_slots[0] + 3, 118) if k not in st_slots and (k - 2) not in st_slots and k % 2 == 1][:NLD]
+assert len(ld_slots) == NLD
+for n, k in enumerate(ld_slots):
     r_lo, r_hi = (16 * n) // PXR, (16 * n + 15) // PXR
     base = f"next_row{r_lo}" if r_lo == r_hi else f"(pl + {16 * n} >= {PXR} ? next_row1 : next_row0)"
-    ops[LD_BASE + 2 * n].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>({base} + col_off[{n}]);"))
-assert max(ST_BASE + 3 * NST, LD_BASE + 2 * NLD) < 118
+    ops[k].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>({base} + col_off[{n}]);"))
 
-# epilogue of output row 0: its accumulator is final once input row 2 is done (slot 119)
+# epilogue of output row 0: its accumulator is final once input row 2 is done (slot 119).
+# An epilogue that reads its bias from the LDS on the spot waits for every LDS read issued before it (the LDS answers in order):
+# ~100+ idle MFMA cycles, 8 x a step.  Row 0: the lane's 16 bias values are requested a few slots ahead (the GroupNorm temporaries
+# are dead by then).  Row 1, whose epilogue is the exposed tail of the step: the accumulator STARTS as the bias (four ds_read_b128
+# straight into its 16 registers at the top of the step, before its first MFMA at slot 25), so its epilogue adds nothing.
 first_row3 = next(k for k, s in enumerate(slots) if s[0] >= 18)
 assert first_row3 == 120
+first_g1 = next(k for k, s in enumerate(slots) if s[2] == 1)
+assert first_g1 == 25
 for j in range(4):
+    ops[first_row3 - 10 + 2 * j].append(("epi", f"bj[{j}] = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * {j} + 4 * half);"))
     ops[first_row3 + 2 + 5 * j].append(("epi", f"epi(0, {j});"))
+    ops[4 + 5 * j].append(("epi", f"acc_init(1, {j});"))
+
+# B fragments: a rolling window of 8 registers-quads.  The register of fragment (set, ks) is re-requested with fragment
+# (set + 2, ks) right behind the last MFMA that reads it, so every fragment is in flight for 7+ MFMA slots (224+ cycles).  With
+# whole sets requested at set boundaries the 4-MFMA sets (input rows 0 and 3 feed one output row) left the following set only
+# 128 cycles, less than four waves' worth of ds_read_b128 take.  Sets 24, 25 are sets 0, 1 of the NEXT step: its input row 0
+# has been in the ring for a whole step, so the step does not open with an exposed LDS round trip behind the barrier.
+last_use = [False] * NSLOT
+for k, sl in enumerate(slots):
+    nxt = slots[k + 1] if k + 1 < NSLOT else None
+    last_use[k] = nxt is None or (nxt[0], nxt[1]) != (sl[0], sl[1])
+
+CARRY = int(os.environ.get('NAF_STEM_CARRY', '1'))   # sets of the next step requested before the barrier (1 | 2)
 
 # ---- emit -------------------------------------------------------------------------------------------
 out = []
 out.append("// GENERATED by tools/gen_stem_sched.py -- do not edit.  One step of stem_conv_kernel<3>: 144 MFMA slots,")
 out.append("// side work pinned behind individual MFMAs.  Included inside step_body (stem_conv_kernel.h).")
 for k, (sidx, ks, g, dy, dx, kh, first) in enumerate(slots):
+    if first and sidx == 0:
+        for c in range(CARRY, 2):
+            for f in range(KH):
+                out.append(f"load_frag({c}, {f}, bb[{c}][{f}]);")
     if first:
         out.append(f"// ---- set {sidx}: input row {sidx // (KS * (8 // KH))}, tap column {dx}, k-steps {kh * KH}..{kh * KH + KH - 1}")
         out.append("__builtin_amdgcn_sched_barrier(0);")
-        if sidx + 1 < NSETS:
-            out.append(f"load_set({sidx + 1}, bb[{(sidx + 1) & 1}]);")
-            out.append("__builtin_amdgcn_sched_barrier(0);")
+        for kind, code in pre[k]:
+            out.append(f"if constexpr (!(ABL & 8)) {{ {code} }}")
+        out.append("__builtin_amdgcn_sched_barrier(0);")
     widx = (dy * KS + dx) * 8 + kh * KH + ks
     out.append(f"acc[{g}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[{widx}], bb[{sidx & 1}][{ks}], acc[{g}], 0, 0, 0);  // slot {k}")
+    if last_use[k] and sidx + 2 <= NSETS + CARRY - 1:
+        out.append(f"load_frag({sidx + 2}, {ks}, bb[{sidx & 1}][{ks}]);")
     for kind, code in ops[k]:
         if kind == "store":
             out.append(f"if constexpr (!(ABL & 8)) {{ {code} }}")
