@@ -235,6 +235,108 @@ __global__ __launch_bounds__(256) void rope_pool_kernel(const RopePoolParams p) 
     }
 }
 
+// Keys-only pass (q == NULL: the attention kernel rotates its queries on load) over bf16 channels-last guidance, one
+// workgroup per cell: the same arithmetic in the same order as rope_pool_kernel<bf16, 8, false> (bit-identical keys), with what
+// that kernel's generality costs taken out of the loop -- no divisions, 32-bit offsets from one cell base, and four pixels
+// per trip whose loads are all requested before the first one is rotated (128 B per lane in flight: the pass is a pure read
+// of the whole guidance tensor and is bound by bytes in flight per CU, not by its ~50 VALU instructions per pixel).
+__global__ __launch_bounds__(256) void rope_pool_keys_kernel(const RopePoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [256 / tpp][Cq] | table rows
+    const int tid = threadIdx.x;
+    int L = (int)blockIdx.x;
+    const int cx = L % p.w;
+    L /= p.w;
+    const int cy = L % p.h;
+    const int b = L / p.h;
+    const int ys = (int)(((int64_t)cy * p.Ho) / p.h), ye = (int)((((int64_t)cy + 1) * p.Ho + p.h - 1) / p.h);
+    const int xs = (int)(((int64_t)cx * p.Wo) / p.w), xe = (int)((((int64_t)cx + 1) * p.Wo + p.w - 1) / p.w);
+    const int wy = ye - ys, wx = xe - xs;
+    const int npix = wy * wx;
+    const int quarter = p.Dh >> 2, half = p.Dh >> 1;
+
+    float* tl = red + (256 / p.tpp) * p.Cq;
+    const int TS = 2 * quarter + 4;
+    {
+        const int q4 = quarter >> 1;
+        for (int i = tid; i < (wy + wx) * q4; i += 256) {
+            const int r = i / q4, c = i - r * q4;
+            const float* src = (r < wy) ? p.tab_y + (int64_t)(ys + r) * 2 * quarter : p.tab_x + (int64_t)(xs + r - wy) * 2 * quarter;
+            *reinterpret_cast<f32x4_t*>(tl + r * TS + c * 4) = *reinterpret_cast<const f32x4_t*>(src + c * 4);
+        }
+        __syncthreads();
+    }
+    const int chunk = tid & (p.tpp - 1), plane = tid / p.tpp, nplanes = 256 / p.tpp;
+    const bool active = chunk < p.nchunk;
+    const int cph = half / 8;
+    const int head = active ? chunk / cph : 0;
+    const int t0 = active ? (chunk - head * cph) * 8 : 0;
+    const int c1 = head * p.Dh + t0;
+    const bool rowtype = t0 < quarter;
+
+    float acc1[8], acc2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc1[i] = acc2[i] = 0.f;
+    if (active) {
+        const char* cell = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.x) + b * p.xs[0] + (int64_t)ys * p.xs[2] + (int64_t)xs * p.xs[3] + c1);
+        const uint32_t sy = (uint32_t)p.xs[2] * 2u, sxb = (uint32_t)p.xs[3] * 2u;   // byte strides (a cell spans < 4 GB: validated)
+        // pixel walk pi = plane, plane + nplanes, ...: (py, px) advance without a division; U pixels per trip, all their
+        // loads requested before the first one is rotated (U x 32 B per lane in flight), accumulated in walk order
+#ifndef NAF_ROPE_U
+#define NAF_ROPE_U 4
+#endif
+        constexpr int U = NAF_ROPE_U;
+        const int dpy = nplanes / wx, dpx = nplanes - dpy * wx;
+        int py = plane / wx, px = plane - py * wx;
+        for (int pi = plane; pi < npix; pi += U * nplanes) {
+            bf16x8_t va[U], vb[U];
+            int yy[U], xx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                yy[u] = py;
+                xx[u] = px;
+                const bool ok = pi + u * nplanes < npix;
+                const char* xp = cell + (uint32_t)(ok ? py : 0) * sy + (uint32_t)(ok ? px : 0) * sxb;   // past the end: a valid address, unused
+                va[u] = *reinterpret_cast<const bf16x8_t*>(xp);
+                vb[u] = *reinterpret_cast<const bf16x8_t*>(xp + half * 2);
+                py += dpy;
+                px += dpx;
+                if (px >= wx) {
+                    px -= wx;
+                    ++py;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // all U pixels requested before the first wait
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = pi + u * nplanes < npix;   // no branch: a branch sinks each pixel's loads next to their use
+                NAF_LDS const float* tb = (NAF_LDS const float*)(rowtype ? tl + yy[u] * TS + t0 : tl + (wy + xx[u]) * TS + (t0 - quarter));
+                const f32x4_t c0 = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb), c1v = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + 4);
+                const f32x4_t s0 = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + quarter), s1v = *reinterpret_cast<NAF_LDS const f32x4_t*>(tb + quarter + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float o1, o2;
+                    naf_rope_rotate((float)va[u][i], (float)vb[u][i], i < 4 ? c0[i & 3] : c1v[i & 3], i < 4 ? s0[i & 3] : s1v[i & 3], o1, o2);
+                    acc1[i] += ok ? o1 : 0.f;
+                    acc2[i] += ok ? o2 : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[plane * p.Cq + c1 + i] = acc1[i];
+            red[plane * p.Cq + c1 + half + i] = acc2[i];
+        }
+    }
+    __syncthreads();
+    const float invn = 1.0f / (float)npix;
+    for (int c = tid; c < p.Cq; c += 256) {
+        float s = 0.f;
+        for (int pl = 0; pl < nplanes; ++pl) s += red[pl * p.Cq + c];
+        const int hd = c / p.Dh, d = c - hd * p.Dh;
+        p.k[b * p.ks[0] + hd * p.ks[1] + (int64_t)cy * p.ks[2] + (int64_t)cx * p.ks[3] + d] = (bf16_t)(s * invn);
+    }
+}
+
 int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
     RopePoolParams p;
     p.x = a->x;
@@ -299,6 +401,13 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
         if (cpw > 1) hipLaunchKernelGGL((rope_pool_kernel<T, V, true>), g, blk, lds, s, p);                 \
         else hipLaunchKernelGGL((rope_pool_kernel<T, V, false>), g, blk, lds, s, p);                        \
     } while (0)
+    // keys only, bf16 channels-last, table rows in LDS, one cell per workgroup, every pixel lane has a pixel: the lean kernel
+    const int64_t cell_span = ((int64_t)(a->Ho + a->h - 1) / a->h + 1) * a->x_stride[2] + ((int64_t)(a->Wo + a->w - 1) / a->w + 1) * a->x_stride[3];
+    if (a->q == nullptr && a->x_dtype == NAF_BF16 && vec && cpw == 1 && p.tab_lds && a->x_stride[1] == 1 && cell_span * 2 < 0x7fffffffLL &&
+        a->x_stride[2] > 0 && a->x_stride[3] > 0 && npix_typ >= 256 / tpp && !naf_knob("NAF_ROPE_GENERAL")) {
+        hipLaunchKernelGGL(rope_pool_keys_kernel, g, blk, lds, s, p);
+        return naf_check_launch("rope_pool_keys_kernel");
+    }
     if (a->x_dtype == NAF_BF16) {
         if (vec) NAF_RP_LAUNCH(bf16_t, 8);
         else NAF_RP_LAUNCH(bf16_t, 1);

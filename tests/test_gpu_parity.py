@@ -88,6 +88,8 @@ def test_rope_tables(dev):
 @pytest.mark.parametrize("shape,heads,lr,fmt", [
     ((1, 256, 32, 48), 4, (8, 12), "nhwc_f32"),       # integer ratio, vector path
     ((2, 256, 23, 30), 4, (5, 7), "nhwc_bf16"),       # overlapping pool windows (Ho % h != 0)
+    ((2, 256, 64, 96), 4, (4, 6), "nhwc_bf16"),       # 16 x 16 cells, bf16 channels-last (the forward's case)
+    ((1, 256, 56, 70), 4, (4, 5), "nhwc_bf16"),       # 14 x 14 cells: the last trip of the pixel walk is partial
     ((1, 64, 12, 10), 1, (12, 10), "nchw_f32"),       # ratio 1, one head of 64, strided (NCHW) input
     ((1, 24, 9, 8), 2, (3, 4), "nchw_f32"),           # Dh = 12: scalar path
     ((1, 96, 16, 16), 1, (4, 4), "nhwc_f32"),         # Dh = 96 (denoising dims)
@@ -113,6 +115,10 @@ def test_rope_pool(dev, shape, heads, lr, fmt):
         k = k5.permute(0, 1, 4, 2, 3).reshape(B, C, *lr).float().cpu()
         assert_close(q, ref_q, 1e-5, 2 ** -8, f"q {fmt} {layout}")       # one bf16 rounding
         assert_close(k, ref_k, 1e-5, 2 ** -8, f"k {fmt} {layout}")
+    # keys only (the forward's call: queries are rotated on load by the attention kernel); bf16 channels-last input takes
+    # the lean rope_pool_keys_kernel, which must give the SAME bits as the general kernel's keys
+    none_q, k5b = ops.rope_pool(xd, ty, tx, heads, lr, write_q=False)
+    assert none_q is None and torch.equal(k5b, k5), f"keys-only pass differs: {float((k5b.float() - k5.float()).abs().max())}"
 
 
 def test_pack_values(dev):
