@@ -128,6 +128,54 @@ typedef struct naf_stem_conv_args {
     const naf_stem_conv0_args* first; /* optional, see above */
 } naf_stem_conv_args;
 int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream);
+/* Plain mode: stats_in == gn_weight == gn_bias == NULL (bias may be NULL too) -> y = conv(x) (+ bias), no GroupNorm, no SiLU,
+ * 128 channels.  It is the DATA GRADIENT of a layer (the backward train.py:127-137 needs): x = the gradient of the layer's
+ * output, w_packed = the flipped, transposed weights [k*k][128 ic][128 oc] (= weight.flip(2,3).permute(2,3,1,0)).  For the
+ * 3x3 layers (reflect padding) run it over the output gradient embedded in a 2-pixel ZERO border ((H+4) x (W+4)): rows /
+ * columns 1 .. H+2 of the result are the gradient on the padded domain, whose border naf_stem_act_bwd(fold) folds back. */
+
+/* ---- training companions of the conv stem --------------------------------------------------------------
+ * naf_stem_act_fwd : a = SiLU(GroupNorm(8, C)(x)) in bf16 (convolutions.py:52-55 / :58-59, the tensor naf_stem_conv_fwd never
+ *   stores), written with a reflected border of `pad` pixels (0 or 1): a is [B, H + 2 pad, W + 2 pad, C] by a_stride =
+ *   {b, y, x}.  It is the input of the layer's weight gradient.
+ * naf_stem_act_bwd : backward of the same function.  da = gradient wrt a (bf16; with fold = 1 the gradient on the PADDED
+ *   domain [B, H + 2, W + 2, C], pointer at its first element: the adjoint of the reflect padding is applied on load), x and
+ *   stats_in = the forward's input and its GroupNorm sums; dx (bf16) = gradient wrt x.  sums [B][C][2] (fp64, zeroed by the
+ *   caller) receives per sample and channel {sum dz, sum dz * xhat} = the contributions to the gradients of gn_bias /
+ *   gn_weight.  phase 1 = sums only, 2 = dx only (sums must be complete), 0 = both.  C a multiple of 64 up to 256. */
+typedef struct naf_stem_act_args {
+    const void* x;
+    void* a;
+    const float* gn_weight;
+    const float* gn_bias;
+    const double* stats_in;
+    int32_t B, H, W;
+    int32_t channels; /* 0 = 128 */
+    int32_t pad;      /* 0 or 1 */
+    float eps;
+    int64_t x_stride[3];
+    int64_t a_stride[3];
+} naf_stem_act_args;
+int naf_stem_act_fwd(const naf_stem_act_args* a, naf_stream_t stream);
+
+typedef struct naf_stem_act_bwd_args {
+    const void* da;
+    const void* x;
+    void* dx;
+    const float* gn_weight;
+    const float* gn_bias;
+    const double* stats_in;
+    double* sums;
+    int32_t B, H, W;
+    int32_t channels; /* 0 = 128 */
+    int32_t fold;     /* 1: da lives on the padded domain, fold its border back */
+    int32_t phase;    /* 0 both, 1 sums, 2 dx */
+    float eps;
+    int64_t da_stride[3];
+    int64_t x_stride[3];
+    int64_t dx_stride[3];
+} naf_stem_act_bwd_args;
+int naf_stem_act_bwd(const naf_stem_act_bwd_args* a, naf_stream_t stream);
 
 /* ---- RoPE tables --------------------------------------------------------------------------------
  * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),
@@ -157,6 +205,23 @@ typedef struct naf_rope_pool_args {
     int64_t k_stride[4];
 } naf_rope_pool_args;
 int naf_rope_pool_fwd(const naf_rope_pool_args* a, naf_stream_t stream);
+
+/* Backward of naf_rope_pool_fwd (train.py:127-137 differentiates rope.py:147-174 and naf.py:63-69):
+ *   dx = R^T (dq + sum over the cells whose pooling window holds the pixel of dk / window size), R^T = rotation by the negative angle.
+ *   dq device bf16 [B, heads, Ho, Wo, Dh], dk_lr device f32 [B, heads, h, w, Dh], strides {b, head, y, x} with Dh contiguous;
+ *   dx device bf16, strides {b, c, y, x} with c contiguous (dx_stride[1] == 1); Dh a multiple of 32; tables as in the forward. */
+typedef struct naf_rope_pool_bwd_args {
+    const void* dq;
+    const float* dk_lr;
+    void* dx;
+    const float* tab_y;
+    const float* tab_x;
+    int32_t B, Cq, heads, Ho, Wo, h, w;
+    int64_t dq_stride[4];
+    int64_t dk_stride[4];
+    int64_t dx_stride[4];
+} naf_rope_pool_bwd_args;
+int naf_rope_pool_bwd(const naf_rope_pool_bwd_args* a, naf_stream_t stream);
 
 /* ---- image pre-shrink -----------------------------------------------------------------------------------
  * Replaces the F.interpolate(mode="bilinear", align_corners=False) of ImageEncoder.forward (naf.py:39-48) that the

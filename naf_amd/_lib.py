@@ -61,6 +61,31 @@ class StemConvArgs(C.Structure):
     ]
 
 
+class RopePoolBwdArgs(C.Structure):
+    _fields_ = [
+        ("dq", C.c_void_p), ("dk_lr", C.c_void_p), ("dx", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p),
+        ("B", C.c_int32), ("Cq", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
+        ("w", C.c_int32), ("dq_stride", I64x4), ("dk_stride", I64x4), ("dx_stride", I64x4),
+    ]
+
+
+class StemActArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("a", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p), ("stats_in", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("channels", C.c_int32), ("pad", C.c_int32), ("eps", C.c_float),
+        ("x_stride", I64x3), ("a_stride", I64x3),
+    ]
+
+
+class StemActBwdArgs(C.Structure):
+    _fields_ = [
+        ("da", C.c_void_p), ("x", C.c_void_p), ("dx", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p),
+        ("stats_in", C.c_void_p), ("sums", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("channels", C.c_int32), ("fold", C.c_int32), ("phase", C.c_int32),
+        ("eps", C.c_float), ("da_stride", I64x3), ("x_stride", I64x3), ("dx_stride", I64x3),
+    ]
+
+
 class XnaBwdArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k_lr", C.c_void_p), ("v_lr", C.c_void_p), ("dout", C.c_void_p), ("dq", C.c_void_p),
@@ -103,6 +128,9 @@ SIGNATURES = {
     "naf_axis_index_table_device": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_stem_conv0_fwd": (C.c_int, [C.POINTER(StemConv0Args), C.c_void_p]),
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
+    "naf_rope_pool_bwd": (C.c_int, [C.POINTER(RopePoolBwdArgs), C.c_void_p]),
+    "naf_stem_act_fwd": (C.c_int, [C.POINTER(StemActArgs), C.c_void_p]),
+    "naf_stem_act_bwd": (C.c_int, [C.POINTER(StemActBwdArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_rope_pool_fwd": (C.c_int, [C.POINTER(RopePoolArgs), C.c_void_p]),
     "naf_preshrink_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -129,8 +129,11 @@ int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream) {
 
 int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_conv_fwd: args is NULL");
-    NAF_REQUIRE((a->x || a->first) && a->y && a->w_packed && a->bias && a->gn_weight && a->gn_bias && a->stats_in,
+    const bool plain = a->stats_in == nullptr && a->gn_weight == nullptr && a->gn_bias == nullptr;   // conv only (+ optional bias)
+    NAF_REQUIRE((a->x || a->first) && a->y && a->w_packed && (plain || (a->bias && a->gn_weight && a->gn_bias && a->stats_in)),
                 "naf_stem_conv_fwd: NULL pointer");
+    NAF_REQUIRE(!plain || (a->first == nullptr && (a->channels == 0 || a->channels == 128)),
+                "naf_stem_conv_fwd: the plain (no GroupNorm / SiLU) mode exists for the 128-channel kernels, without `first`");
     if (a->first != nullptr) {
         const naf_stem_conv0_args* f = a->first;
         NAF_REQUIRE(a->ksize == 1 && f->ksize == 1, "naf_stem_conv_fwd: `first` (recomputed conv0 input) exists for the 1x1 branch only");
@@ -148,6 +151,39 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     // 1x1 layers are HBM-bound (independent-wave kernel); 3x3 layers are MFMA-bound (weight-stationary strips)
     if (a->ksize == 1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream));
+}
+
+int naf_rope_pool_bwd(const naf_rope_pool_bwd_args* a, naf_stream_t stream) {
+    NAF_REQUIRE(a != nullptr, "naf_rope_pool_bwd: args is NULL");
+    NAF_REQUIRE(a->dq && a->dk_lr && a->dx && a->tab_y && a->tab_x, "naf_rope_pool_bwd: NULL pointer");
+    NAF_REQUIRE(a->B > 0 && a->heads > 0 && a->Cq > 0 && a->Cq % a->heads == 0 && a->Ho > 0 && a->Wo > 0 && a->h > 0 && a->w > 0 &&
+                a->Ho >= a->h && a->Wo >= a->w, "naf_rope_pool_bwd: sizes out of range");
+    NAF_REQUIRE(al16(a->dq) && al16(a->dk_lr) && al16(a->dx), "naf_rope_pool_bwd: tensors must be 16-byte aligned");
+    for (int i = 0; i < 4; ++i)
+        NAF_REQUIRE(a->dq_stride[i] % 8 == 0 && a->dk_stride[i] % 4 == 0 && (i == 1 || a->dx_stride[i] % 8 == 0), "naf_rope_pool_bwd: strides must keep 16-byte alignment");
+    return naf_launch_rope_pool_bwd(a, static_cast<hipStream_t>(stream));
+}
+
+int naf_stem_act_fwd(const naf_stem_act_args* a, naf_stream_t stream) {
+    NAF_REQUIRE(a != nullptr, "naf_stem_act_fwd: args is NULL");
+    NAF_REQUIRE(a->x && a->a && a->gn_weight && a->gn_bias && a->stats_in, "naf_stem_act_fwd: NULL pointer");
+    NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_act_fwd: size out of range");
+    NAF_REQUIRE(a->pad == 0 || (a->pad == 1 && a->H >= 2 && a->W >= 2), "naf_stem_act_fwd: pad %d (0, or 1 with H, W >= 2)", a->pad);
+    NAF_REQUIRE(al16(a->x) && al16(a->a), "naf_stem_act_fwd: tensors must be 16-byte aligned");
+    for (int i = 0; i < 3; ++i) NAF_REQUIRE(a->x_stride[i] % 8 == 0 && a->a_stride[i] % 8 == 0, "naf_stem_act_fwd: strides must be multiples of 8 elements");
+    return naf_launch_stem_act_fwd(a, static_cast<hipStream_t>(stream));
+}
+
+int naf_stem_act_bwd(const naf_stem_act_bwd_args* a, naf_stream_t stream) {
+    NAF_REQUIRE(a != nullptr, "naf_stem_act_bwd: args is NULL");
+    NAF_REQUIRE(a->da && a->x && a->gn_weight && a->gn_bias && a->stats_in && a->sums, "naf_stem_act_bwd: NULL pointer");
+    NAF_REQUIRE(a->phase >= 0 && a->phase <= 2 && (a->phase == 1 || a->dx), "naf_stem_act_bwd: phase %d / dx", a->phase);
+    NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_act_bwd: size out of range");
+    NAF_REQUIRE(a->fold == 0 || (a->fold == 1 && a->H >= 2 && a->W >= 2), "naf_stem_act_bwd: fold %d (0, or 1 with H, W >= 2)", a->fold);
+    NAF_REQUIRE(al16(a->x) && al16(a->da) && (a->dx == nullptr || al16(a->dx)), "naf_stem_act_bwd: tensors must be 16-byte aligned");
+    for (int i = 0; i < 3; ++i)
+        NAF_REQUIRE(a->x_stride[i] % 8 == 0 && a->da_stride[i] % 8 == 0 && a->dx_stride[i] % 8 == 0, "naf_stem_act_bwd: strides must be multiples of 8 elements");
+    return naf_launch_stem_act_bwd(a, static_cast<hipStream_t>(stream));
 }
 
 static int xna_validate(const naf_xna_args* a) {

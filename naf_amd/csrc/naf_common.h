@@ -55,6 +55,9 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s);           
 int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s);           // stem_conv1x1.hip
 int naf_launch_stem_conv0_generic(const naf_stem_conv0_args* a, hipStream_t s);    // stem_generic.hip (widths other than 128)
 int naf_launch_stem_conv_generic(const naf_stem_conv_args* a, hipStream_t s);
+int naf_launch_rope_pool_bwd(const naf_rope_pool_bwd_args* a, hipStream_t s);
+int naf_launch_stem_act_fwd(const naf_stem_act_args* a, hipStream_t s);
+int naf_launch_stem_act_bwd(const naf_stem_act_bwd_args* a, hipStream_t s);
 
 int naf_launch_axis_table(int32_t* out_dev, int L_out, int L_in, int k, hipStream_t s);  // axis_table.hip
 

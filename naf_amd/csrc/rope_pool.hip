@@ -418,3 +418,111 @@ int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s) {
 #undef NAF_RP_LAUNCH
     return naf_check_launch("rope_pool_kernel");
 }
+
+
+// ---- backward of (RoPE -> queries, RoPE -> mean -> keys) -------------------------------------------------------------
+// q = R(x), k = mean over the cell's window of R(x)  =>  dx = R^T (dq + sum over the cells whose window holds the pixel of
+// dk / npix(cell)).  R rotates the pair (t, t + Dh/2) by the pixel's angle (rope.py:15-34), so R^T is the rotation by the
+// negative angle.  dq bf16 [B, heads, Ho, Wo, Dh] and dk f32 [B, heads, h, w, Dh] by strides {b, head, y, x} (Dh contiguous),
+// dx bf16 by strides {b, c, y, x} with c contiguous (channels-last).  Adaptive-pool windows (naf.py:63-69) may overlap by one
+// row / column when Ho % h != 0: a pixel then sits in up to 2 x 2 cells.  One thread = (pixel, 8 pairs).
+struct RopePoolBwdParams {
+    const bf16_t* dq;
+    const float* dk;
+    bf16_t* dx;
+    const float* tab_y;
+    const float* tab_x;
+    int32_t B, Cq, heads, Dh, Ho, Wo, h, w, tpp, nchunk;
+    int64_t qs[4], ks[4], xs[4];
+};
+
+__global__ __launch_bounds__(256) void rope_pool_bwd_kernel(const RopePoolBwdParams p) {
+    const int chunk = threadIdx.x & (p.tpp - 1), plane = threadIdx.x / p.tpp, nplanes = 256 / p.tpp;
+    if (chunk >= p.nchunk) return;
+    const int y = blockIdx.x, b = blockIdx.y;
+    const int half = p.Dh >> 1, quarter = p.Dh >> 2;
+    const int cph = half / 8;
+    const int head = chunk / cph, t0 = (chunk - head * cph) * 8;
+    const bool rowtype = t0 < quarter;
+    // cells whose window [floor(i Ho / h), ceil((i + 1) Ho / h)) holds row y: i0 = floor(y h / Ho) and possibly a neighbour
+    auto cells_of = [](int pos, int L, int n, int (&idx)[2], float (&inv)[2]) {
+        int cnt = 0;
+        const int i0 = (int)(((int64_t)pos * n) / L);
+        for (int i = max(i0 - 1, 0); i <= min(i0 + 1, n - 1); ++i) {
+            const int s = (int)(((int64_t)i * L) / n), e = (int)((((int64_t)i + 1) * L + n - 1) / n);
+            if (pos >= s && pos < e && cnt < 2) {
+                idx[cnt] = i;
+                inv[cnt] = 1.0f / (float)(e - s);
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+    int cyi[2] = {0, 0};
+    float cyw[2] = {0.f, 0.f};
+    const int ncy = cells_of(y, p.Ho, p.h, cyi, cyw);
+    const bf16_t* dqb = p.dq + b * p.qs[0] + head * p.qs[1] + (int64_t)y * p.qs[2] + t0;
+    const float* dkb = p.dk + b * p.ks[0] + head * p.ks[1] + t0;
+    bf16_t* dxb = p.dx + b * p.xs[0] + (int64_t)y * p.xs[2] + head * p.Dh + t0;
+    for (int x = plane; x < p.Wo; x += nplanes) {
+        const bf16x8_t g1v = *reinterpret_cast<const bf16x8_t*>(dqb + (int64_t)x * p.qs[3]);
+        const bf16x8_t g2v = *reinterpret_cast<const bf16x8_t*>(dqb + (int64_t)x * p.qs[3] + half);
+        float g1[8], g2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            g1[i] = (float)g1v[i];
+            g2[i] = (float)g2v[i];
+        }
+        int cxi[2] = {0, 0};
+        float cxw[2] = {0.f, 0.f};
+        const int ncx = cells_of(x, p.Wo, p.w, cxi, cxw);
+        for (int iy = 0; iy < ncy; ++iy)
+            for (int ix = 0; ix < ncx; ++ix) {
+                const float* kp = dkb + (int64_t)cyi[iy] * p.ks[2] + (int64_t)cxi[ix] * p.ks[3];
+                const float wgt = cyw[iy] * cxw[ix];
+                const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(kp), a1 = *reinterpret_cast<const f32x4_t*>(kp + 4);
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(kp + half), b1 = *reinterpret_cast<const f32x4_t*>(kp + half + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g1[i] = fmaf(a0[i], wgt, g1[i]);
+                    g1[4 + i] = fmaf(a1[i], wgt, g1[4 + i]);
+                    g2[i] = fmaf(b0[i], wgt, g2[i]);
+                    g2[4 + i] = fmaf(b1[i], wgt, g2[4 + i]);
+                }
+            }
+        const float* tb = rowtype ? p.tab_y + (int64_t)y * 2 * quarter + t0 : p.tab_x + (int64_t)x * 2 * quarter + (t0 - quarter);
+        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(tb), c1v = *reinterpret_cast<const f32x4_t*>(tb + 4);
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(tb + quarter), s1v = *reinterpret_cast<const f32x4_t*>(tb + quarter + 4);
+        bf16x8_t o1, o2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float c = i < 4 ? c0[i & 3] : c1v[i & 3], sn = i < 4 ? s0[i & 3] : s1v[i & 3];
+            o1[i] = (bf16_t)fmaf(g1[i], c, g2[i] * sn);        // forward: o1 = a c - b s, o2 = b c + a s
+            o2[i] = (bf16_t)fmaf(g2[i], c, -(g1[i] * sn));
+        }
+        *reinterpret_cast<bf16x8_t*>(dxb + (int64_t)x * p.xs[3]) = o1;
+        *reinterpret_cast<bf16x8_t*>(dxb + (int64_t)x * p.xs[3] + half) = o2;
+    }
+}
+
+int naf_launch_rope_pool_bwd(const naf_rope_pool_bwd_args* a, hipStream_t s) {
+    RopePoolBwdParams p;
+    p.dq = static_cast<const bf16_t*>(a->dq); p.dk = a->dk_lr; p.dx = static_cast<bf16_t*>(a->dx);
+    p.tab_y = a->tab_y; p.tab_x = a->tab_x;
+    p.B = a->B; p.Cq = a->Cq; p.heads = a->heads; p.Dh = a->Cq / a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w;
+    for (int i = 0; i < 4; ++i) { p.qs[i] = a->dq_stride[i]; p.ks[i] = a->dk_stride[i]; p.xs[i] = a->dx_stride[i]; }
+    if (p.Dh % 32 != 0 || a->dx_stride[1] != 1) {
+        naf_set_error("naf_rope_pool_bwd: head dim %d must be a multiple of 32 and dx channels-last", p.Dh);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    p.nchunk = a->Cq / 16;
+    int tpp = 1;
+    while (tpp < p.nchunk) tpp <<= 1;
+    if (tpp > 256 || a->B > 65535) {
+        naf_set_error("naf_rope_pool_bwd: guidance dim %d / batch %d out of range", a->Cq, a->B);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    p.tpp = tpp;
+    hipLaunchKernelGGL(rope_pool_bwd_kernel, dim3((uint32_t)a->Ho, (uint32_t)a->B), dim3(256), 0, s, p);
+    return naf_check_launch("rope_pool_bwd_kernel");
+}

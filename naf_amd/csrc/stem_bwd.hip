@@ -1,0 +1,245 @@
+// Training-side companions of the fused conv stem (train.py:127-137 differentiates the encoder of convolutions.py:6-92).
+//
+// The forward layer is y = conv(a) + bias with a = SiLU(GroupNorm(x)) (convolutions.py:52-61), computed by
+// naf_stem_conv_fwd without ever storing a.  Its backward needs three things this file provides; the two convolutions of
+// the backward themselves are naf_stem_conv_fwd in plain mode (data gradient, flipped / transposed weights) and the
+// caller's weight-gradient GEMM:
+//   * naf_stem_act_fwd : a = SiLU(GroupNorm(x)) materialised in bf16, optionally with the reflected border of the 3x3
+//     layers (convolutions.py:17-19 padding_mode="reflect"), as the input of the weight gradient;
+//   * naf_stem_act_bwd : dx = GroupNorm'(SiLU'(da)) plus the per-(sample, channel) sums that are the gradients of the
+//     GroupNorm affine parameters.  With `fold` the incoming da is the data gradient on the PADDED domain
+//     ((H + 2) x (W + 2), what the plain 3x3 convolution over the zero-bordered output gradient produces) and the adjoint of
+//     the reflect padding -- border rows / columns added back onto rows 1, H-2 / columns 1, W-2 -- is applied on load.
+// GroupNorm backward (N = elements of a (sample, group)): dz = da * silu'(z), dxhat = gamma * dz,
+//     dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dgamma_c = sum dz * xhat,  dbeta_c = sum dz.
+// Two phases over (da, x): sums, then apply; both recompute z and silu'(z) (the passes are HBM-bound).
+// Layout as in the forward stem: channels-last bf16, thread -> (pixel lane, 16-byte chunk of 8 channels).
+#include "naf_common.h"
+
+namespace {
+struct StemActParams {
+    const bf16_t* x;
+    bf16_t* a;
+    const bf16_t* da;
+    bf16_t* dx;
+    const float* gamma;
+    const float* beta;
+    const double* stats_in;   // [B][8][2] sum, sum^2 of x
+    double* sums;             // [B][C][2]: sum dz, sum dz * xhat
+    int32_t B, H, W, C, pad, fold, tpp, rows_per_block;
+    float eps;
+    int64_t xs[3], as[3], das[3], dxs[3];
+};
+
+constexpr int GROUPS = 8;
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return min(max(i, 0), n - 1);
+}
+
+// per-channel affine of GroupNorm for sample b: z = x * sc + sh, xhat = x * rs + rm (rs = rstd, rm = -mean * rstd)
+__device__ __forceinline__ void gn_vectors(const StemActParams& p, int b, float* cv /* [4][C] LDS */) {
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const int g = c / (p.C / GROUPS);
+        const double n = (double)p.H * (double)p.W * (double)(p.C / GROUPS);
+        const double s1 = p.stats_in[(b * GROUPS + g) * 2 + 0], s2 = p.stats_in[(b * GROUPS + g) * 2 + 1];
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float gm = p.gamma[c];
+        cv[c] = gm * rstd;
+        cv[p.C + c] = p.beta[c] - (float)mean * gm * rstd;
+        cv[2 * p.C + c] = rstd;
+        cv[3 * p.C + c] = -(float)mean * rstd;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)); }
+}  // namespace
+
+// a[(oy, ox)] = silu(gn(x[reflect(oy - pad), reflect(ox - pad)])), (H + 2 pad) x (W + 2 pad) outputs per sample
+__global__ __launch_bounds__(256) void stem_act_fwd_kernel(const StemActParams p) {
+    extern __shared__ __attribute__((aligned(16))) float cv[];
+    const int b = blockIdx.y;
+    gn_vectors(p, b, cv);
+    __syncthreads();
+    const int chunk = threadIdx.x & (p.tpp - 1), plane = threadIdx.x / p.tpp, nplanes = 256 / p.tpp;
+    if (chunk * 8 >= p.C) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = cv[chunk * 8 + e];
+        sh[e] = cv[p.C + chunk * 8 + e];
+    }
+    const int OH = p.H + 2 * p.pad, OW = p.W + 2 * p.pad;
+    const int r0 = blockIdx.x * p.rows_per_block, r1 = min(OH, r0 + p.rows_per_block);
+    const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
+    bf16_t* ab = p.a + (int64_t)b * p.as[0] + chunk * 8;
+    for (int oy = r0; oy < r1; ++oy) {
+        const int sy = reflect_idx(oy - p.pad, p.H);
+        for (int ox = plane; ox < OW; ox += nplanes) {
+            const int sx = reflect_idx(ox - p.pad, p.W);
+            const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(xb + (int64_t)sy * p.xs[1] + (int64_t)sx * p.xs[2]);
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float z = fmaf((float)v[e], sc[e], sh[e]);
+                o[e] = (bf16_t)(z * sigmoidf_fast(z));
+            }
+            *reinterpret_cast<bf16x8_t*>(ab + (int64_t)oy * p.as[1] + (int64_t)ox * p.as[2]) = o;
+        }
+    }
+}
+
+// PHASE 1: sums[b][c] += {sum dz, sum dz * xhat} over the block's rows.  PHASE 2: dx.
+template <int PHASE>
+__global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p) {
+    extern __shared__ __attribute__((aligned(16))) float cv[];   // [4][C] affine vectors | [2][8] group means | reduction scratch
+    const int b = blockIdx.y;
+    gn_vectors(p, b, cv);
+    float* gm = cv + 4 * p.C;             // [2][GROUPS]: mean(dxhat), mean(dxhat * xhat)
+    float* red = gm + 2 * GROUPS;         // [nplanes][2 C] (phase 1)
+    if (PHASE == 2 && threadIdx.x < 2 * GROUPS) {
+        const int g = threadIdx.x & 7, which = threadIdx.x >> 3, cpg = p.C / GROUPS;
+        double s = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) s += (double)p.gamma[c] * p.sums[((int64_t)b * p.C + c) * 2 + which];
+        gm[which * GROUPS + g] = (float)(s / ((double)p.H * (double)p.W * (double)cpg));
+    }
+    __syncthreads();
+    const int chunk = threadIdx.x & (p.tpp - 1), plane = threadIdx.x / p.tpp, nplanes = 256 / p.tpp;
+    const bool active = chunk * 8 < p.C;
+    float sc[8], sh[8], rs[8], rm[8], gam[8], s1[8], s2[8];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = active ? chunk * 8 + e : 0;
+        sc[e] = cv[c];
+        sh[e] = cv[p.C + c];
+        rs[e] = cv[2 * p.C + c];
+        rm[e] = cv[3 * p.C + c];
+        gam[e] = p.gamma[c];
+        s1[e] = s2[e] = 0.f;
+    }
+    if (PHASE == 2 && active) {   // 8 channels of a chunk sit in one group (C / 8 channels per group, a multiple of 8... or of 2: see launcher)
+        const int g = (chunk * 8) / (p.C / GROUPS);
+        m1 = gm[g];
+        m2 = gm[GROUPS + g];
+    }
+    const int r0 = blockIdx.x * p.rows_per_block, r1 = min(p.H, r0 + p.rows_per_block);
+    const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
+    const bf16_t* db = p.da + (int64_t)b * p.das[0] + chunk * 8;   // fold: points at padded (0, 0); interior (y, x) is (y + 1, x + 1)
+    bf16_t* ob = PHASE == 2 ? p.dx + (int64_t)b * p.dxs[0] + chunk * 8 : nullptr;
+    if (active) {
+        for (int y = r0; y < r1; ++y) {
+            for (int x = plane; x < p.W; x += nplanes) {
+                const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xb + (int64_t)y * p.xs[1] + (int64_t)x * p.xs[2]);
+                float da[8];
+                if (!p.fold) {
+                    const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)y * p.das[1] + (int64_t)x * p.das[2]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) da[e] = (float)dv[e];
+                } else {
+                    // adjoint of reflect padding (pad 1): padded row -1 mirrors row 1, padded row H mirrors row H - 2
+                    const int ry[3] = {y, (y == 1) ? -1 : -2, (y == p.H - 2) ? p.H : -2};
+                    const int rx[3] = {x, (x == 1) ? -1 : -2, (x == p.W - 2) ? p.W : -2};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) da[e] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (ry[i] == -2) continue;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            if (rx[j] == -2) continue;
+                            const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)(ry[i] + 1) * p.das[1] + (int64_t)(rx[j] + 1) * p.das[2]);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) da[e] += (float)dv[e];
+                        }
+                    }
+                }
+                bf16x8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)xv[e];
+                    const float z = fmaf(xf, sc[e], sh[e]);
+                    const float s = sigmoidf_fast(z);
+                    const float dz = da[e] * (s * fmaf(z, 1.0f - s, 1.0f));
+                    const float xh = fmaf(xf, rs[e], rm[e]);
+                    if (PHASE == 1) {
+                        s1[e] += dz;
+                        s2[e] = fmaf(dz, xh, s2[e]);
+                    } else {
+                        o[e] = (bf16_t)(rs[e] * (gam[e] * dz - m1 - xh * m2));
+                    }
+                }
+                if (PHASE == 2) *reinterpret_cast<bf16x8_t*>(ob + (int64_t)y * p.dxs[1] + (int64_t)x * p.dxs[2]) = o;
+            }
+        }
+    }
+    if (PHASE == 1) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[plane * 2 * p.C + chunk * 8 + e] = s1[e];
+                red[plane * 2 * p.C + p.C + chunk * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
+            float s = 0.f;
+            for (int pl = 0; pl < nplanes; ++pl) s += red[pl * 2 * p.C + i];
+            const int which = i / p.C, c = i - which * p.C;
+            atomicAdd(&p.sums[((int64_t)b * p.C + c) * 2 + which], (double)s);
+        }
+    }
+}
+
+static int act_common(StemActParams& p, int C, int H, const char* who) {
+    if (C < 16 || C > 256 || C % 64 != 0) {   // a 16-byte chunk (8 channels) must not straddle two of the 8 GroupNorm groups
+        naf_set_error("%s: %d channels (multiples of 64 up to 256)", who, C);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    int tpp = 1;
+    while (tpp * 8 < C) tpp <<= 1;
+    p.tpp = tpp;
+    p.C = C;
+    // ~8 blocks per CU and sample: enough to fill the chip at batch 1, few enough that the sums' atomics stay cheap
+    const int target = naf_cu_count() * 8;
+    int rows = (H + target - 1) / target;
+    if (rows < 1) rows = 1;
+    p.rows_per_block = rows;
+    return NAF_OK;
+}
+
+int naf_launch_stem_act_fwd(const naf_stem_act_args* a, hipStream_t s) {
+    StemActParams p{};
+    const int C = a->channels ? a->channels : 128;
+    p.x = static_cast<const bf16_t*>(a->x); p.a = static_cast<bf16_t*>(a->a);
+    p.gamma = a->gn_weight; p.beta = a->gn_bias; p.stats_in = a->stats_in;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.pad = a->pad; p.eps = a->eps;
+    for (int i = 0; i < 3; ++i) { p.xs[i] = a->x_stride[i]; p.as[i] = a->a_stride[i]; }
+    const int rc = act_common(p, C, a->H + 2 * a->pad, "naf_stem_act_fwd");
+    if (rc != NAF_OK) return rc;
+    const int OH = a->H + 2 * a->pad;
+    const dim3 grid((OH + p.rows_per_block - 1) / p.rows_per_block, a->B);
+    hipLaunchKernelGGL(stem_act_fwd_kernel, grid, dim3(256), 4 * C * sizeof(float), s, p);
+    return naf_check_launch("stem_act_fwd_kernel");
+}
+
+int naf_launch_stem_act_bwd(const naf_stem_act_bwd_args* a, hipStream_t s) {
+    StemActParams p{};
+    const int C = a->channels ? a->channels : 128;
+    p.x = static_cast<const bf16_t*>(a->x); p.da = static_cast<const bf16_t*>(a->da); p.dx = static_cast<bf16_t*>(a->dx);
+    p.gamma = a->gn_weight; p.beta = a->gn_bias; p.stats_in = a->stats_in; p.sums = a->sums;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.fold = a->fold; p.eps = a->eps;
+    for (int i = 0; i < 3; ++i) { p.xs[i] = a->x_stride[i]; p.das[i] = a->da_stride[i]; p.dxs[i] = a->dx_stride[i]; }
+    const int rc = act_common(p, C, a->H, "naf_stem_act_bwd");
+    if (rc != NAF_OK) return rc;
+    const dim3 grid((a->H + p.rows_per_block - 1) / p.rows_per_block, a->B);
+    const size_t lds = (size_t)(4 * C + 2 * GROUPS + (256 / p.tpp) * 2 * C) * sizeof(float);
+    if (a->phase == 0 || a->phase == 1) hipLaunchKernelGGL(stem_act_bwd_kernel<1>, grid, dim3(256), lds, s, p);
+    if (a->phase == 0 || a->phase == 2) hipLaunchKernelGGL(stem_act_bwd_kernel<2>, grid, dim3(256), lds, s, p);
+    return naf_check_launch("stem_act_bwd_kernel");
+}

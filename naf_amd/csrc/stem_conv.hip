@@ -62,10 +62,13 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         return NAF_ERR_INVALID;
     }
     const size_t lds = stem_conv_lds<3>();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    const bool plain = a->stats_in == nullptr;   // no GroupNorm / SiLU in front of the convolution (data-gradient pass)
+    const void* fn = plain ? reinterpret_cast<const void*>(stem_conv_kernel<3, 0, true>) : reinterpret_cast<const void*>(stem_conv_kernel<3>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", lds);
         return NAF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(stem_conv_kernel<3>, dim3((uint32_t)nb), dim3(256), lds, s, p);
+    if (plain) hipLaunchKernelGGL((stem_conv_kernel<3, 0, true>), dim3((uint32_t)nb), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(stem_conv_kernel<3>, dim3((uint32_t)nb), dim3(256), lds, s, p);
     return naf_check_launch("stem_conv_kernel");
 }

@@ -51,8 +51,11 @@ __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rc
 
 // DENSE: rows are dense in x and y and H*W is a multiple of 32 -> every group is complete, one uniform base + one
 // constant lane offset per access, a branch-free loop body (which also keeps hipcc's vmcnt waits exact).
-template <bool IMG, typename T, bool DENSE>
+// PLAIN (stats_in == NULL in the C ABI): no GroupNorm, no SiLU -- y = conv1x1(x) (+ bias if given); with the transposed
+// weights this is the layer's data gradient.
+template <bool IMG, typename T, bool DENSE, bool PLAIN = false>
 __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_kernel(const StemConv1Params p) {
+    static_assert(!(IMG && PLAIN), "the recomputed-conv0 input exists for the forward layer only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                           // [128][WROW] weights
     bf16_t* ot = wl + C1 * WROW;                                            // [NW1 waves][32][OROW1]
@@ -70,17 +73,21 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     }
     if (tid < C1) {
         const int c = tid, g = c >> 4;
-        const double n = (double)p.H * (double)p.W * 16.0;
-        const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const float gmm = p.gamma[c];
-        cvec[c] = p.bias[c];
-        cvec[C1 + c] = gmm * rstd;
-        cvec[2 * C1 + c] = p.beta[c] - (float)mean * gmm * rstd;
-        if constexpr (IMG) cvec[3 * C1 + c] = p.b0[c];
+        if constexpr (PLAIN) {
+            cvec[c] = p.bias ? p.bias[c] : 0.f;
+        } else {
+            const double n = (double)p.H * (double)p.W * 16.0;
+            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float gmm = p.gamma[c];
+            cvec[c] = p.bias[c];
+            cvec[C1 + c] = gmm * rstd;
+            cvec[2 * C1 + c] = p.beta[c] - (float)mean * gmm * rstd;
+            if constexpr (IMG) cvec[3 * C1 + c] = p.b0[c];
+        }
     }
     __syncthreads();
 
@@ -226,6 +233,10 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         // GroupNorm affine + SiLU in registers, then into the wave's LDS tile as [px][ch]
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            if constexpr (PLAIN) {
+                *reinterpret_cast<u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8) = raw[it];
+                continue;
+            }
             // two channels per instruction: v_pk_fma / v_pk_mul / v_pk_add on f32 pairs
             bf16x8_t o;
 #pragma unroll
@@ -400,7 +411,10 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
     } while (0)
     const bool dense = (a->x_stride[1] == (int64_t)a->W * a->x_stride[2] || a->first != nullptr) &&
                        a->y_stride[1] == (int64_t)a->W * a->y_stride[2] && (((int64_t)a->H * a->W) % 32 == 0);
-    if (dense) {
+    if (a->stats_in == nullptr) {   // plain convolution (data-gradient pass)
+        if (dense) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float, true, true>));
+        else NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float, false, true>));
+    } else if (dense) {
         if (variant == 0) NAF_LAUNCH_1X1((stem_conv1x1_kernel<false, float, true>));
         else if (variant == 1) NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, float, true>));
         else NAF_LAUNCH_1X1((stem_conv1x1_kernel<true, bf16_t, true>));

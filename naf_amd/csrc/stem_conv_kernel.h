@@ -63,7 +63,9 @@ struct StemGeom {
 // ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue
 // (bias, sums, LDS tile), 4 no LDS B-fragment reads (MFMA on stale registers), 8 no row stores, 16 no global loads,
 // 32 no per-step barrier, 64 no per-slot scheduling pins, 128 cycle counters per step, 256 phase timestamps
-template <int KS, int ABL = 0>
+// PLAIN: no GroupNorm, no SiLU -- y = conv(x) (+ bias if given): the data gradient of a layer is this kernel on the output
+// gradient with the flipped, transposed weights (stats_in == NULL in the C ABI).
+template <int KS, int ABL = 0, bool PLAIN = false>
 __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams p) {
     static_assert(KS == 3, "the 1x1 layers have their own kernel (stem_conv1x1.hip)");
     using G = StemGeom<KS>;
@@ -94,17 +96,23 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
     //   cvec[0][c] conv bias, cvec[1][c] / cvec[2][c] GroupNorm scale / shift of the INPUT channel c
     const int chunk = tid & 15, pl = tid >> 4;
     if (tid < C) {
-        const int g = tid >> 4;  // 16 channels per group
-        const double n = (double)p.H * (double)p.W * 16.0;
-        const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const float gmm = p.gamma[tid];
-        cvec[tid] = p.bias[tid];
-        cvec[C + tid] = gmm * rstd;
-        cvec[2 * C + tid] = p.beta[tid] - (float)mean * gmm * rstd;
+        if constexpr (PLAIN) {
+            cvec[tid] = p.bias ? p.bias[tid] : 0.f;
+            cvec[C + tid] = 1.f;
+            cvec[2 * C + tid] = 0.f;
+        } else {
+            const int g = tid >> 4;  // 16 channels per group
+            const double n = (double)p.H * (double)p.W * 16.0;
+            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float gmm = p.gamma[tid];
+            cvec[tid] = p.bias[tid];
+            cvec[C + tid] = gmm * rstd;
+            cvec[2 * C + tid] = p.beta[tid] - (float)mean * gmm * rstd;
+        }
     }
     __syncthreads();
 
@@ -116,6 +124,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
         gbv[e] = f32x2_t{cvec[2 * C + chunk * 8 + 2 * e], cvec[2 * C + chunk * 8 + 2 * e + 1]};
         ga2v[e] = gav[e] * -1.4426950408889634f;
         gb2v[e] = gbv[e] * -1.4426950408889634f;
+        if constexpr (PLAIN) {   // the schedule's y * rcp(1 + exp2(u)) with u = -1e30: exp2 -> 0, rcp(1) = 1, y = x * 1 + 0
+            ga2v[e] = f32x2_t{0.f, 0.f};
+            gb2v[e] = f32x2_t{-1e30f, -1e30f};
+        }
     }
     // Addressing: wave-uniform 64-bit row bases (SGPR) + per-lane 32-bit byte offsets inside a row, so that a
     // load / store is one global instruction with no per-lane 64-bit arithmetic and half the registers.
@@ -164,8 +176,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
         bf16x8_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            o[e] = (bf16_t)silu(fmaf((float)v[e], a0[e], b0[e]));
-            o[4 + e] = (bf16_t)silu(fmaf((float)v[4 + e], a1[e], b1[e]));
+            o[e] = PLAIN ? v[e] : (bf16_t)silu(fmaf((float)v[e], a0[e], b0[e]));
+            o[4 + e] = PLAIN ? v[4 + e] : (bf16_t)silu(fmaf((float)v[4 + e], a1[e], b1[e]));
         }
         *reinterpret_cast<bf16x8_t*>(ring + slot * ROWE + px * PXE + chunk * 8) = o;
     };

@@ -178,6 +178,128 @@ class _ReflectPad(torch.autograd.Function):
         return out, None
 
 
+def _stem_layers(seq: nn.Sequential):
+    """(norm, conv) pairs of a branch after its first convolution (convolutions.py:52-61: norm1 -> SiLU -> conv1, norm2 -> ...)."""
+    out = []
+    for blk in list(seq)[1:]:
+        out += [(blk.norm1, blk.conv1), (blk.norm2, blk.conv2)]
+    return out
+
+
+class _HipStem(torch.autograd.Function):
+    """Both branches of the conv stem (convolutions.py:67-92) as ONE differentiable op on the HIP kernels: the forward is the
+    inference stem (naf_stem_conv0_fwd / naf_stem_conv_fwd, bf16 activations, fp32 accumulation, fp64 GroupNorm sums) with
+    every layer's input kept; the backward walks the layers down with
+      data gradient    naf_stem_conv_fwd in plain mode on the flipped / transposed weights (3x3: over the output gradient in a
+                       2-pixel zero border, i.e. on the reflect-PADDED domain),
+      norm + SiLU      naf_stem_act_bwd (folds the padded border back on load, returns the GroupNorm affine gradients),
+      weight gradient  MIOpen's bf16 wgrad on a = SiLU(GroupNorm(x)) re-materialised by naf_stem_act_fwd (with its reflected
+                       border) -- the one step that is not a kernel of this library yet.
+    bf16 roundings of stored activations / gradients are treated as identities (as torch.autocast does for bf16 convolutions:
+    this is the reference's use_bf16 training mode, train.py:120).  Default width (128 hidden channels) only."""
+
+    @staticmethod
+    def forward(ctx, enc, image, *params):
+        B, _, H, W = image.shape
+        dev = image.device
+        branches = (enc.encoder, enc.sem_encoder)
+        hid = 128
+        nlayer = len(_stem_layers(enc.encoder))
+        stats = torch.zeros((2, nlayer + 1, B, 8, 2), dtype=torch.float64, device=dev)
+        cat = torch.empty((B, H, W, 2 * hid), dtype=torch.bfloat16, device=dev)
+        img = image.detach()
+        if img.dtype not in (torch.float32, torch.bfloat16):
+            img = img.float()
+        saved = []
+        for br, seq in enumerate(branches):
+            conv0 = seq[0]
+            ys = [torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev) for _ in range(max(nlayer, 1))]
+            dst = ys[0] if nlayer else cat[..., br * hid:(br + 1) * hid]
+            ops.stem_conv0(img, conv0.weight.detach().float().contiguous(), conv0.bias.detach().float(), dst, stats[br, 0])
+            for li, (norm, conv) in enumerate(_stem_layers(seq)):
+                last = li == nlayer - 1
+                dst = cat[..., br * hid:(br + 1) * hid] if last else ys[li + 1]
+                ops.stem_conv(ys[li], stats[br, li], norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
+                              enc._packed(conv), conv.bias.detach().float(), dst, None if last else stats[br, li + 1])
+            saved.append(ys)
+        ctx.enc, ctx.image, ctx.saved, ctx.stats, ctx.nparams = enc, image, saved, stats, len(params)
+        return cat.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, image, stats = ctx.enc, ctx.image, ctx.stats
+        B, _, H, W = image.shape
+        dev = g.device
+        hid = 128
+        gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16)                       # [B, H, W, 256], channels contiguous
+        grads = []
+        dimage = None
+        ext = None
+        for br, seq in enumerate((enc.encoder, enc.sem_encoder)):
+            ys = ctx.saved[br]
+            layers = _stem_layers(seq)
+            gl = gcl[..., br * hid:(br + 1) * hid].contiguous()             # gradient of the layer's conv output
+            bgrads = []
+            for li in range(len(layers) - 1, -1, -1):
+                norm, conv = layers[li]
+                k = conv.kernel_size[0]
+                w = conv.weight.detach()
+                gw, gb = norm.weight.detach().float(), norm.bias.detach().float()
+                # weight / bias gradient: MIOpen wgrad on a = SiLU(GroupNorm(x)) (bf16, channels-last, reflected border)
+                a_pad = ops.stem_act(ys[li], stats[br, li], gw, gb, norm.eps, pad=k // 2)
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    gl.permute(0, 3, 1, 2), a_pad.permute(0, 3, 1, 2), w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
+                    [hid], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+                del a_pad
+                # data gradient: the same conv kernel, plain, on the flipped / transposed weights
+                wt = w.flip(2, 3).permute(2, 3, 1, 0).reshape(k * k, hid, hid).contiguous().to(torch.bfloat16)
+                dx = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
+                if k == 3:
+                    if ext is None:
+                        ext = torch.zeros((B, H + 4, W + 4, hid), dtype=torch.bfloat16, device=dev)   # the border stays zero
+                    ext[:, 2:H + 2, 2:W + 2].copy_(gl)
+                    full = torch.empty_like(ext)
+                    ops.stem_conv_plain(ext, wt, full)
+                    sums = ops.stem_act_bwd(full[:, 1:H + 3, 1:W + 3], ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=True)
+                    del full
+                else:
+                    da = torch.empty_like(gl)
+                    ops.stem_conv_plain(gl, wt, da)
+                    sums = ops.stem_act_bwd(da, ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=False)
+                    del da
+                s32 = sums.sum(0).float()
+                bgrads.append((s32[:, 1].to(norm.weight.dtype), s32[:, 0].to(norm.bias.dtype),
+                               dw.to(conv.weight.dtype), db.to(conv.bias.dtype)))
+                gl = dx
+            # first convolution (3 -> 128, fp32 image): tiny, through autograd on a recompute
+            conv0 = seq[0]
+            need_img = ctx.needs_input_grad[1]
+            with torch.enable_grad():
+                im = image.detach().float().requires_grad_(need_img)
+                w0 = conv0.weight.detach().requires_grad_(True)
+                b0 = conv0.bias.detach().requires_grad_(True)
+                pad = conv0.kernel_size[0] // 2
+                y0 = F.conv2d(_ReflectPad.apply(im, pad) if pad else im, w0, b0)
+                outs = torch.autograd.grad(y0, [w0, b0] + ([im] if need_img else []), gl.permute(0, 3, 1, 2).float())
+            if need_img:
+                dimage = outs[2] if dimage is None else dimage + outs[2]
+            grads += [outs[0], outs[1]]
+            for t in reversed(bgrads):
+                grads += list(t)
+        assert len(grads) == ctx.nparams
+        return (None, dimage.to(image.dtype) if dimage is not None else None, *grads)
+
+
+def _hip_stem_params(enc):
+    """Parameters in the order _HipStem.backward returns their gradients."""
+    out = []
+    for seq in (enc.encoder, enc.sem_encoder):
+        out += [seq[0].weight, seq[0].bias]
+        for norm, conv in _stem_layers(seq):
+            out += [norm.weight, norm.bias, conv.weight, conv.bias]
+    return out
+
+
 class ImageEncoder(nn.Module):
     """Guidance encoder (naf.py:11-52).  Both conv branches run through the library's fused HIP stem
     (naf_stem_conv0_fwd / naf_stem_conv_fwd: GroupNorm+SiLU+conv in one MFMA pass per layer): the hand-scheduled
@@ -515,7 +637,9 @@ class NAF(nn.Module):
         reference's random rescale (rope.py:107-124, NAF's rope_rescale); in ``.eval()`` mode they are deterministic.  Needs the shapes
         ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9).
         ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
-        mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32."""
+        mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32.  ``amp="hip"`` is the same
+        precision class on this library's own stem: ``_HipStem`` (fused forward kernels, bf16 activations kept per layer, HIP
+        data-gradient / GroupNorm+SiLU backward kernels)."""
         if not (image.is_cuda and features.is_cuda):
             raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback)")
         enc = self.image_encoder
@@ -526,13 +650,35 @@ class NAF(nn.Module):
         if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
             x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
                               mode="bilinear", align_corners=False)
-        if enc.use_encoder:
+        if enc.use_encoder and amp == "hip":
+            if not enc._hip_stem_default_width():
+                raise RuntimeError("forward_train(amp='hip'): the differentiable HIP stem serves the default width (dim 256)")
+            x = _HipStem.apply(enc, x, *_hip_stem_params(enc))
+            if x.shape[-2:] != (ho, wo):
+                x = x.float()
+        elif enc.use_encoder:
             x = x.float().contiguous(memory_format=torch.channels_last)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(amp)):
                 x = torch.cat([enc._branch_train(x, enc.encoder), enc._branch_train(x, enc.sem_encoder)], dim=1)
             x = x.float()
         if x.shape[-2:] != (ho, wo):
             x = F.adaptive_avg_pool2d(x, output_size=(ho, wo))                 # naf.py:34
+        if amp == "hip" and heads_rope == heads and (x.shape[1] // heads_rope) % 32 == 0:
+            # RoPE, key pooling and their backward as HIP kernels too (naf_rope_pool_fwd / naf_rope_pool_bwd): the guidance stays
+            # bf16 channels-last from the stem's last layer to the attention kernel, and so does its gradient on the way back
+            if enc.rope.training and enc.rope.cache_train_coords:
+                if (ho, wo) not in enc.rope._train_tables:
+                    enc.rope._train_tables[(ho, wo)] = _rope_train_tables(enc.rope, ho, wo)
+                tab_y, tab_x = enc.rope._train_tables[(ho, wo)]
+            else:
+                tab_y, tab_x = _rope_train_tables(enc.rope, ho, wo) if enc.rope.training else enc.rope.tables(ho, wo)
+            xcl = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            q5, k5 = ops.RopePoolFunction.apply(xcl, tab_y.contiguous(), tab_x.contiguous(), heads_rope, (h, w))
+            B, C = features.shape[:2]
+            v5 = features.reshape(B, heads, C // heads, h, w).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
+            out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
+            out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
+            return out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
         # [Ho, 2, P], [Wo, 2, P]; in training mode with the reference's coordinate augmentation (rope.py:107-124)
         if enc.rope.training and enc.rope.cache_train_coords:

@@ -155,6 +155,73 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
     _lib.check(rc, "naf_stem_conv_fwd")
 
 
+def stem_conv_plain(x: torch.Tensor, w_packed: torch.Tensor, y: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
+    """y = conv(x) (+ bias): ``naf_stem_conv_fwd`` without GroupNorm / SiLU, bf16 [B,H,W,128] views, reflect padding for the
+    3x3 kernel.  With ``w_packed`` = the flipped, transposed weights it is a layer's data gradient (see include/naf_hip.h)."""
+    lib = _lib.load()
+    _gpu(x, "x")
+    B, H, W, Cc = x.shape
+    if Cc != 128 or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
+        raise ValueError("stem_conv_plain: bf16 [B,H,W,128] activations with channels contiguous")
+    if tuple(w_packed.shape[1:]) != (Cc, Cc) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
+        raise ValueError(f"stem_conv_plain: packed weight {tuple(w_packed.shape)} / {w_packed.dtype}")
+    a = StemConvArgs()
+    a.x, a.y, a.w_packed = x.data_ptr(), y.data_ptr(), w_packed.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.gn_weight = a.gn_bias = a.stats_in = a.stats_out = None
+    a.ksize = {1: 1, 9: 3}[int(w_packed.shape[0])]
+    a.channels = Cc
+    a.B, a.H, a.W, a.eps = B, H, W, 0.0
+    a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
+    a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
+    with torch.cuda.device(x.device), _Timed("stem_dgrad%d" % a.ksize):
+        rc = lib.naf_stem_conv_fwd(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_stem_conv_fwd")
+
+
+def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor, eps: float,
+             pad: int = 0) -> torch.Tensor:
+    """SiLU(GroupNorm(8, C)(x)) as bf16 [B, H + 2 pad, W + 2 pad, C] with a reflected border (``naf_stem_act_fwd``)."""
+    lib = _lib.load()
+    _gpu(x, "x")
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H + 2 * pad, W + 2 * pad, Cc), dtype=torch.bfloat16, device=x.device)
+    a = _lib.StemActArgs()
+    a.x, a.a, a.gn_weight, a.gn_bias, a.stats_in = x.data_ptr(), out.data_ptr(), gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    a.B, a.H, a.W, a.channels, a.pad, a.eps = B, H, W, Cc, int(pad), float(eps)
+    a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
+    a.a_stride = I64x3(int(out.stride(0)), int(out.stride(1)), int(out.stride(2)))
+    with torch.cuda.device(x.device), _Timed("stem_act"):
+        rc = lib.naf_stem_act_fwd(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_stem_act_fwd")
+    return out
+
+
+def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,
+                 eps: float, dx: torch.Tensor, fold: bool = False) -> torch.Tensor:
+    """Backward of SiLU(GroupNorm(x)) (``naf_stem_act_bwd``): writes dx (bf16 [B,H,W,C] view) and returns the fp64 sums
+    [B, C, 2] = per sample {d gn_bias, d gn_weight}.  ``fold``: da is [B, H+2, W+2, C], the gradient on the reflect-padded
+    domain."""
+    lib = _lib.load()
+    _gpu(x, "x")
+    B, H, W, Cc = x.shape
+    want = (B, H + 2, W + 2, Cc) if fold else (B, H, W, Cc)
+    if tuple(da.shape) != want or da.dtype != torch.bfloat16 or da.stride(3) != 1 or dx.stride(3) != 1 or tuple(dx.shape) != (B, H, W, Cc):
+        raise ValueError(f"stem_act_bwd: da {tuple(da.shape)} (want {want}) / dx {tuple(dx.shape)}")
+    sums = torch.zeros((B, Cc, 2), dtype=torch.float64, device=x.device)
+    a = _lib.StemActBwdArgs()
+    a.da, a.x, a.dx = da.data_ptr(), x.data_ptr(), dx.data_ptr()
+    a.gn_weight, a.gn_bias, a.stats_in, a.sums = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr(), sums.data_ptr()
+    a.B, a.H, a.W, a.channels, a.fold, a.phase, a.eps = B, H, W, Cc, int(bool(fold)), 0, float(eps)
+    a.da_stride = I64x3(int(da.stride(0)), int(da.stride(1)), int(da.stride(2)))
+    a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
+    a.dx_stride = I64x3(int(dx.stride(0)), int(dx.stride(1)), int(dx.stride(2)))
+    with torch.cuda.device(x.device), _Timed("stem_act_bwd"):
+        rc = lib.naf_stem_act_bwd(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_stem_act_bwd")
+    return sums
+
+
 # ------------------------------------------------------------------------------------------------
 def rope_tables(periods: torch.Tensor, Ho: int, Wo: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin tables [Ho, 2, P] and [Wo, 2, P] (fp32) for the module's `periods` buffer [P]."""
@@ -388,6 +455,48 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
         rc = lib.naf_xna_bwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_bwd")
     return dq, dk.permute(0, 3, 1, 2, 4), dv.permute(0, 3, 1, 2, 4)
+
+
+def rope_pool_bwd(dq: torch.Tensor, dk: torch.Tensor, tab_y: torch.Tensor, tab_x: torch.Tensor, out_size) -> torch.Tensor:
+    """Backward of ``rope_pool``: dq bf16 [B, heads, Ho, Wo, Dh], dk [B, heads, h, w, Dh] (cast to fp32) -> dx, a logical
+    [B, heads * Dh, Ho, Wo] view of a channels-last bf16 buffer (``naf_rope_pool_bwd``)."""
+    lib = _lib.load()
+    _gpu(dq, "dq")
+    B, heads, Ho, Wo, Dh = dq.shape
+    h, w = dk.shape[2], dk.shape[3]
+    if dq.dtype != torch.bfloat16 or dq.stride(4) != 1:
+        dq = dq.to(torch.bfloat16).contiguous()
+    dk = dk.float()
+    if dk.stride(4) != 1:
+        dk = dk.contiguous()
+    dx = torch.empty((B, Ho, Wo, heads * Dh), dtype=torch.bfloat16, device=dq.device).permute(0, 3, 1, 2)
+    a = _lib.RopePoolBwdArgs()
+    a.dq, a.dk_lr, a.dx, a.tab_y, a.tab_x = dq.data_ptr(), dk.data_ptr(), dx.data_ptr(), tab_y.data_ptr(), tab_x.data_ptr()
+    a.B, a.Cq, a.heads, a.Ho, a.Wo, a.h, a.w = B, heads * Dh, heads, Ho, Wo, h, w
+    a.dq_stride = _strides4(dq, (0, 1, 2, 3))
+    a.dk_stride = _strides4(dk, (0, 1, 2, 3))
+    a.dx_stride = _strides4(dx, (0, 1, 2, 3))
+    with torch.cuda.device(dq.device), _Timed("rope_pool_bwd"):
+        rc = lib.naf_rope_pool_bwd(C.byref(a), _stream(dq))
+    _lib.check(rc, "naf_rope_pool_bwd")
+    return dx
+
+
+class RopePoolFunction(torch.autograd.Function):
+    """Differentiable ``rope_pool`` (queries and pooled keys of the guidance): forward = naf_rope_pool_fwd, backward =
+    naf_rope_pool_bwd.  x: logical [B, Cq, Ho, Wo] bf16, channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, tab_y, tab_x, heads, lr_size):
+        q5, k5 = rope_pool(x, tab_y, tab_x, heads, lr_size, q_layout="channels_last")
+        ctx.save_for_backward(tab_y, tab_x)
+        ctx.size = tuple(x.shape[-2:])
+        return q5, k5
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        tab_y, tab_x = ctx.saved_tensors
+        return rope_pool_bwd(dq, dk, tab_y, tab_x, ctx.size), None, None, None, None
 
 
 class XnaFunction(torch.autograd.Function):

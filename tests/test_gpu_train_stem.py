@@ -1,0 +1,165 @@
+"""The differentiable HIP stem (naf_amd.model._HipStem: train.py:127-137 through convolutions.py:52-92) against torch autograd
+on the same layers: every building block alone (plain convolution = data gradient, SiLU(GroupNorm) forward / backward with and
+without the reflect-padding fold), then the gradients of all 36 encoder parameters and of the image through the whole model."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def group_stats(x):
+    """fp64 {sum, sum^2} per (sample, group of 16 channels) of a [B, H, W, 128] tensor, as the forward kernels accumulate them."""
+    B = x.shape[0]
+    xd = x.double().reshape(B, -1, 8, 16)
+    return torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1).contiguous()
+
+
+@pytest.mark.parametrize("k,H,W", [(3, 24, 40), (1, 16, 32), (3, 7, 33), (1, 5, 9)])
+def test_plain_convolution(dev, k, H, W):
+    """naf_stem_conv_fwd without GroupNorm / SiLU == F.conv2d (reflect padding) on the bf16 inputs, fp32 accumulation."""
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(k * 100 + H)
+    x = torch.randn(2, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(128, 128, k, k, generator=g) / (128 * k * k) ** 0.5).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    wp = w.permute(2, 3, 0, 1).reshape(k * k, 128, 128).contiguous().to(torch.bfloat16)
+    y = torch.empty_like(x)
+    ops.stem_conv_plain(x, wp, y, bias=b)
+    xin = x.float().permute(0, 3, 1, 2)
+    if k == 3:
+        xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
+    ref = F.conv2d(xin, wp.float().reshape(k, k, 128, 128).permute(2, 3, 0, 1), b).permute(0, 2, 3, 1)
+    err = (y.float() - ref).abs()
+    assert float((err - 2 ** -8 * ref.abs()).max()) < 2e-3, float(err.max())     # one bf16 rounding of the output
+    y2 = torch.empty_like(x)
+    ops.stem_conv_plain(x, wp, y2)                                                # bias is optional
+    assert rel(y2.float(), ref - b) < 5e-3
+
+
+@pytest.mark.parametrize("pad,H,W", [(0, 12, 20), (1, 12, 20), (1, 2, 5)])
+def test_act_forward(dev, pad, H, W):
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7 + pad)
+    x = (torch.randn(2, H, W, 128, generator=g) * 2 + 0.5).to(dev).to(torch.bfloat16)
+    gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
+    a = ops.stem_act(x, group_stats(x), gw, gb, 1e-5, pad=pad)
+    ref = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 8, gw, gb, 1e-5))
+    if pad:
+        ref = F.pad(ref, (1, 1, 1, 1), mode="reflect")
+    ref = ref.permute(0, 2, 3, 1)
+    assert a.shape == ref.shape
+    assert float((a.float() - ref).abs().max()) < 3e-2 and rel(a.float(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("fold,H,W", [(False, 12, 20), (True, 12, 20), (True, 3, 4), (True, 2, 2)])
+def test_act_backward(dev, fold, H, W):
+    """dx, d gamma, d beta of a = SiLU(GroupNorm(x)) vs autograd; with fold the incoming gradient lives on the reflect-padded
+    domain and autograd differentiates through F.pad(mode='reflect') as well."""
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11 + H)
+    B = 2
+    x = (torch.randn(B, H, W, 128, generator=g) * 1.5 - 0.3).to(dev).to(torch.bfloat16)
+    gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
+    shp = (B, H + 2, W + 2, 128) if fold else (B, H, W, 128)
+    da = torch.randn(shp, generator=g).to(dev).to(torch.bfloat16)
+    dx = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+    sums = ops.stem_act_bwd(da, x, group_stats(x), gw, gb, 1e-5, dx, fold=fold)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gwr, gbr = gw.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+    a = F.silu(F.group_norm(xr, 8, gwr, gbr, 1e-5))
+    if fold:
+        a = F.pad(a, (1, 1, 1, 1), mode="reflect")
+    a.backward(da.float().permute(0, 3, 1, 2))
+    assert rel(dx.float(), xr.grad.permute(0, 2, 3, 1)) < 6e-3
+    assert rel(sums[..., 1].sum(0).float(), gwr.grad) < 2e-3 and rel(sums[..., 0].sum(0).float(), gbr.grad) < 2e-3
+
+
+def test_strided_views(dev):
+    """The kernels take the strided views the backward hands them: interior of a zero-bordered buffer, channel halves."""
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, H, W = 1, 10, 18
+    big = torch.randn(B, H + 4, W + 4, 256, generator=g).to(dev).to(torch.bfloat16)
+    x = big[:, 2:H + 2, 2:W + 2, 128:]
+    gw, gb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    a = ops.stem_act(x, group_stats(x), gw, gb, 1e-5, pad=0)
+    a2 = ops.stem_act(x.contiguous(), group_stats(x), gw, gb, 1e-5, pad=0)
+    assert torch.equal(a, a2)
+    da = torch.randn(B, H + 2, W + 2, 128, generator=g).to(dev).to(torch.bfloat16)
+    out = torch.zeros(B, H + 4, W + 4, 128, dtype=torch.bfloat16, device=dev)
+    s1 = ops.stem_act_bwd(da, x, group_stats(x), gw, gb, 1e-5, out[:, 2:H + 2, 2:W + 2], fold=True)
+    ref = torch.empty(B, H, W, 128, dtype=torch.bfloat16, device=dev)
+    s2 = ops.stem_act_bwd(da.clone(), x.contiguous(), group_stats(x), gw, gb, 1e-5, ref, fold=True)
+    assert torch.equal(out[:, 2:H + 2, 2:W + 2], ref) and float(out[:, :2].abs().max()) == 0.0
+    assert rel(s1, s2) < 1e-6
+
+
+@pytest.mark.parametrize("shape,lr", [((2, 256, 32, 48), (4, 6)), ((1, 256, 23, 30), (5, 7)), ((1, 128, 16, 16), (16, 16))])
+def test_rope_pool_backward(dev, shape, lr):
+    """naf_rope_pool_bwd vs autograd through the oracle's RoPE + adaptive key pooling (divisible, overlapping windows, ratio 1)."""
+    from oracle import naf_oracle as O
+    from naf_amd import ops
+    B, C, H, W = shape
+    heads = C // 64
+    g = torch.Generator(device="cpu").manual_seed(21)
+    per = O.rope_periods(C, heads, 100.0)
+    x = torch.randn(shape, generator=g).requires_grad_(True)
+    gq = torch.randn(shape, generator=g).to(torch.bfloat16).float()
+    gk = torch.randn(B, C, *lr, generator=g)
+    q = O.rope(x, per, heads)
+    k = O.key_pool(q, lr)
+    ((q * gq).sum() + (k * gk).sum()).backward()
+    ty, tx = ops.rope_tables(per.to(dev), H, W)
+    to5 = lambda t: t.to(dev).reshape(B, heads, 64, *t.shape[-2:]).permute(0, 1, 3, 4, 2).contiguous()
+    dx = ops.rope_pool_bwd(to5(gq).to(torch.bfloat16), to5(gk), ty, tx, (H, W))
+    assert dx.shape == shape and dx.dtype == torch.bfloat16
+    assert rel(dx.float().cpu(), x.grad) < 4e-3
+
+
+@pytest.mark.parametrize("size,lr,ksz,img_grad", [(96, 6, 3, True), (64, 4, 3, False)])
+def test_model_gradients_match_torch_stem(dev, size, lr, ksz, img_grad):
+    """forward_train(amp='hip') vs forward_train(amp=False) (fp32 torch stem, same HIP attention): output and the gradients of
+    every encoder parameter (and of the image) agree to bf16-activation accuracy."""
+    from naf_amd import NAF
+    torch.manual_seed(3)
+    model = NAF(kernel_size=ksz).to(dev).eval()          # eval: deterministic RoPE coordinates on both paths
+    with torch.no_grad():                                  # non-trivial GroupNorm affine / biases
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    g = torch.Generator(device="cpu").manual_seed(9)
+    image = torch.randn(2, 3, size, size, generator=g).to(dev)
+    feats = torch.randn(2, 64, lr, lr, generator=g).to(dev)
+    wout = torch.randn(2, 64, size, size, generator=g).to(dev)
+    res = {}
+    for mode in (False, "hip"):
+        model.zero_grad(set_to_none=True)
+        im = image.clone().requires_grad_(img_grad)
+        out = model.forward_train(im, feats, (size, size), amp=mode)
+        (out.float() * wout).sum().backward()
+        res[mode] = (out.detach().float(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                     im.grad.detach().clone() if img_grad else None)
+    out_r, gr, gi_r = res[False]
+    out_h, gh, gi_h = res["hip"]
+    assert rel(out_h, out_r) < 2e-2
+    assert set(gr) == set(gh) and len(gr) == 36
+    worst = max((rel(gh[n], gr[n]), n) for n in gr)
+    assert worst[0] < 6e-2, worst
+    if img_grad:
+        assert rel(gi_h, gi_r) < 6e-2

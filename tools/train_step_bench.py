@@ -13,7 +13,7 @@ img = torch.randn(1, 3, 448, 448, device=dev)
 ft = torch.randn(1, 384, 28, 28, device=dev)
 tgt = torch.randn(1, 384, 448, 448, device=dev)
 
-AMP = "--amp" in sys.argv
+AMP = "hip" if "--hip" in sys.argv else ("--amp" in sys.argv)   # --hip: the library's own differentiable stem (_HipStem)
 
 def step():
     opt.zero_grad(set_to_none=True)
@@ -31,5 +31,12 @@ e0.record()
 n = 10
 for _ in range(n): l = step()
 e1.record(); torch.cuda.synchronize()
-print(("amp (bf16 stem convs) " if AMP else "") + "fwd+bwd+SGD step: %.2f ms   peak memory %.0f MB   (reference, A100-40GB: 163.08 ms, 6016.5 MB)   loss %.4f"
+print(("HIP stem (bf16 activations) " if AMP == "hip" else "amp (bf16 stem convs) " if AMP else "") + "fwd+bwd+SGD step: %.2f ms   peak memory %.0f MB   (reference, A100-40GB: 163.08 ms, 6016.5 MB)   loss %.4f"
       % (e0.elapsed_time(e1) / n, torch.cuda.max_memory_allocated() / 2**20, float(l)))
+
+if "--profile" in sys.argv:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=70))
