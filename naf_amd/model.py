@@ -678,7 +678,9 @@ class NAF(nn.Module):
             v5 = features.reshape(B, heads, C // heads, h, w).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
             out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
             out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
-            return out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
+            # [B, heads, Ho, Wo, Dv] is a view of a [B, Ho, Wo, heads * Dv] buffer: hand it out as a logical NCHW view of that
+            # (channels-last memory, no transpose copy of the largest tensor of the step)
+            return out5.permute(0, 2, 3, 1, 4).reshape(B, ho, wo, C).permute(0, 3, 1, 2)
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
         # [Ho, 2, P], [Wo, 2, P]; in training mode with the reference's coordinate augmentation (rope.py:107-124)
         if enc.rope.training and enc.rope.cache_train_coords:
@@ -718,7 +720,12 @@ class NAF(nn.Module):
             if return_weights:
                 raise NotImplementedError("naf_amd: return_weights is an inference feature (notebooks/attention_maps.ipynb); "
                                           "call under torch.no_grad() or after .eval()")
-            return self.forward_train(image, features, output_size)
+            # under torch.autocast(bfloat16) -- the reference's use_bf16 training mode (train.py:120, denoising.py:209) -- the
+            # default-width model trains through this library's own differentiable stem (bf16 activations, HIP backward kernels)
+            amp = False
+            if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+                amp = "hip" if self.image_encoder._hip_stem_default_width() else True
+            return self.forward_train(image, features, output_size, amp=amp)
         with torch.no_grad():
             return self._forward_inference(image, features, output_size, return_weights)
 

@@ -163,3 +163,35 @@ def test_model_gradients_match_torch_stem(dev, size, lr, ksz, img_grad):
     assert worst[0] < 6e-2, worst
     if img_grad:
         assert rel(gi_h, gi_r) < 6e-2
+
+
+def test_autocast_training_call_uses_the_hip_stem(dev, monkeypatch):
+    """train.py:120-137 as the reference writes it: ``with torch.autocast(bfloat16): out = naf(image, feats, size)`` in
+    .train() mode, loss.backward(), optimizer step -- dispatches to the differentiable HIP stem and trains."""
+    from naf_amd import NAF, ops
+    torch.manual_seed(0)
+    model = NAF(kernel_size=3).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    calls = {"n": 0}
+    real = ops.stem_conv_plain
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "stem_conv_plain", spy)
+    image = torch.randn(1, 3, 64, 64, device=dev)
+    feats = torch.randn(1, 32, 4, 4, device=dev)
+    target = torch.randn(1, 32, 64, 64, device=dev)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(image, feats, (64, 64))
+        loss = (out.float() - target).pow(2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert calls["n"] == 3 * 8                       # eight 128 -> 128 layers, one data-gradient launch each
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    assert out.shape == (1, 32, 64, 64) and all(l == l for l in losses) and losses[-1] != losses[0]   # parameters moved
