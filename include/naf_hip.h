@@ -177,6 +177,25 @@ typedef struct naf_stem_act_bwd_args {
 } naf_stem_act_bwd_args;
 int naf_stem_act_bwd(const naf_stem_act_bwd_args* a, naf_stream_t stream);
 
+/* naf_stem_wgrad : weight gradient of a layer y = conv(SiLU(GroupNorm(x))) + bias (convolutions.py:52-61), 128 channels:
+ *   dw[ty][tx][oc][ic] += sum over pixels of dy[., oc] * a_reflect_padded[. + (ty, tx), ic], a recomputed from x / stats_in on the
+ *   fly (never materialised).  dy, x device bf16 [B, H, W, 128] by strides {b, y, x}; dw device f32 [k][k][128 oc][128 ic]
+ *   (= weight.grad.permute(2, 3, 0, 1): taps outermost keeps the atomics coalesced), ACCUMULATED: zero it first.  ksize 1 or 3. */
+typedef struct naf_stem_wgrad_args {
+    const void* dy;
+    const void* x;
+    float* dw;
+    const float* gn_weight;
+    const float* gn_bias;
+    const double* stats_in;
+    int32_t ksize;
+    int32_t B, H, W;
+    float eps;
+    int64_t dy_stride[3];
+    int64_t x_stride[3];
+} naf_stem_wgrad_args;
+int naf_stem_wgrad(const naf_stem_wgrad_args* a, naf_stream_t stream);
+
 /* ---- RoPE tables --------------------------------------------------------------------------------
  * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),
  * eval mode.  tab_y device float [Ho][2][n_periods] (cos then sin), tab_x device float [Wo][2][..].

@@ -69,6 +69,14 @@ class RopePoolBwdArgs(C.Structure):
     ]
 
 
+class StemWgradArgs(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p),
+        ("stats_in", C.c_void_p), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("eps", C.c_float),
+        ("dy_stride", I64x3), ("x_stride", I64x3),
+    ]
+
+
 class StemActArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("a", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p), ("stats_in", C.c_void_p),
@@ -129,6 +137,7 @@ SIGNATURES = {
     "naf_stem_conv0_fwd": (C.c_int, [C.POINTER(StemConv0Args), C.c_void_p]),
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
     "naf_rope_pool_bwd": (C.c_int, [C.POINTER(RopePoolBwdArgs), C.c_void_p]),
+    "naf_stem_wgrad": (C.c_int, [C.POINTER(StemWgradArgs), C.c_void_p]),
     "naf_stem_act_fwd": (C.c_int, [C.POINTER(StemActArgs), C.c_void_p]),
     "naf_stem_act_bwd": (C.c_int, [C.POINTER(StemActBwdArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -193,8 +193,8 @@ class _HipStem(torch.autograd.Function):
       data gradient    naf_stem_conv_fwd in plain mode on the flipped / transposed weights (3x3: over the output gradient in a
                        2-pixel zero border, i.e. on the reflect-PADDED domain),
       norm + SiLU      naf_stem_act_bwd (folds the padded border back on load, returns the GroupNorm affine gradients),
-      weight gradient  MIOpen's bf16 wgrad on a = SiLU(GroupNorm(x)) re-materialised by naf_stem_act_fwd (with its reflected
-                       border) -- the one step that is not a kernel of this library yet.
+      weight gradient  naf_stem_wgrad: a GEMM contracted over pixels (transposing LDS reads feed both MFMA operands), with
+                       a = SiLU(GroupNorm(x)) recomputed in its loader.
     bf16 roundings of stored activations / gradients are treated as identities (as torch.autocast does for bf16 convolutions:
     this is the reference's use_bf16 training mode, train.py:120).  Default width (128 hidden channels) only."""
 
@@ -245,12 +245,9 @@ class _HipStem(torch.autograd.Function):
                 k = conv.kernel_size[0]
                 w = conv.weight.detach()
                 gw, gb = norm.weight.detach().float(), norm.bias.detach().float()
-                # weight / bias gradient: MIOpen wgrad on a = SiLU(GroupNorm(x)) (bf16, channels-last, reflected border)
-                a_pad = ops.stem_act(ys[li], stats[br, li], gw, gb, norm.eps, pad=k // 2)
-                _, dw, db = torch.ops.aten.convolution_backward(
-                    gl.permute(0, 3, 1, 2), a_pad.permute(0, 3, 1, 2), w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
-                    [hid], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
-                del a_pad
+                # weight / bias gradient: naf_stem_wgrad (pixel-contraction GEMM; a = SiLU(GroupNorm(x)) recomputed in its loader)
+                dw = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k)
+                db = gl.sum(dim=(0, 1, 2), dtype=torch.float32)
                 # data gradient: the same conv kernel, plain, on the flipped / transposed weights
                 wt = w.flip(2, 3).permute(2, 3, 1, 0).reshape(k * k, hid, hid).contiguous().to(torch.bfloat16)
                 dx = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)

@@ -197,6 +197,27 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
     return out
 
 
+def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,
+               eps: float, ksize: int) -> torch.Tensor:
+    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))): ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128]."""
+    lib = _lib.load()
+    _gpu(x, "x")
+    B, H, W, Cc = x.shape
+    if Cc != 128 or tuple(dy.shape) != (B, H, W, Cc) or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.stride(3) != 1 or x.stride(3) != 1:
+        raise ValueError("stem_wgrad: bf16 [B,H,W,128] tensors with channels contiguous")
+    dw = torch.zeros((ksize, ksize, Cc, Cc), dtype=torch.float32, device=x.device)     # taps outermost: coalesced atomics
+    a = _lib.StemWgradArgs()
+    a.dy, a.x, a.dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
+    a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    a.ksize, a.B, a.H, a.W, a.eps = int(ksize), B, H, W, float(eps)
+    a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
+    a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
+    with torch.cuda.device(x.device), _Timed("stem_wgrad%d" % ksize):
+        rc = lib.naf_stem_wgrad(C.byref(a), _stream(x))
+    _lib.check(rc, "naf_stem_wgrad")
+    return dw.permute(2, 3, 0, 1)
+
+
 def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,
                  eps: float, dx: torch.Tensor, fold: bool = False) -> torch.Tensor:
     """Backward of SiLU(GroupNorm(x)) (``naf_stem_act_bwd``): writes dx (bf16 [B,H,W,C] view) and returns the fp64 sums

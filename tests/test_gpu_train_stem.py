@@ -90,6 +90,26 @@ def test_act_backward(dev, fold, H, W):
     assert rel(sums[..., 1].sum(0).float(), gwr.grad) < 2e-3 and rel(sums[..., 0].sum(0).float(), gbr.grad) < 2e-3
 
 
+@pytest.mark.parametrize("k,B,H,W", [(3, 1, 20, 64), (1, 2, 9, 32), (3, 2, 13, 45), (1, 1, 7, 19), (3, 1, 2, 2)])
+def test_weight_gradient(dev, k, B, H, W):
+    """naf_stem_wgrad vs autograd of conv(reflect_pad(SiLU(GroupNorm(x)))) w.r.t. the weight, on the same bf16 tensors."""
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(31 + H)
+    x = (torch.randn(B, H, W, 128, generator=g) * 1.3 + 0.2).to(dev).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
+    gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
+    dw = ops.stem_wgrad(dy, x, group_stats(x), gw, gb, 1e-5, k)
+    a = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 8, gw, gb, 1e-5)).to(torch.bfloat16).float()   # the kernel's bf16 operand
+    if k == 3:
+        a = F.pad(a, (1, 1, 1, 1), mode="reflect")
+    w = torch.zeros(128, 128, k, k, device=dev, requires_grad=True)
+    F.conv2d(a, w).backward(dy.float().permute(0, 3, 1, 2))
+    assert dw.shape == w.grad.shape
+    assert rel(dw, w.grad) < 3e-3, rel(dw, w.grad)
+    for t in range(k * k):       # every tap on its own: a wrong pixel shift of one tap must not hide in the norm of the others
+        assert rel(dw[:, :, t // k, t % k], w.grad[:, :, t // k, t % k]) < 5e-3, t
+
+
 def test_strided_views(dev):
     """The kernels take the strided views the backward hands them: interior of a zero-bordered buffer, channel halves."""
     from naf_amd import ops
