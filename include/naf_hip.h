@@ -180,7 +180,9 @@ int naf_stem_act_bwd(const naf_stem_act_bwd_args* a, naf_stream_t stream);
 /* naf_stem_wgrad : weight gradient of a layer y = conv(SiLU(GroupNorm(x))) + bias (convolutions.py:52-61), 128 channels:
  *   dw[ty][tx][oc][ic] += sum over pixels of dy[., oc] * a_reflect_padded[. + (ty, tx), ic], a recomputed from x / stats_in on the
  *   fly (never materialised).  dy, x device bf16 [B, H, W, 128] by strides {b, y, x}; dw device f32 [k][k][128 oc][128 ic]
- *   (= weight.grad.permute(2, 3, 0, 1): taps outermost keeps the atomics coalesced), ACCUMULATED: zero it first.  ksize 1 or 3. */
+ *   (= weight.grad.permute(2, 3, 0, 1): taps outermost keeps the atomics coalesced), ACCUMULATED: zero it first.  ksize 1 or 3.
+ *   stats_in == NULL: x already IS a (the unpadded output of naf_stem_act_fwd) -- the faster sequence: the activation arithmetic
+ *   runs once in a bandwidth-bound kernel instead of three times in front of the matrix instructions. */
 typedef struct naf_stem_wgrad_args {
     const void* dy;
     const void* x;

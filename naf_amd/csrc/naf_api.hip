@@ -166,7 +166,7 @@ int naf_rope_pool_bwd(const naf_rope_pool_bwd_args* a, naf_stream_t stream) {
 
 int naf_stem_wgrad(const naf_stem_wgrad_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_wgrad: args is NULL");
-    NAF_REQUIRE(a->dy && a->x && a->dw && a->gn_weight && a->gn_bias && a->stats_in, "naf_stem_wgrad: NULL pointer");
+    NAF_REQUIRE(a->dy && a->x && a->dw && (a->stats_in == nullptr || (a->gn_weight && a->gn_bias)), "naf_stem_wgrad: NULL pointer");
     NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_wgrad: kernel size %d (1 or 3)", a->ksize);
     NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_wgrad: size out of range");
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_wgrad: reflect padding needs H, W >= 2");

@@ -37,7 +37,14 @@ __device__ __forceinline__ int wg_reflect(int i, int n) {
 }
 }  // namespace
 
-template <int KS>
+// ACT: x is the layer's INPUT and a = SiLU(GroupNorm(x)) is computed on the way into LDS; otherwise x already is a
+// (naf_stem_act_fwd's output: stats_in == NULL in the C ABI).  Measured at 448^2 (3x3, gpurun r5k): 0.174 ms with ACT, 0.138 ms
+// plain + 0.020 ms for naf_stem_act_fwd: the activation arithmetic is not what bounds the kernel.  Neither are the loads (two
+// segments ahead: no change) nor the atomics (0.035 ms since they are coalesced).  What is left is the LDS: 32 transposing
+// b64 reads per wave and segment for 24 MFMAs, i.e. ~2 500 cycles per segment against 768 MFMA cycles (340 TFLOP/s).
+// Fewer reads per MFMA (the three taps' fragments are the same pixel run shifted by one: 3 reads + v_alignbit instead of 6)
+// is the next step; MIOpen's bf16 wgrad takes 0.347 ms on the same layer.
+template <int KS, bool ACT>
 __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParams p) {
     constexpr int HALO = KS / 2, APX = SEG + 2 * HALO, TAPS = KS;      // taps of this workgroup's tap row
     constexpr int NDP = SEG * 16 / 256;                                // dY pieces (16 B) per thread per segment
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ty = blockIdx.y, b = blockIdx.z;
     const int r0 = blockIdx.x * p.rows_per_block, r1 = min(p.H, r0 + p.rows_per_block);
-    if (tid < WC) {
+    if (ACT && tid < WC) {
         const int g = tid >> 4;
         const double n = (double)p.H * (double)p.W * 16.0;
         const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
@@ -66,8 +73,8 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        sc[e] = cv[chunk * 8 + e];
-        sh[e] = cv[WC + chunk * 8 + e];
+        sc[e] = ACT ? cv[chunk * 8 + e] : 1.f;
+        sh[e] = ACT ? cv[WC + chunk * 8 + e] : 0.f;
     }
     const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0] + chunk * 8;
     const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
@@ -98,7 +105,9 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
 #pragma unroll
         for (int n = 0; n < NAP; ++n) {
             const int j = pl + 16 * n;
-            if (j < APX) {
+            if (!ACT) {
+                if (j < APX) *reinterpret_cast<u32x4_t*>(&At[buf][j * WPX + chunk * 8]) = areg[n];
+            } else if (j < APX) {
                 const bf16x8_t v = __builtin_bit_cast(bf16x8_t, areg[n]);
                 bf16x8_t o;
 #pragma unroll
@@ -194,7 +203,13 @@ int naf_launch_stem_wgrad(const naf_stem_wgrad_args* a, hipStream_t s) {
     if (rows < 1) rows = 1;
     p.rows_per_block = rows;
     const dim3 grid((a->H + rows - 1) / rows, a->ksize, a->B);
-    if (a->ksize == 3) hipLaunchKernelGGL(stem_wgrad_kernel<3>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<1>, grid, dim3(256), 0, s, p);
+    const bool act = a->stats_in != nullptr;
+    if (a->ksize == 3) {
+        if (act) hipLaunchKernelGGL((stem_wgrad_kernel<3, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<3, false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (act) hipLaunchKernelGGL((stem_wgrad_kernel<1, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<1, false>), grid, dim3(256), 0, s, p);
+    }
     return naf_check_launch("stem_wgrad_kernel");
 }

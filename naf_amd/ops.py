@@ -197,9 +197,10 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
     return out
 
 
-def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,
-               eps: float, ksize: int) -> torch.Tensor:
-    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))): ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128]."""
+def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tensor], gn_weight: Optional[torch.Tensor],
+               gn_bias: Optional[torch.Tensor], eps: float, ksize: int) -> torch.Tensor:
+    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))): ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128].
+    ``stats_in=None``: x already is the activation SiLU(GroupNorm(.)) (``stem_act(..., pad=0)``)."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape
@@ -208,7 +209,10 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_wei
     dw = torch.zeros((ksize, ksize, Cc, Cc), dtype=torch.float32, device=x.device)     # taps outermost: coalesced atomics
     a = _lib.StemWgradArgs()
     a.dy, a.x, a.dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
-    a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    if stats_in is not None:
+        a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    else:
+        a.gn_weight = a.gn_bias = a.stats_in = None
     a.ksize, a.B, a.H, a.W, a.eps = int(ksize), B, H, W, float(eps)
     a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))

@@ -106,6 +106,9 @@ def test_weight_gradient(dev, k, B, H, W):
     F.conv2d(a, w).backward(dy.float().permute(0, 3, 1, 2))
     assert dw.shape == w.grad.shape
     assert rel(dw, w.grad) < 3e-3, rel(dw, w.grad)
+    a0 = ops.stem_act(x, group_stats(x), gw, gb, 1e-5, pad=0)                       # the two-call sequence: activation once, ...
+    dw2 = ops.stem_wgrad(dy, a0, None, None, None, 1e-5, k)                          # ... plain pixel-contraction GEMM on it
+    assert rel(dw2, w.grad) < 3e-3
     for t in range(k * k):       # every tap on its own: a wrong pixel shift of one tap must not hide in the norm of the others
         assert rel(dw[:, :, t // k, t % k], w.grad[:, :, t // k, t % k]) < 5e-3, t
 

@@ -20,4 +20,20 @@ for H in (448, 1024):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
+        a = ops.stem_act(x, st, gw, gb, 1e-5, pad=0)
+        for _ in range(3):
+            ops.stem_wgrad(dy, a, None, None, None, 1e-5, k)
+        e0.record()
+        for _ in range(20):
+            ops.stem_wgrad(dy, a, None, None, None, 1e-5, k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / 20
+        e0.record()
+        for _ in range(20):
+            ops.stem_act(x, st, gw, gb, 1e-5, pad=0)
+        e1.record()
+        torch.cuda.synchronize()
+        ms3 = e0.elapsed_time(e1) / 20
+        print(f"   plain (a materialised): {ms2:.4f} ms + act {ms3:.4f} ms")
         print(f"{os.path.basename(os.environ.get('NAF_HIP_LIB', 'default')):24s} {H}^2 k={k}: {ms:.4f} ms  {2 * H * H * 128 * 128 * k * k / ms / 1e9:.0f} TFLOP/s")
