@@ -187,6 +187,7 @@ typedef struct naf_stem_wgrad_args {
     const void* dy;
     const void* x;
     float* dw;
+    float* db;        /* optional f32 [128], ACCUMULATED (zero it first): sum of dy over pixels = the bias gradient */
     const float* gn_weight;
     const float* gn_bias;
     const double* stats_in;
@@ -197,6 +198,23 @@ typedef struct naf_stem_wgrad_args {
     int64_t x_stride[3];
 } naf_stem_wgrad_args;
 int naf_stem_wgrad(const naf_stem_wgrad_args* a, naf_stream_t stream);
+
+/* naf_stem_conv0_wgrad : weight and bias gradient of the first convolution (3 -> 128, ksize 1 or 3, reflect; convolutions.py:68-75):
+ *   dw[(c * k + ty) * k + tx][oc] += sum over pixels of dy[., oc] * image_reflect_padded[. + (ty, tx), c]   (f32 [3*k*k][128] =
+ *   weight.grad.permute(1, 2, 3, 0)), db[oc] += sum of dy; both ACCUMULATED (zero them first).  dy device bf16 [B, H, W, 128] by
+ *   strides {b, y, x}; image device f32 / bf16 by strides {b, c, y, x} as in naf_stem_conv0_fwd. */
+typedef struct naf_stem_conv0_wgrad_args {
+    const void* dy;
+    const void* image;
+    float* dw;
+    float* db;
+    int32_t image_dtype; /* naf_dtype */
+    int32_t ksize;
+    int32_t B, H, W;
+    int64_t dy_stride[3];
+    int64_t image_stride[4];
+} naf_stem_conv0_wgrad_args;
+int naf_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, naf_stream_t stream);
 
 /* ---- RoPE tables --------------------------------------------------------------------------------
  * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),

@@ -71,9 +71,16 @@ class RopePoolBwdArgs(C.Structure):
 
 class StemWgradArgs(C.Structure):
     _fields_ = [
-        ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p),
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p),
         ("stats_in", C.c_void_p), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("eps", C.c_float),
         ("dy_stride", I64x3), ("x_stride", I64x3),
+    ]
+
+
+class StemConv0WgradArgs(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("image", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("image_dtype", C.c_int32),
+        ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dy_stride", I64x3), ("image_stride", I64x4),
     ]
 
 
@@ -138,6 +145,7 @@ SIGNATURES = {
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
     "naf_rope_pool_bwd": (C.c_int, [C.POINTER(RopePoolBwdArgs), C.c_void_p]),
     "naf_stem_wgrad": (C.c_int, [C.POINTER(StemWgradArgs), C.c_void_p]),
+    "naf_stem_conv0_wgrad": (C.c_int, [C.POINTER(StemConv0WgradArgs), C.c_void_p]),
     "naf_stem_act_fwd": (C.c_int, [C.POINTER(StemActArgs), C.c_void_p]),
     "naf_stem_act_bwd": (C.c_int, [C.POINTER(StemActBwdArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -175,6 +175,16 @@ int naf_stem_wgrad(const naf_stem_wgrad_args* a, naf_stream_t stream) {
     return naf_launch_stem_wgrad(a, static_cast<hipStream_t>(stream));
 }
 
+int naf_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, naf_stream_t stream) {
+    NAF_REQUIRE(a != nullptr, "naf_stem_conv0_wgrad: args is NULL");
+    NAF_REQUIRE(a->dy && a->image && a->dw && a->db, "naf_stem_conv0_wgrad: NULL pointer");
+    NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_conv0_wgrad: kernel size %d (1 or 3)", a->ksize);
+    NAF_REQUIRE(a->image_dtype == NAF_BF16 || a->image_dtype == NAF_F32, "naf_stem_conv0_wgrad: image_dtype %d", a->image_dtype);
+    NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_conv0_wgrad: size out of range");
+    NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv0_wgrad: reflect padding needs H, W >= 2");
+    return naf_launch_stem_conv0_wgrad(a, static_cast<hipStream_t>(stream));
+}
+
 int naf_stem_act_fwd(const naf_stem_act_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_stem_act_fwd: args is NULL");
     NAF_REQUIRE(a->x && a->a && a->gn_weight && a->gn_bias && a->stats_in, "naf_stem_act_fwd: NULL pointer");

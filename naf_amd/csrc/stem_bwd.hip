@@ -243,3 +243,106 @@ int naf_launch_stem_act_bwd(const naf_stem_act_bwd_args* a, hipStream_t s) {
     if (a->phase == 0 || a->phase == 2) hipLaunchKernelGGL(stem_act_bwd_kernel<2>, grid, dim3(256), lds, s, p);
     return naf_check_launch("stem_act_bwd_kernel");
 }
+
+
+// ---- weight / bias gradient of the first convolution (3 -> 128, convolutions.py:68-75) ---------------------------------
+// dW0[oc][c][ty][tx] = sum over pixels of dy[px][oc] * image[reflect(px + tap)][c]: 27 (or 3) outputs per oc -- far too thin for
+// the matrix pipe; a thread owns an output channel (lanes = consecutive oc: the dy reads of a wave are one 128-byte run per pixel),
+// keeps its 27 sums in registers and reads the image taps as LDS broadcasts from the three staged rows.  Stored tap-major
+// ([c][ty][tx][oc], fp32 atomics on 128-byte runs); the host permutes the 3 456 numbers into the parameter's layout.
+namespace {
+struct Conv0WgradParams {
+    const bf16_t* dy;
+    const void* image;
+    float* dw;   // [3 * KS * KS][128]
+    float* db;   // [128]
+    int32_t B, H, W, rows_per_block;
+    int64_t dys[3], is[4];
+};
+}  // namespace
+
+template <int KS, typename T>
+__global__ __launch_bounds__(256) void stem_conv0_wgrad_kernel(const Conv0WgradParams p) {
+    constexpr int HALO = KS / 2, NT = 3 * KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float simg[];   // [KS rows][3 ch][W + 2 HALO]
+    const int tid = threadIdx.x, oc = tid & 127, sub = tid >> 7;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * p.rows_per_block, r1 = min(p.H, r0 + p.rows_per_block);
+    const int WP = p.W + 2 * HALO;
+    const T* ib = reinterpret_cast<const T*>(p.image) + (int64_t)b * p.is[0];
+    const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0] + oc;
+    float acc[NT], bs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = 0.f;
+    for (int y = r0; y < r1; ++y) {
+        __syncthreads();
+        for (int i = tid; i < KS * 3 * WP; i += 256) {
+            const int r = i / (3 * WP), rem = i - r * 3 * WP, c = rem / WP, j = rem - c * WP;
+            const int yy = reflect_idx(y + r - HALO, p.H), xx = reflect_idx(j - HALO, p.W);
+            simg[i] = (float)ib[c * p.is[1] + (int64_t)yy * p.is[2] + (int64_t)xx * p.is[3]];
+        }
+        __syncthreads();
+        for (int x = sub; x < p.W; x += 2) {
+            const float g = (float)dyb[(int64_t)y * p.dys[1] + (int64_t)x * p.dys[2]];
+            bs += g;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int ty = 0; ty < KS; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < KS; ++tx)
+                        acc[(c * KS + ty) * KS + tx] = fmaf(g, simg[(ty * 3 + c) * WP + x + tx], acc[(c * KS + ty) * KS + tx]);
+        }
+    }
+    // the two pixel halves of an output channel meet in LDS, then one set of atomics per workgroup
+    __syncthreads();
+    float* red = simg;   // [NT + 1][128] <= the staged rows for every W >= 13 (the launcher sizes the LDS for both uses)
+    if (sub == 1) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) red[i * 128 + oc] = acc[i];
+        red[NT * 128 + oc] = bs;
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) atomicAdd(&p.dw[i * 128 + oc], acc[i] + red[i * 128 + oc]);
+        atomicAdd(&p.db[oc], bs + red[NT * 128 + oc]);
+    }
+}
+
+int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t s) {
+    Conv0WgradParams p;
+    p.dy = static_cast<const bf16_t*>(a->dy); p.image = a->image; p.dw = a->dw; p.db = a->db;
+    p.B = a->B; p.H = a->H; p.W = a->W;
+    for (int i = 0; i < 3; ++i) p.dys[i] = a->dy_stride[i];
+    for (int i = 0; i < 4; ++i) p.is[i] = a->image_stride[i];
+    const int target = naf_cu_count() * 2;
+    int rows = (a->H * a->B + target - 1) / target;
+    if (rows < 1) rows = 1;
+    p.rows_per_block = rows;
+    const int NT = 3 * a->ksize * a->ksize, WP = a->W + 2 * (a->ksize / 2);
+    size_t lds = (size_t)a->ksize * 3 * WP * sizeof(float);
+    if (lds < (size_t)(NT + 1) * 128 * sizeof(float)) lds = (size_t)(NT + 1) * 128 * sizeof(float);
+    if (lds > 150 * 1024) {
+        naf_set_error("naf_stem_conv0_wgrad: image width %d too large for the staged rows", a->W);
+        return NAF_ERR_UNSUPPORTED;
+    }
+    const dim3 grid((a->H + rows - 1) / rows, a->B);
+#define NAF_C0W(KS, T)                                                                                                        \
+    do {                                                                                                                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv0_wgrad_kernel<KS, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            naf_set_error("naf_stem_conv0_wgrad: cannot reserve %zu bytes of LDS", lds);                                      \
+            return NAF_ERR_LAUNCH;                                                                                            \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((stem_conv0_wgrad_kernel<KS, T>), grid, dim3(256), lds, s, p);                                     \
+    } while (0)
+    if (a->ksize == 3) {
+        if (a->image_dtype == NAF_BF16) NAF_C0W(3, bf16_t);
+        else NAF_C0W(3, float);
+    } else {
+        if (a->image_dtype == NAF_BF16) NAF_C0W(1, bf16_t);
+        else NAF_C0W(1, float);
+    }
+#undef NAF_C0W
+    return naf_check_launch("stem_conv0_wgrad_kernel");
+}

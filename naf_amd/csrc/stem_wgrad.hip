@@ -17,6 +17,7 @@ struct StemWgradParams {
     const bf16_t* dy;
     const bf16_t* x;
     float* dw;                // [KS][KS][128 oc][128 ic]
+    float* db;                // [128] or NULL: sum of dY over pixels (the bias gradient), by the tap-row-0 workgroups
     const float* gamma;
     const float* beta;
     const double* stats_in;
@@ -99,9 +100,20 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
             areg[n] = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)ya * p.xs[1] + (int64_t)xx * p.xs[2]);
         }
     };
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool want_db = p.db != nullptr && ty == 0;
     auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n = 0; n < NDP; ++n) *reinterpret_cast<u32x4_t*>(&Dt[buf][(pl + 16 * n) * WPX + chunk * 8]) = dreg[n];
+        for (int n = 0; n < NDP; ++n) {
+            *reinterpret_cast<u32x4_t*>(&Dt[buf][(pl + 16 * n) * WPX + chunk * 8]) = dreg[n];
+            if (want_db) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(dreg[n][e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(dreg[n][e] & 0xffff0000u);
+                }
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NAP; ++n) {
             const int j = pl + 16 * n;
@@ -168,6 +180,19 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
             __syncthreads();
         }
     }
+    if (want_db) {   // 16 pixel lanes per channel chunk -> LDS -> 128 atomics per workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&Dt[0][0]);     // [16 pixel lanes][128]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[pl * WC + chunk * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < WC) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sacc += red[q * WC + tid];
+            atomicAdd(&p.db[tid], sacc);
+        }
+    }
     // D[oc = 8 j + 4 half + i][ic = n32] (acc index 4 j + i) -> dW[ty][tx][oc][ic]: a lane per ic, so one atomic instruction
     // touches two 128-byte runs (scattered over [oc][ic][ty][tx] it was 64 lines per instruction and 3.5 x the kernel's time)
     const int n32 = lane & 31, half = lane >> 5;
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
 
 int naf_launch_stem_wgrad(const naf_stem_wgrad_args* a, hipStream_t s) {
     StemWgradParams p;
-    p.dy = static_cast<const bf16_t*>(a->dy); p.x = static_cast<const bf16_t*>(a->x); p.dw = a->dw;
+    p.dy = static_cast<const bf16_t*>(a->dy); p.x = static_cast<const bf16_t*>(a->x); p.dw = a->dw; p.db = a->db;
     p.gamma = a->gn_weight; p.beta = a->gn_bias; p.stats_in = a->stats_in;
     p.B = a->B; p.H = a->H; p.W = a->W; p.eps = a->eps;
     for (int i = 0; i < 3; ++i) { p.dys[i] = a->dy_stride[i]; p.xs[i] = a->x_stride[i]; }

@@ -234,53 +234,61 @@ class _HipStem(torch.autograd.Function):
         gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16)                       # [B, H, W, 256], channels contiguous
         grads = []
         dimage = None
-        ext = None
+        need_img = ctx.needs_input_grad[1]
         for br, seq in enumerate((enc.encoder, enc.sem_encoder)):
             ys = ctx.saved[br]
             layers = _stem_layers(seq)
-            gl = gcl[..., br * hid:(br + 1) * hid].contiguous()             # gradient of the layer's conv output
+            k = layers[0][1].kernel_size[0] if layers else 1
+            # 3x3 branch: a layer's output gradient lives in the interior of a buffer with a 2-pixel ZERO border (what the
+            # data-gradient convolution of the padded domain reads); naf_stem_act_bwd writes the next one straight into
+            # the other buffer's interior, so only the branch's incoming gradient is ever copied
+            ext = [torch.zeros((B, H + 4, W + 4, hid), dtype=torch.bfloat16, device=dev) for _ in range(2)] if k == 3 else None
+            if k == 3:
+                gl = ext[0][:, 2:H + 2, 2:W + 2]
+                gl.copy_(gcl[..., br * hid:(br + 1) * hid])
+            else:
+                gl = gcl[..., br * hid:(br + 1) * hid]
             bgrads = []
             for li in range(len(layers) - 1, -1, -1):
                 norm, conv = layers[li]
-                k = conv.kernel_size[0]
                 w = conv.weight.detach()
                 gw, gb = norm.weight.detach().float(), norm.bias.detach().float()
                 # weight / bias gradient: naf_stem_wgrad (pixel-contraction GEMM; a = SiLU(GroupNorm(x)) recomputed in its loader)
-                dw = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k)
-                db = gl.sum(dim=(0, 1, 2), dtype=torch.float32)
+                dw, db = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k, with_bias=True)
                 # data gradient: the same conv kernel, plain, on the flipped / transposed weights
                 wt = w.flip(2, 3).permute(2, 3, 1, 0).reshape(k * k, hid, hid).contiguous().to(torch.bfloat16)
-                dx = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
                 if k == 3:
-                    if ext is None:
-                        ext = torch.zeros((B, H + 4, W + 4, hid), dtype=torch.bfloat16, device=dev)   # the border stays zero
-                    ext[:, 2:H + 2, 2:W + 2].copy_(gl)
-                    full = torch.empty_like(ext)
-                    ops.stem_conv_plain(ext, wt, full)
+                    cur = (len(layers) - 1 - li) & 1
+                    full = torch.empty_like(ext[cur])
+                    ops.stem_conv_plain(ext[cur], wt, full)
+                    dx = ext[cur ^ 1][:, 2:H + 2, 2:W + 2]
                     sums = ops.stem_act_bwd(full[:, 1:H + 3, 1:W + 3], ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=True)
                     del full
                 else:
-                    da = torch.empty_like(gl)
+                    da = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
                     ops.stem_conv_plain(gl, wt, da)
+                    dx = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
                     sums = ops.stem_act_bwd(da, ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=False)
                     del da
                 s32 = sums.sum(0).float()
                 bgrads.append((s32[:, 1].to(norm.weight.dtype), s32[:, 0].to(norm.bias.dtype),
                                dw.to(conv.weight.dtype), db.to(conv.bias.dtype)))
                 gl = dx
-            # first convolution (3 -> 128, fp32 image): tiny, through autograd on a recompute
+            # first convolution (3 -> 128 on the image): naf_stem_conv0_wgrad; through ATen only when the image wants a gradient
             conv0 = seq[0]
-            need_img = ctx.needs_input_grad[1]
-            with torch.enable_grad():
-                im = image.detach().float().requires_grad_(need_img)
-                w0 = conv0.weight.detach().requires_grad_(True)
-                b0 = conv0.bias.detach().requires_grad_(True)
-                pad = conv0.kernel_size[0] // 2
-                y0 = F.conv2d(_ReflectPad.apply(im, pad) if pad else im, w0, b0)
-                outs = torch.autograd.grad(y0, [w0, b0] + ([im] if need_img else []), gl.permute(0, 3, 1, 2).float())
-            if need_img:
+            if not need_img:
+                dw0, db0 = ops.stem_conv0_wgrad(gl, image.detach(), conv0.kernel_size[0])
+                grads += [dw0.to(conv0.weight.dtype), db0.to(conv0.bias.dtype)]
+            else:
+                with torch.enable_grad():
+                    im = image.detach().float().requires_grad_(True)
+                    w0 = conv0.weight.detach().requires_grad_(True)
+                    b0 = conv0.bias.detach().requires_grad_(True)
+                    pad = conv0.kernel_size[0] // 2
+                    y0 = F.conv2d(_ReflectPad.apply(im, pad) if pad else im, w0, b0)
+                    outs = torch.autograd.grad(y0, [w0, b0, im], gl.permute(0, 3, 1, 2).float())
                 dimage = outs[2] if dimage is None else dimage + outs[2]
-            grads += [outs[0], outs[1]]
+                grads += [outs[0], outs[1]]
             for t in reversed(bgrads):
                 grads += list(t)
         assert len(grads) == ctx.nparams
@@ -720,7 +728,7 @@ class NAF(nn.Module):
             # under torch.autocast(bfloat16) -- the reference's use_bf16 training mode (train.py:120, denoising.py:209) -- the
             # default-width model trains through this library's own differentiable stem (bf16 activations, HIP backward kernels)
             amp = False
-            if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
                 amp = "hip" if self.image_encoder._hip_stem_default_width() else True
             return self.forward_train(image, features, output_size, amp=amp)
         with torch.no_grad():

@@ -198,17 +198,21 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
 
 
 def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tensor], gn_weight: Optional[torch.Tensor],
-               gn_bias: Optional[torch.Tensor], eps: float, ksize: int) -> torch.Tensor:
-    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))): ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128].
-    ``stats_in=None``: x already is the activation SiLU(GroupNorm(.)) (``stem_act(..., pad=0)``)."""
+               gn_bias: Optional[torch.Tensor], eps: float, ksize: int, with_bias: bool = False):
+    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))) + b: ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128].
+    ``stats_in=None``: x already is the activation SiLU(GroupNorm(.)) (``stem_act(..., pad=0)``).  ``with_bias``: also returns
+    the bias gradient [128] (sum of dy over pixels, accumulated by the same kernel)."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape
     if Cc != 128 or tuple(dy.shape) != (B, H, W, Cc) or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.stride(3) != 1 or x.stride(3) != 1:
         raise ValueError("stem_wgrad: bf16 [B,H,W,128] tensors with channels contiguous")
-    dw = torch.zeros((ksize, ksize, Cc, Cc), dtype=torch.float32, device=x.device)     # taps outermost: coalesced atomics
+    buf = torch.zeros((ksize * ksize * Cc * Cc + Cc,), dtype=torch.float32, device=x.device)   # one memset for both
+    dw = buf[: ksize * ksize * Cc * Cc].view(ksize, ksize, Cc, Cc)                       # taps outermost: coalesced atomics
+    db = buf[ksize * ksize * Cc * Cc:]
     a = _lib.StemWgradArgs()
     a.dy, a.x, a.dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
+    a.db = db.data_ptr() if with_bias else None
     if stats_in is not None:
         a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
     else:
@@ -219,7 +223,29 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tenso
     with torch.cuda.device(x.device), _Timed("stem_wgrad%d" % ksize):
         rc = lib.naf_stem_wgrad(C.byref(a), _stream(x))
     _lib.check(rc, "naf_stem_wgrad")
-    return dw.permute(2, 3, 0, 1)
+    return (dw.permute(2, 3, 0, 1), db) if with_bias else dw.permute(2, 3, 0, 1)
+
+
+def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dW [128, 3, k, k], db [128]) of the first convolution (``naf_stem_conv0_wgrad``): dy bf16 [B,H,W,128], image [B,3,H,W]."""
+    lib = _lib.load()
+    _gpu(dy, "dy")
+    B, H, W, Cc = dy.shape
+    if Cc != 128 or dy.dtype != torch.bfloat16 or dy.stride(3) != 1 or tuple(image.shape) != (B, 3, H, W):
+        raise ValueError(f"stem_conv0_wgrad: dy {tuple(dy.shape)} / image {tuple(image.shape)}")
+    if image.dtype not in _DT:
+        image = image.float()
+    nt = 3 * ksize * ksize
+    buf = torch.zeros(((nt + 1) * Cc,), dtype=torch.float32, device=dy.device)
+    a = _lib.StemConv0WgradArgs()
+    a.dy, a.image, a.dw, a.db = dy.data_ptr(), image.data_ptr(), buf.data_ptr(), buf[nt * Cc:].data_ptr()
+    a.image_dtype, a.ksize, a.B, a.H, a.W = _DT[image.dtype], int(ksize), B, H, W
+    a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
+    a.image_stride = _strides4(image, (0, 1, 2, 3))
+    with torch.cuda.device(dy.device), _Timed("stem_conv0_wgrad"):
+        rc = lib.naf_stem_conv0_wgrad(C.byref(a), _stream(dy))
+    _lib.check(rc, "naf_stem_conv0_wgrad")
+    return buf[: nt * Cc].view(3, ksize, ksize, Cc).permute(3, 0, 1, 2), buf[nt * Cc:]
 
 
 def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,

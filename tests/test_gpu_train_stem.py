@@ -98,7 +98,8 @@ def test_weight_gradient(dev, k, B, H, W):
     x = (torch.randn(B, H, W, 128, generator=g) * 1.3 + 0.2).to(dev).to(torch.bfloat16)
     dy = torch.randn(B, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
     gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
-    dw = ops.stem_wgrad(dy, x, group_stats(x), gw, gb, 1e-5, k)
+    dw, db = ops.stem_wgrad(dy, x, group_stats(x), gw, gb, 1e-5, k, with_bias=True)
+    assert rel(db, dy.float().sum((0, 1, 2))) < 1e-4
     a = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 8, gw, gb, 1e-5)).to(torch.bfloat16).float()   # the kernel's bf16 operand
     if k == 3:
         a = F.pad(a, (1, 1, 1, 1), mode="reflect")
@@ -111,6 +112,22 @@ def test_weight_gradient(dev, k, B, H, W):
     assert rel(dw2, w.grad) < 3e-3
     for t in range(k * k):       # every tap on its own: a wrong pixel shift of one tap must not hide in the norm of the others
         assert rel(dw[:, :, t // k, t % k], w.grad[:, :, t // k, t % k]) < 5e-3, t
+
+
+@pytest.mark.parametrize("k,B,H,W", [(3, 2, 12, 20), (1, 1, 9, 33), (3, 1, 2, 2)])
+def test_first_convolution_weight_gradient(dev, k, B, H, W):
+    from naf_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(41 + H)
+    image = torch.randn(B, 3, H, W, generator=g).to(dev)
+    dy = torch.randn(B, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
+    dw, db = ops.stem_conv0_wgrad(dy, image, k)
+    w = torch.zeros(128, 3, k, k, device=dev, requires_grad=True)
+    bb = torch.zeros(128, device=dev, requires_grad=True)
+    xin = F.pad(image, (1, 1, 1, 1), mode="reflect") if k == 3 else image
+    F.conv2d(xin, w, bb).backward(dy.float().permute(0, 3, 1, 2))
+    assert dw.shape == w.grad.shape and rel(dw, w.grad) < 1e-4 and rel(db, bb.grad) < 1e-4
+    dwb, dbb = ops.stem_conv0_wgrad(dy, image.to(torch.bfloat16), k)            # bf16 image
+    assert rel(dwb, w.grad) < 1e-2
 
 
 def test_strided_views(dev):
