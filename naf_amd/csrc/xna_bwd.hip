@@ -2,17 +2,18 @@
 #include "xna_bwd_kernel.h"
 
 #define NAF_DECL(K) int naf_xna_bwd_launch_k##K(const XnaBwdParams& p, int Dv, hipStream_t s);
-NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9)
+NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13)
 #undef NAF_DECL
 
 static bool bwd_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-// 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..9, Dq = 64, integer
-// ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0) and Dv in {32, 64, 96, 128, 192, 256}.
+// 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..13, Dq = 64, integer
+// ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0), Dv in {32, 64, 96, 128, 192, 256} and K/V windows + round buffers
+// within 160 KB of LDS (all Dv up to k = 11; k = 13: Dv <= 128).
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->ky != a->kx) return 0;
     const int ks = a->ky;
-    if (ks < 3 || ks > 9 || (ks & 1) == 0) return 0;
+    if (ks < 3 || ks > 13 || (ks & 1) == 0) return 0;   // 15: hipcc 7.2 crashes in 'AMDGPU Rewrite AGPR-Copy-MFMA' on that instantiation
     if (a->Dq != 64) return 0;
     if (a->h < ks || a->w < ks) return 0;
     if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
@@ -21,6 +22,7 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
         case 32: case 64: case 96: case 128: case 192: case 256: break;
         default: return 0;
     }
+    if (xna_bwd_lds_for(ks, a->Dv) > 160 * 1024) return 0;   // k = 13 with Dv > 128: windows exceed the LDS
     if (!bwd_aligned(a->q) || !bwd_aligned(a->k_lr) || !bwd_aligned(a->v_lr) || !bwd_aligned(a->dout) || !bwd_aligned(a->dq)) return 0;
     for (int i = 0; i < 4; ++i)
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->dout_stride[i] % 8 || a->dq_stride[i] % 8) return 0;
@@ -30,7 +32,7 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     if (!naf_xna_bwd_eligible(a)) {
         naf_set_error(
-            "naf_xna_bwd: needs square odd kernel 3..9, Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
+            "naf_xna_bwd: needs square odd kernel 3..13 (windows within the LDS), Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
             "Dv in {32,64,96,128,192,256} and 16-byte aligned tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
             a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;
@@ -62,6 +64,8 @@ int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
         case 5: return naf_xna_bwd_launch_k5(p, a->Dv, s);
         case 7: return naf_xna_bwd_launch_k7(p, a->Dv, s);
         case 9: return naf_xna_bwd_launch_k9(p, a->Dv, s);
+        case 11: return naf_xna_bwd_launch_k11(p, a->Dv, s);
+        case 13: return naf_xna_bwd_launch_k13(p, a->Dv, s);
     }
     return NAF_ERR_UNSUPPORTED;
 }

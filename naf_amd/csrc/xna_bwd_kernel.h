@@ -58,8 +58,10 @@ struct XnaBwdGeom {
     }
 };
 
+// Windows of 11 x 11 and more are compiled for one wave per SIMD: their k^2 x (64 + Dv) accumulators need more than 256
+// registers per lane (and at the larger Dv their K/V tiles leave room for one workgroup per CU anyway).
 template <int KS, int DV>
-__global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
+__global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const XnaBwdParams p) {
     using G = XnaBwdGeom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32;   // 32-channel k-steps of the dP contraction
@@ -370,17 +372,27 @@ __global__ __launch_bounds__(256, 2) void xna_bwd_kernel(const XnaBwdParams p) {
 template <int KS, int DV>
 static int xna_bwd_launch_one(const XnaBwdParams& p, hipStream_t s) {
     constexpr size_t lds = XnaBwdGeom<KS, DV>::lds_bytes();
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_bwd_kernel<KS, DV>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
-            return NAF_ERR_LAUNCH;
+    if constexpr (lds > 160 * 1024) {   // the windows of (KS, DV) do not fit the LDS: eligibility excludes it (table-driven kernel)
+        naf_set_error("naf_xna_bwd: window %d with Dv = %d needs %zu bytes of LDS", KS, DV, lds);
+        return NAF_ERR_UNSUPPORTED;
+    } else {
+        auto kern = xna_bwd_kernel<KS, DV>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+                return NAF_ERR_LAUNCH;
+            }
         }
+        hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, s, p);
+        return naf_check_launch("xna_bwd_kernel");
     }
-    hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(256), lds, s, p);
-    return naf_check_launch("xna_bwd_kernel");
+}
+
+// LDS the cell kernel needs for (window, Dv): the same formula as XnaBwdGeom::lds_bytes (eligibility, host side)
+inline size_t xna_bwd_lds_for(int ks, int dv) {
+    const size_t nslot = (size_t)ks * ks, mt = ((nslot + 31) / 32) * 2;
+    return nslot * (72 + dv + 8) * 2 + 2 * 4 * mt * 64 * 8 + (size_t)4 * 16 * (72 + dv + 8) * 2;
 }
 
 template <int KS>

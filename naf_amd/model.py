@@ -640,7 +640,7 @@ class NAF(nn.Module):
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
         differentiate them (the fused inference stem has no backward).  In ``.train()`` mode the RoPE coordinates get the
         reference's random rescale (rope.py:107-124, NAF's rope_rescale); in ``.eval()`` mode they are deterministic.  Needs the shapes
-        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 9).
+        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 13 with K/V windows inside the LDS).
         ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
         mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32.  ``amp="hip"`` is the same
         precision class on this library's own stem: ``_HipStem`` (fused forward kernels, bf16 activations kept per layer, HIP

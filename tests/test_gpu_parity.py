@@ -703,6 +703,8 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (2, 128, (5, 6), (40, 96), 3),         # Dv = 32, d = (8, 16): 8 tiles per cell, non-square grid
     (1, 768, (7, 7), (7, 112), 7),         # Dv = 192, dy = 1: one tile per cell (three dead waves per round), k = h = w
     (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
+    (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): one workgroup per CU
+    (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow)
 ])
 def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
     """naf_xna_bwd vs autograd through the oracle's forward, same bf16-rounded q, k, v and output gradient."""
