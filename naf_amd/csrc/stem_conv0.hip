@@ -256,7 +256,8 @@ __device__ __forceinline__ constexpr int split_xpart(int t) { return t == 0 ? 1 
 __device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 1 : t == 1 ? 0 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0; }
 }  // namespace
 
-template <typename T>
+// T0 = first term used: 0 -> all six (fp32-exact products), 3 -> the three largest (products carried to 16 mantissa bits).
+template <typename T, int T0>
 __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const StemConv0Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem0);                       // [12][128][16]
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = T0; t < 6; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -533,7 +534,9 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
             hipLaunchKernelGGL(kern, g8, blk8, lds, s, p);
             return naf_check_launch("stem_conv0_split_kernel");
         };
-        return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t>) : launch(stem_conv0_split_kernel<float>);
+        static const bool three = [] { const char* e = naf_knob("NAF_CONV0_TERMS"); return e && atoi(e) == 3; }();   // A/B knob
+        if (three) return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 3>) : launch(stem_conv0_split_kernel<float, 3>);
+        return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 0>) : launch(stem_conv0_split_kernel<float, 0>);
     }
     if (a->ksize == 3) {
         if (a->image_dtype == NAF_BF16) hipLaunchKernelGGL((stem_conv0_kernel<3, bf16_t>), g, blk, 0, s, p);

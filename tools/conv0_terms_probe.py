@@ -1,0 +1,17 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from naf_amd import ops
+dev = torch.device("cuda:0")
+img = torch.randn(1, 3, 1024, 1024, device=dev)
+w = torch.randn(128, 3, 3, 3, device=dev) * 0.2
+b = torch.randn(128, device=dev)
+y = torch.empty(1, 1024, 1024, 128, dtype=torch.bfloat16, device=dev)
+st = torch.zeros(1, 8, 2, dtype=torch.float64, device=dev)
+for _ in range(3): ops.stem_conv0(img, w, b, y, st)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(50): ops.stem_conv0(img, w, b, y, st)
+e1.record(); torch.cuda.synchronize()
+ref = torch.nn.functional.conv2d(torch.nn.functional.pad(img.double(), (1,1,1,1), mode="reflect"), w.double(), b.double()).permute(0,2,3,1)
+err = (y.double() - ref).abs()
+print(os.environ.get("NAF_CONV0_TERMS", "6"), "terms: %.4f ms" % (e0.elapsed_time(e1) / 50), "max err vs fp64 / bf16 ulp: %.3f" % float((err / (ref.abs() * 2**-8 + 1e-6)).max()), "mismatch vs bf16(ref): %.5f" % float((y != ref.to(torch.bfloat16)).float().mean()))
