@@ -201,6 +201,13 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             }
         }
 
+        // The fragments are dead from here on (their row-major copies are in LDS): the next round's are requested NOW and travel
+        // during the softmax, dQ, the P / dS hand-over and phase 2.  Behind the barrier (round 1) they only had phase 2 -- ~600
+        // cycles of MFMAs against an HBM round trip of 2 000+ -- and every round opened with the wave parked on vmcnt.
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(t0 + 4 + wave, qf, gf);
+        __builtin_amdgcn_sched_barrier(0);
+
         // ---- lane = query: softmax statistics, delta, dS^T ----
         float m = -INFINITY;
 #pragma unroll
@@ -307,9 +314,6 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             }
         }
         __syncthreads();
-        // next round's fragments travel during phase 2 (the phase-1 registers are dead by now)
-        load_tile(t0 + 4 + wave, qf, gf);
-        __builtin_amdgcn_sched_barrier(0);
 
         // ================= phase 2: this wave's channel slice over the round's four tiles =================
 #pragma unroll
