@@ -39,7 +39,16 @@ struct XnaBwdParams {
     uint32_t nblocks;
     float scale, scale_log2e;
     int64_t qs[4], ks[4], vs[4], gs[4], dqs[4];  // {b, head, y, x} element strides (gs: dout)
+#ifdef NAF_BWD_TIMING
+    unsigned long long* tim;   // tools/xna_bwd_probe.hip: [workgroup][wave][8] s_memtime sums per phase
+#endif
 };
+
+#ifdef NAF_BWD_TIMING
+#define BWD_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define BWD_T(i) do { } while (0)
+#endif
 
 template <int KS, int DV>
 struct XnaBwdGeom {
@@ -78,6 +87,9 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, grp = lane >> 4;
+#ifdef NAF_BWD_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     // dispatch order in groups of 16 (xna_block_order in xna_mfma_kernel.h: all XCDs sweep the same cell rows)
     uint32_t L = blockIdx.x;
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
         }
     }
     __syncthreads();
+    BWD_T(0);   // window staging
 
     // row tiles of the cell: tile t -> row ty = t / tpr, first column tx0 = (t % tpr) * 16   (dx % 16 == 0)
     const int tpr = p.dx >> 4, ntile = p.dy * tpr;
@@ -161,10 +174,20 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
 #pragma unroll
         for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + ks * 32);
     };
-    bf16x8_t qf[2], gf[DKS];
-    load_tile(wave, qf, gf);
+    // One fragment set, re-requested for the next round as soon as the S / dP MFMAs have consumed it.  A second set (requests two
+    // rounds ahead, NSET = 2) was measured and is NOT faster (G1 1.02 -> 1.04 ms, k = 9 0.876 -> 0.925: gpurun r6g): the 42-46 % of
+    // a wave's life spent in the first phase of a round (tools/xna_bwd_probe.hip, profiles/r02_xna_bwd_phase.txt) is not the
+    // fragments' latency but the phase itself -- 32 ds_read_b128 of K / V rows per wave against 64 dependent MFMAs, eight waves
+    // per CU on one LDS.
+    constexpr int NSET = 1;
+    bf16x8_t qfs[NSET][2], gfs[NSET][DKS];
+    load_tile(wave, qfs[0], gfs[0]);
+    if constexpr (NSET == 2) load_tile(4 + wave, qfs[1], gfs[1]);
 
-    for (int t0 = 0; t0 < ntile; t0 += 4) {
+    auto round = [&](int t0, auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value % NSET;
+        bf16x8_t (&qf)[2] = qfs[SET];
+        bf16x8_t (&gf)[DKS] = gfs[SET];
         // ================= phase 1: this wave's tile =================
         const int t = t0 + wave;
         const bool live = t < ntile;
@@ -201,13 +224,14 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             }
         }
 
-        // The fragments are dead from here on (their row-major copies are in LDS): the next round's are requested NOW and travel
-        // during the softmax, dQ, the P / dS hand-over and phase 2.  Behind the barrier (round 1) they only had phase 2 -- ~600
-        // cycles of MFMAs against an HBM round trip of 2 000+ -- and every round opened with the wave parked on vmcnt.
+        // The fragments are dead from here on (their row-major copies are in LDS): this set is re-requested NOW for the round
+        // after next.  (Round 1 requested the next round's behind the barrier: ~600 cycles of phase-2 MFMAs against a loaded HBM
+        // round trip of ~9 000, every round opened with the wave parked on vmcnt.)
         __builtin_amdgcn_sched_barrier(0);
-        load_tile(t0 + 4 + wave, qf, gf);
+        load_tile(t0 + 4 * NSET + wave, qf, gf);
         __builtin_amdgcn_sched_barrier(0);
 
+        BWD_T(1);   // fragments' arrival + LDS copies + S / dP MFMAs
         // ---- lane = query: softmax statistics, delta, dS^T ----
         float m = -INFINITY;
 #pragma unroll
@@ -252,6 +276,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 dsf[ks][j] = (bf16_t)(p.scale * sT[mt][r] * (gT[mt][r] - delta));
             }
 
+        BWD_T(2);   // softmax, delta, dS^T
         // ---- dQ^T[d][q] = K^T . dS^T : lane (q, grp) gets 4 consecutive d per 16-d tile; pairs -> 16-byte stores ----
         if (live) {
             bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
@@ -289,6 +314,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             }
         }
 
+        BWD_T(3);   // dQ
         // ---- lane = key: P and dS in A-operand form for the contractions over queries ----
         {
             // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout
@@ -313,7 +339,9 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 Sl[(wave * MT + mt) * 64 + lane] = sk;
             }
         }
+        BWD_T(4);   // P / dS (key-major) -> LDS
         __syncthreads();
+        BWD_T(5);   // barrier 1
 
         // ================= phase 2: this wave's channel slice over the round's four tiles =================
 #pragma unroll
@@ -347,8 +375,18 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                     if (wave + 4 * i < NVT) accV[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, bg[i], accV[mt][i], 0, 0, 0);
             }
         }
+        BWD_T(6);   // phase 2
         __syncthreads();   // the round's LDS buffers are free again
+        BWD_T(7);   // barrier 2
+    };
+    for (int t0 = 0; t0 < ntile; t0 += 8) {
+        round(t0, std::integral_constant<int, 0>{});
+        if (t0 + 4 < ntile) round(t0 + 4, std::integral_constant<int, 1>{});
     }
+#ifdef NAF_BWD_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) p.tim[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
+#endif
 
     // ---- the cell's partial sums -> fp32 accumulators.  acc[mt][r] is key mt*16 + grp*4 + r, column col ----
     float* dkb = p.dk + (((int64_t)b * p.h) * p.w * p.heads + head) * 64;
