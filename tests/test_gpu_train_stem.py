@@ -235,3 +235,25 @@ def test_autocast_training_call_uses_the_hip_stem(dev, monkeypatch):
     assert calls["n"] == 3 * 8                       # eight 128 -> 128 layers, one data-gradient launch each
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert out.shape == (1, 32, 64, 64) and all(l == l for l in losses) and losses[-1] != losses[0]   # parameters moved
+
+
+@pytest.mark.parametrize("img_hw,out_hw,lr_hw", [((64, 96), (64, 96), (4, 6)), ((128, 128), (64, 64), (4, 4))])
+def test_hip_training_path_other_geometries(dev, img_hw, out_hw, lr_hw):
+    """Non-square images, and an image larger than the output (the guidance is pooled between stem and RoPE, naf.py:34):
+    forward_train(amp='hip') against the fp32 torch stem, outputs and encoder gradients."""
+    from naf_amd import NAF
+    torch.manual_seed(5)
+    model = NAF(kernel_size=3).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(13)
+    image = torch.randn(1, 3, *img_hw, generator=g).to(dev)
+    feats = torch.randn(1, 32, *lr_hw, generator=g).to(dev)
+    wout = torch.randn(1, 32, *out_hw, generator=g).to(dev)
+    res = {}
+    for mode in (False, "hip"):
+        model.zero_grad(set_to_none=True)
+        out = model.forward_train(image, feats, out_hw, amp=mode)
+        (out.float() * wout).sum().backward()
+        res[mode] = (out.detach().float(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert rel(res["hip"][0], res[False][0]) < 2e-2
+    worst = max((rel(res["hip"][1][n], res[False][1][n]), n) for n in res[False][1])
+    assert worst[0] < 6e-2, worst
