@@ -96,8 +96,9 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
         sp.m = p;
         const int dvt_u = [&] {   // Dv tile of the unstaged plan: the largest divisor of Dv whose window fits the LDS
             static const int cand[] = {256, 192, 128, 96, 64, 48, 32, 16};
+            static const int cap = [] { const char* e = naf_knob("NAF_XNA_SLIDE_DVT"); return e ? atoi(e) : 1 << 30; }();   // A/B knob
             for (int c : cand)
-                if (a->Dv % c == 0 && xna_mfma_lds_for(a->ky, 1, c, false) <= 160 * 1024) return c;
+                if (c <= cap && a->Dv % c == 0 && xna_mfma_lds_for(a->ky, 1, c, false) <= 160 * 1024) return c;
             return 0;
         }();
         sp.m.nchunk = a->Dv / dvt_u;
