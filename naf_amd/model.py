@@ -222,12 +222,20 @@ class _HipStem(torch.autograd.Function):
                 ops.stem_conv(ys[li], stats[br, li], norm.weight.detach().float(), norm.bias.detach().float(), norm.eps,
                               enc._packed(conv), conv.bias.detach().float(), dst, None if last else stats[br, li + 1])
             saved.append(ys)
-        ctx.enc, ctx.image, ctx.saved, ctx.stats, ctx.nparams = enc, image, saved, stats, len(params)
+        # saved through autograd's own slots (version-counter checks, freed with the graph); the module is only consulted for its
+        # layer structure and current parameter values
+        ctx.save_for_backward(image, stats, *[y for ys in saved for y in ys])
+        ctx.enc, ctx.nsaved, ctx.nparams = enc, [len(ys) for ys in saved], len(params)
         return cat.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g):
-        enc, image, stats = ctx.enc, ctx.image, ctx.stats
+        enc = ctx.enc
+        image, stats, *flat = ctx.saved_tensors
+        saved, pos = [], 0
+        for n in ctx.nsaved:
+            saved.append(flat[pos:pos + n])
+            pos += n
         B, _, H, W = image.shape
         dev = g.device
         hid = 128
@@ -236,7 +244,7 @@ class _HipStem(torch.autograd.Function):
         dimage = None
         need_img = ctx.needs_input_grad[1]
         for br, seq in enumerate((enc.encoder, enc.sem_encoder)):
-            ys = ctx.saved[br]
+            ys = saved[br]
             layers = _stem_layers(seq)
             k = layers[0][1].kernel_size[0] if layers else 1
             # 3x3 branch: a layer's output gradient lives in the interior of a buffer with a 2-pixel ZERO border (what the
