@@ -50,6 +50,38 @@ def test_struct_layout_matches_header(built_lib):
     assert f == C.sizeof(_lib.XnaBwdArgs) and g == C.sizeof(_lib.ForwardArgs)
 
 
+def test_training_struct_layouts_match_header(built_lib):
+    """Size AND the offset of the last field of every training-side argument struct (round 2) against gcc's view of the header."""
+    import subprocess, tempfile
+    from naf_amd import _lib
+    pairs = [("naf_stem_act_args", _lib.StemActArgs, "a_stride"), ("naf_stem_act_bwd_args", _lib.StemActBwdArgs, "dx_stride"),
+             ("naf_stem_wgrad_args", _lib.StemWgradArgs, "x_stride"), ("naf_stem_conv0_wgrad_args", _lib.StemConv0WgradArgs, "image_stride"),
+             ("naf_rope_pool_bwd_args", _lib.RopePoolBwdArgs, "dx_stride")]
+    body = "".join(f'printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {last}));' for c, _, last in pairs)
+    src = '#include "naf_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){' + body + 'return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        rows = [tuple(map(int, l.split())) for l in subprocess.check_output([os.path.join(d, "p")]).decode().splitlines()]
+    for (cname, ct, last), (size, off) in zip(pairs, rows):
+        assert size == C.sizeof(ct), cname
+        assert off == getattr(ct, last).offset, (cname, last)
+
+
+def test_hip_stem_parameter_order():
+    """_HipStem.backward returns its gradients in the order _hip_stem_params lists the parameters: per branch conv0 (w, b),
+    then per layer (norm.w, norm.b, conv.w, conv.b) -- all 36 encoder parameters, each once."""
+    from naf_amd.model import NAF, _hip_stem_params, _stem_layers
+    m = NAF()
+    ps = _hip_stem_params(m.image_encoder)
+    enc_params = [p for n, p in m.named_parameters() if n.startswith("image_encoder.") and p.requires_grad]
+    assert len(ps) == 36 and {id(p) for p in ps} == {id(p) for p in enc_params}
+    assert ps[0] is m.image_encoder.encoder[0].weight and ps[1] is m.image_encoder.encoder[0].bias
+    n0, c0 = _stem_layers(m.image_encoder.encoder)[0]
+    assert ps[2] is n0.weight and ps[3] is n0.bias and ps[4] is c0.weight and ps[5] is c0.bias
+    assert ps[18] is m.image_encoder.sem_encoder[0].weight
+
+
 @pytest.mark.parametrize("L_in", [1, 2, 3, 5, 7, 14, 28, 32, 64])
 def test_axis_index_table_matches_oracle(built_lib, L_in):
     from naf_amd import ops
