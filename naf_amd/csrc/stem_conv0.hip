@@ -257,8 +257,18 @@ __device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 1 
 }  // namespace
 
 // T0 = first term used: 0 -> all six (fp32-exact products), 3 -> the three largest (products carried to 16 mantissa bits).
+#ifdef NAF_CONV0_TIMING   // tools/conv0_probe.hip: s_memtime sums per wave and phase
+__device__ unsigned long long g_conv0_tim[4096 * 8];
+#define C0_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define C0_T(i) do { } while (0)
+#endif
+
 template <typename T, int T0>
 __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const StemConv0Params p) {
+#ifdef NAF_CONV0_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem0);                       // [12][128][16]
     bf16_t* otile = wl + 12 * C0 * 16;                                    // [NWS][32][OPX]
@@ -333,20 +343,28 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
     float sv[16], nx[16];
     int g = blockIdx.x * NWS + wave;
     load_taps(g, sv);
+    C0_T(0);   // set-up: split weights -> LDS, first taps requested
     for (; g < p.ngroups; g += gstride) {
         bf16x8_t xb[3][2];
         split_taps(sv, xb);
+        C0_T(1);   // taps arrive + three-way split
         load_taps(g + gstride, nx);                          // next segment's taps are in flight during this one's MFMAs
         __builtin_amdgcn_sched_barrier(0);
         const int y = g / p.gpr, x0 = (g - y * p.gpr) * 32;
         const float vmask = (x0 + n32 < p.W) ? 1.0f : 0.0f;
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
+            // the accumulators START as the bias (row 4 j + i of a tile = channel 32 m + 8 j + 4 half + i): eight ds_read_b128 ahead of
+            // the MFMA chain instead of one in front of every epilogue slice, each of which waited for the LDS on the spot
             f32x16_t acc[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(&biasv[32 * (2 * mp + q) + 8 * j + 4 * half]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[q][j * 4 + i] = bj[i];
+                }
 #pragma unroll
             for (int t = T0; t < 6; ++t)
 #pragma unroll
@@ -361,9 +379,7 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = 2 * mp + q;
-                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(&biasv[32 * m + 8 * j + 4 * half]);
-                    const f32x2_t v0 = f32x2_t{acc[q][j * 4], acc[q][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
-                    const f32x2_t v1 = f32x2_t{acc[q][j * 4 + 2], acc[q][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+                    const f32x2_t v0 = f32x2_t{acc[q][j * 4], acc[q][j * 4 + 1]}, v1 = f32x2_t{acc[q][j * 4 + 2], acc[q][j * 4 + 3]};   // bias included
                     bf16x4_t o;
                     o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
                     const f32x2_t w0 = v0 * vmask, w1 = v1 * vmask;
@@ -372,6 +388,7 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
                     if (p.y != nullptr) *reinterpret_cast<bf16x4_t*>(otw + n32 * OPX + 32 * m + 8 * j + 4 * half) = o;
                 }
         }
+        C0_T(2);   // MFMAs + epilogue into the LDS tile
         if (p.y != nullptr) {
             char* yr = reinterpret_cast<char*>(yb + (int64_t)y * p.ys[1] + (int64_t)x0 * p.ys[2]);
             if (x0 + 32 <= p.W) {                            // whole segment: 8 reads, then 8 stores, no per-store predicate
@@ -392,9 +409,14 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        C0_T(3);   // tile reads + row stores issued
 #pragma unroll
         for (int q = 0; q < 16; ++q) sv[q] = nx[q];
     }
+#ifdef NAF_CONV0_TIMING
+    if (lane == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 8; ++i) g_conv0_tim[(blockIdx.x * NWS + wave) * 8 + i] = tacc[i];
+#endif
 
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {
