@@ -183,11 +183,17 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         const int n0 = g * 32;
         const float* cv = cvec;
 
+        // accumulators start as the conv bias (row 4 j + i of tile m = channel 32 m + 8 j + 4 half + i): 16 ds_read_b128 ahead of
+        // the MFMAs instead of one in front of every epilogue slice (the LDS answers in order: each of those waited on the spot)
         f32x16_t acc[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cv + 32 * m + 8 * j + 4 * half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[m][j * 4 + i] = bj[i];
+            }
         if constexpr (IMG) {
             // conv0 (exact fp32) -> + bias -> bf16 (= the activation conv0 would have stored) -> GroupNorm affine + SiLU
             // -> the wave's LDS tile as [px][ch]; lane (px = n32, half) owns channels 32 m + 8 j + 4 half + i
@@ -279,9 +285,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4_t bj = *reinterpret_cast<const f32x4_t*>(cv + 32 * m + 8 * j + 4 * half);
-                    const f32x2_t v0 = f32x2_t{acc[m][j * 4], acc[m][j * 4 + 1]} + f32x2_t{bj[0], bj[1]};
-                    const f32x2_t v1 = f32x2_t{acc[m][j * 4 + 2], acc[m][j * 4 + 3]} + f32x2_t{bj[2], bj[3]};
+                    const f32x2_t v0 = f32x2_t{acc[m][j * 4], acc[m][j * 4 + 1]}, v1 = f32x2_t{acc[m][j * 4 + 2], acc[m][j * 4 + 3]};   // bias included
                     bf16x4_t o;
                     o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
                     const f32x2_t w0 = FULL ? v0 : v0 * vmask, w1 = FULL ? v1 : v1 * vmask;
