@@ -4,7 +4,10 @@
 #include <type_traits>
 
 #ifndef NAF_STEM_CARRY
-#define NAF_STEM_CARRY 1   // B-fragment sets of the next step requested before the barrier (must match tools/gen_stem_sched.py)
+#define NAF_STEM_CARRY 1   // B-fragment sets of the next step requested before the barrier (the generated schedule asserts it)
+#endif
+#ifndef NAF_STEM_SCHED_INC
+#define NAF_STEM_SCHED_INC "stem_conv_sched3.inc"   // tools/gen_stem_sched.py; tools/stem_probe.hip compares schedules
 #endif
 #ifndef NAF_STEM_SLOT_PINS
 #define NAF_STEM_SLOT_PINS 1
@@ -237,12 +240,18 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
     // B fragments: a rolling window of two sets (8 fragments); a step is entered with its sets 0, 1 already requested (by
     // the tail of the step before, or here for step 0)
     bf16x8_t bb[2][KH] = {};
-    if (!(ABL & 4)) {
-#pragma unroll
-        for (int f = 0; f < NAF_STEM_CARRY * KH; ++f) bb[f / KH][f % KH] = *reinterpret_cast<const bf16x8_t*>(ring + lane_b + f * 16);
+    {
+        auto load_frag0 = [&](int i, int dx, int kh, int ks, bf16x8_t& dst) __attribute__((always_inline)) {
+            if (ABL & 4) return;
+            dst = *reinterpret_cast<const bf16x8_t*>(ring + i * ROWE + dx * PXE + lane_b + (kh * KH + ks) * 16);
+        };
+#define NAF_SCHED_PROLOGUE
+#include NAF_STEM_SCHED_INC
+#undef NAF_SCHED_PROLOGUE
     }
-    // Row 1's accumulator starts as the conv bias (row 4j + r of the 32x32 tile = output channel 32 wave + 8 j + 4 half + r): the
-    // schedule re-initialises it at the top of a step, straight from the LDS into the accumulator registers.  Row 0 starts at 0.
+    // Accumulator row 4j + r of the 32x32 tile = output channel 32 wave + 8 j + 4 half + r.  The schedule decides where the bias
+    // enters: an accumulator either starts from 0 (first MFMA with a zero C operand) and gets the bias in its epilogue, or is
+    // initialised with the bias straight from the LDS (acc_init) ahead of its first MFMA.
     f32x16_t acc[RS];
     auto acc_init = [&](int g, int j) __attribute__((always_inline)) {
         const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
@@ -257,11 +266,9 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
         for (int i = 0; i < NROW; ++i) slot_off[i] = ((step * RS + i) % RING) * ROWE;
 
         bf16_t* ot = otile + (step & 1) * (RS * TW * PXE);
-        f32x4_t bj[4];   // the lane's 16 bias values for row 0's epilogue, read a few slots ahead by the schedule
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        f32x4_t bj[4];   // the lane's 16 bias values for the epilogues, read a few slots ahead by the schedule
         // epilogue slice: accumulator rows 4j..4j+3 of output row g -> bias, GroupNorm sums, bf16, LDS tile
-        auto epi = [&](int g, int j) __attribute__((always_inline)) {
+        auto epi = [&](int g, int j, auto add_bias) __attribute__((always_inline)) {
             if (ABL & 2) {
                 asm volatile("" ::"v"(acc[g][j * 4]), "v"(acc[g][j * 4 + 1]), "v"(acc[g][j * 4 + 2]), "v"(acc[g][j * 4 + 3]));
                 return;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
             const int orow = sy + step * RS + g;
             const float vmask = (!EDGE || ((orow < sy_end) && (sx + n32 < p.W))) ? 1.0f : 0.0f;
             f32x2_t v0 = f32x2_t{acc[g][j * 4], acc[g][j * 4 + 1]}, v1 = f32x2_t{acc[g][j * 4 + 2], acc[g][j * 4 + 3]};
-            if (g == 0) {   // row 1's accumulator started as the bias
+            if constexpr (decltype(add_bias)::value) {   // not an accumulator that started as the bias
                 v0 += f32x2_t{bj[j][0], bj[j][1]};
                 v1 += f32x2_t{bj[j][2], bj[j][3]};
             }
@@ -284,14 +291,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
             *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
         };
 
-        // fragment ks of set sidx = (input row i, tap column dx, k half kh); sets NSETS, NSETS + 1 are sets 0, 1 of the step after
-        // this one (its input row 0 = this step's input row RS, in the ring since the step before)
-        auto load_frag = [&](int sidx, int ks, bf16x8_t& dst) __attribute__((always_inline)) {
+        // fragment ks of the set (input row i, tap column dx, k half kh) of this step, or (nxt) of the step after this one (rows
+        // the schedule asks for ahead of the barrier have been in the ring since the step before)
+        auto load_frag = [&](int nxt, int i, int dx, int kh, int ks, bf16x8_t& dst) __attribute__((always_inline)) {
             if (ABL & 4) return;
-            const int nxt = sidx >= NSETS ? 1 : 0;
-            const int sx_ = sidx - nxt * NSETS;
-            const int rt = sx_ / (8 / KH), kh = sx_ - rt * (8 / KH);
-            const int i = rt / KS, dx = rt - i * KS;
             const int row_off = nxt ? (((step + 1) * RS + i) % RING) * ROWE : slot_off[i];
             dst = *reinterpret_cast<const bf16x8_t*>(ring + row_off + dx * PXE + lane_b + (kh * KH + ks) * 16);
         };
@@ -324,15 +327,19 @@ __global__ __launch_bounds__(256, 1) void stem_conv_kernel(const StemConvParams 
     do {                                                             \
         if constexpr (!(ABL & 64) && NAF_STEM_SLOT_PINS) __builtin_amdgcn_sched_barrier(0); \
     } while (0)
-#include "stem_conv_sched3.inc"
+            using T = std::true_type;
+            using F = std::false_type;
+            long long tm1 = 0;
+#define NAF_SCHED_TAIL_MARK                                                    \
+    do {                                                                       \
+        if constexpr ((ABL & 128) != 0) tm1 = __builtin_readcyclecounter();    \
+    } while (0)
+#include NAF_STEM_SCHED_INC
+#undef NAF_SCHED_TAIL_MARK
 #undef NAF_SLOT_PIN
 #undef NAF_PIN1
 #undef NAF_PIN2
 #undef NAF_PIN4
-            long long tm1 = 0;
-            if constexpr ((ABL & 128) != 0) tm1 = __builtin_readcyclecounter();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) epi(1, j);
             if constexpr ((ABL & 128) != 0) {
                 const long long tm2 = __builtin_readcyclecounter();
                 __syncthreads();

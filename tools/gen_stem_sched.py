@@ -9,33 +9,63 @@ independent instructions per slot, never a dependent chain.  hipcc does not do t
 the side work in clumps and sinks unanchored arithmetic to its use), so the slot assignment is spelled
 out here and every micro-op is anchored (asm volatile "+v") behind the MFMA of its slot.
 
-    python tools/gen_stem_sched.py            # rewrites the .inc (committed; the build does not run this)
+    python tools/gen_stem_sched.py [out.inc]  # rewrites the .inc (committed; the build does not run this)
 
 Geometry (must match StemGeom<3>): RS = 2 output rows, KH = 4 k-steps per B-fragment set, 24 sets =
 (4 input rows x 3 tap columns x 2 k-halves); input rows 1, 2 feed both output rows (8 MFMAs / set), rows
 0 and 3 feed one (4 MFMAs / set): 144 MFMA slots per step.
+
+MFMA order (NAF_STEM_ORDER):
+  rows  input rows 0, 1, 2, 3 in turn (default).  Rows 0 and 3 feed ONE output row each: 2 x 24 MFMAs that write the
+        accumulator the MFMA before them wrote, with a fragment read / side work between them.
+  pair  (round 3 experiment, rejected) no MFMA ever follows one on its own accumulator: row 1, then rows 0 and 3
+        interleaved fragment by fragment, then row 2; both epilogues behind the last MFMA.  The hypothesis -- a dependent
+        MFMA behind side work loses accumulator forwarding -- is false on gfx950: tools/mfma_chain_probe.hip measures
+        32.3-32.7 cycles per MFMA for 1, 2 or 3 rotating accumulators with 0-6 fillers between them
+        (profiles/r03_mfma_chain_probe.txt); the MFMA-only core of the step takes the same time in both orders, and the
+        16 bias registers that stay live to the end push the step body into scratch (0.30 -> 0.44 ms).
 """
 import os
+import sys
 
 KS, RS, KH, NROW = 3, 2, 4, 4
 NLD, NST = 5, 4
 TW, PXR = 32, 40
 NSETS = NROW * KS * (8 // KH)
+ORDER = os.environ.get("NAF_STEM_ORDER", "rows")
 
-# ---- slots --------------------------------------------------------------------------------------
-slots = []          # (sidx, ks, g, dy, dx, kh, first_of_set)
-for sidx in range(NSETS):
-    rt, kh = divmod(sidx, 8 // KH)
-    i, dx = divmod(rt, KS)
-    first = True
+# ---- sets (fragment groups) in issue order, and the MFMA slots ------------------------------------
+# seq[p] = (input row i, tap column dx, k half kh); slot = (p, ks, g, dy, dx, kh)
+if ORDER == "rows":
+    seq = [(i, dx, kh) for i in range(NROW) for dx in range(KS) for kh in range(8 // KH)]
+    blocks = [[p] for p in range(NSETS)]                      # every set alone
+else:
+    r1 = [(1, dx, kh) for dx in range(KS) for kh in range(8 // KH)]
+    r2 = [(2, dx, kh) for dx in range(KS) for kh in range(8 // KH)]
+    pq = []
+    for dx in range(KS):
+        for kh in range(8 // KH):
+            pq += [(0, dx, kh), (3, dx, kh)]
+    seq = r1 + pq + r2
+    blocks = [[p] for p in range(6)] + [[6 + 2 * q, 7 + 2 * q] for q in range(6)] + [[p] for p in range(18, 24)]
+assert len(seq) == NSETS and sorted(seq) == sorted((i, dx, kh) for i in range(NROW) for dx in range(KS) for kh in range(2))
+
+slots = []          # (p, ks, g, dy, dx, kh)
+set_first_slot = {}
+for blk in blocks:
     for ks in range(KH):
-        for g in range(RS):
-            dy = i - g
-            if 0 <= dy < KS:
-                slots.append((sidx, ks, g, dy, dx, kh, first))
-                first = False
+        for p in blk:
+            i, dx, kh = seq[p]
+            for g in range(RS):
+                dy = i - g
+                if 0 <= dy < KS:
+                    set_first_slot.setdefault(p, len(slots))
+                    slots.append((p, ks, g, dy, dx, kh))
 NSLOT = len(slots)
 assert NSLOT == 144
+for a, b in zip(slots, slots[1:]):
+    if ORDER != "rows":
+        assert a[2] != b[2], "two MFMAs in a row on one accumulator"
 ops = [[] for _ in range(NSLOT)]
 
 # ---- micro-ops ------------------------------------------------------------------------------------
@@ -86,11 +116,13 @@ last_commit = COMMIT_BASE + COMMIT_STRIDE * (NLD - 1) + len(PIECE_PLAN) - 1
 FIRST_BASE = max(60, last_commit + 1)      # ld[n] was consumed by A-stages before this slot
 assert FIRST_BASE > last_commit_read
 # The LDS answers in order, so a wait for ONE value is a wait for every read issued before it.  A row store's tile read
-# therefore goes BEFORE the B-fragment reads of a set (first slot of a set, ahead of load_set): its wait is then lgkmcnt(4),
-# not lgkmcnt(0) -- waiting for the freshly issued fragment set idles the MFMA pipe ~100+ cycles per store.
-pre = [[] for _ in range(NSLOT)]            # micro-ops emitted before load_set at the first slot of a set
-set_starts = [k for k, sl in enumerate(slots) if sl[6]]
-st_slots = [k for k in set_starts if k >= FIRST_BASE][:NST]
+# therefore goes BEFORE the B-fragment read of its slot: its wait then leaves the fragment reads in flight.
+pre = [[] for _ in range(NSLOT)]            # micro-ops emitted before the MFMA of a slot
+if ORDER == "rows":
+    cand = sorted(set_first_slot.values())
+else:
+    cand = list(range(0, NSLOT, 4))
+st_slots = [k for k in cand if k >= FIRST_BASE][:NST]
 assert len(st_slots) == NST and st_slots[-1] + 2 < 112
 for n, k in enumerate(st_slots):
     pre[k].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds[{n}]);"))
@@ -102,51 +134,84 @@ for n, k in enumerate(ld_slots):
     base = f"next_row{r_lo}" if r_lo == r_hi else f"(pl + {16 * n} >= {PXR} ? next_row1 : next_row0)"
     ops[k].append(("load", f"ld[{n}] = *reinterpret_cast<const u32x4_t*>({base} + col_off[{n}]);"))
 
-# epilogue of output row 0: its accumulator is final once input row 2 is done (slot 119).
-# An epilogue that reads its bias from the LDS on the spot waits for every LDS read issued before it (the LDS answers in order):
-# ~100+ idle MFMA cycles, 8 x a step.  Row 0: the lane's 16 bias values are requested a few slots ahead (the GroupNorm temporaries
-# are dead by then).  Row 1, whose epilogue is the exposed tail of the step: the accumulator STARTS as the bias (four ds_read_b128
-# straight into its 16 registers at the top of the step, before its first MFMA at slot 25), so its epilogue adds nothing.
-first_row3 = next(k for k, s in enumerate(slots) if s[0] >= 18)
-assert first_row3 == 120
-first_g1 = next(k for k, s in enumerate(slots) if s[2] == 1)
-assert first_g1 == 25
-for j in range(4):
-    ops[first_row3 - 10 + 2 * j].append(("epi", f"bj[{j}] = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * {j} + 4 * half);"))
-    ops[first_row3 + 2 + 5 * j].append(("epi", f"epi(0, {j});"))
-    ops[4 + 5 * j].append(("epi", f"acc_init(1, {j});"))
+# Epilogues.  An epilogue that reads its bias from the LDS on the spot waits for every LDS read issued before it (the LDS
+# answers in order): ~100+ idle MFMA cycles, 8 x a step.
+tail = []
+if ORDER == "rows":
+    # Row 0's accumulator is final once input row 2 is done (slot 119): its epilogue hides behind row 3's MFMAs, the lane's 16
+    # bias values requested a few slots ahead (the GroupNorm temporaries are dead by then).  Row 1, whose epilogue is the exposed
+    # tail of the step: the accumulator STARTS as the bias (four ds_read_b128 straight into its 16 registers at the top of the
+    # step, before its first MFMA at slot 25), so its epilogue adds nothing.
+    first_row3 = next(k for k, s in enumerate(slots) if seq[s[0]][0] == 3)
+    assert first_row3 == 120
+    first_g1 = next(k for k, s in enumerate(slots) if s[2] == 1)
+    assert first_g1 == 25
+    for j in range(4):
+        ops[first_row3 - 10 + 2 * j].append(("epi", f"bj[{j}] = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * {j} + 4 * half);"))
+        ops[first_row3 + 2 + 5 * j].append(("epi", f"epi(0, {j}, T{{}});"))
+        ops[4 + 5 * j].append(("epi", f"acc_init(1, {j});"))
+    tail = [f"epi(1, {j}, F{{}});" for j in range(4)]
+    zero_first = {0}          # output rows whose first MFMA starts from 0
+else:
+    # Both accumulators start from 0 and finish with the last two MFMAs: bias values requested a few slots before the end, both
+    # epilogues behind the last MFMA (row 0's first: its last MFMA is the older one).
+    for j in range(4):
+        ops[NSLOT - 14 + 2 * j].append(("epi", f"bj[{j}] = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * {j} + 4 * half);"))
+    tail = [f"epi({g}, {j}, T{{}});" for g in range(RS) for j in range(4)]
+    zero_first = {0, 1}
 
-# B fragments: a rolling window of 8 registers-quads.  The register of fragment (set, ks) is re-requested with fragment
-# (set + 2, ks) right behind the last MFMA that reads it, so every fragment is in flight for 7+ MFMA slots (224+ cycles).  With
-# whole sets requested at set boundaries the 4-MFMA sets (input rows 0 and 3 feed one output row) left the following set only
-# 128 cycles, less than four waves' worth of ds_read_b128 take.  Sets 24, 25 are sets 0, 1 of the NEXT step: its input row 0
-# has been in the ring for a whole step, so the step does not open with an exposed LDS round trip behind the barrier.
-last_use = [False] * NSLOT
+# B fragments: a rolling window of 8 register quads, bb[p & 1][ks] for set p.  The register of fragment (p, ks) is re-requested
+# with fragment (p + 2, ks) right behind the last MFMA that reads it, so every fragment is in flight for 7+ MFMA slots (224+
+# cycles).  Sets 24, 25 are sets 0, 1 of the NEXT step; CARRY of them are requested before the barrier (their input row must
+# have been in the ring for a whole step: row 0 in `rows` order, row 1 in `pair` order -- the next step's row 1 is this step's
+# row 3), the others at the top of the step.
+last_slot_of = {}
 for k, sl in enumerate(slots):
-    nxt = slots[k + 1] if k + 1 < NSLOT else None
-    last_use[k] = nxt is None or (nxt[0], nxt[1]) != (sl[0], sl[1])
+    last_slot_of[(sl[0], sl[1])] = k
+CARRY = int(os.environ.get('NAF_STEM_CARRY', '1' if ORDER == "rows" else '2'))   # must match NAF_STEM_CARRY of the header
+if ORDER == "rows":
+    assert CARRY <= 2 and all(seq[c][0] == 0 for c in range(CARRY))
+else:
+    assert CARRY <= 2 and all(seq[c][0] == 1 for c in range(CARRY))
 
-CARRY = int(os.environ.get('NAF_STEM_CARRY', '1'))   # sets of the next step requested before the barrier (1 | 2)
+def frag(p, ks):
+    nxt = 1 if p >= NSETS else 0
+    i, dx, kh = seq[p - nxt * NSETS]
+    return f"load_frag({nxt}, {i}, {dx}, {kh}, {ks}, bb[{p & 1}][{ks}]);"
 
 # ---- emit -------------------------------------------------------------------------------------------
 out = []
 out.append("// GENERATED by tools/gen_stem_sched.py -- do not edit.  One step of stem_conv_kernel<3>: 144 MFMA slots,")
-out.append("// side work pinned behind individual MFMAs.  Included inside step_body (stem_conv_kernel.h).")
-for k, (sidx, ks, g, dy, dx, kh, first) in enumerate(slots):
-    if first and sidx == 0:
-        for c in range(CARRY, 2):
-            for f in range(KH):
-                out.append(f"load_frag({c}, {f}, bb[{c}][{f}]);")
-    if first:
-        out.append(f"// ---- set {sidx}: input row {sidx // (KS * (8 // KH))}, tap column {dx}, k-steps {kh * KH}..{kh * KH + KH - 1}")
+out.append(f"// side work pinned behind individual MFMAs (MFMA order: {ORDER}).  Included inside stem_conv_kernel.h: once with")
+out.append("// NAF_SCHED_PROLOGUE (the fragment sets step 0 is entered with), once inside step_body.")
+out.append("#ifdef NAF_SCHED_PROLOGUE")
+out.append(f"static_assert(NAF_STEM_CARRY == {CARRY}, \"header and schedule disagree on the carried fragment sets\");")
+for c in range(CARRY):
+    for f in range(KH):
+        i, dx, kh = seq[c]
+        out.append(f"load_frag0({i}, {dx}, {kh}, {f}, bb[{c}][{f}]);")
+out.append("#else")
+for c in range(CARRY, 2):
+    for f in range(KH):
+        out.append(frag(c, f))
+started = set()
+for k, (p, ks, g, dy, dx, kh) in enumerate(slots):
+    if set_first_slot[p] == k:
+        i = seq[p][0]
+        out.append(f"// ---- set {p}: input row {i}, tap column {dx}, k-steps {kh * KH}..{kh * KH + KH - 1}")
+    if pre[k] or set_first_slot[p] == k:
         out.append("__builtin_amdgcn_sched_barrier(0);")
         for kind, code in pre[k]:
             out.append(f"if constexpr (!(ABL & 8)) {{ {code} }}")
         out.append("__builtin_amdgcn_sched_barrier(0);")
     widx = (dy * KS + dx) * 8 + kh * KH + ks
-    out.append(f"acc[{g}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[{widx}], bb[{sidx & 1}][{ks}], acc[{g}], 0, 0, 0);  // slot {k}")
-    if last_use[k] and sidx + 2 <= NSETS + CARRY - 1:
-        out.append(f"load_frag({sidx + 2}, {ks}, bb[{sidx & 1}][{ks}]);")
+    src = f"acc[{g}]"
+    if g in zero_first and g not in started:
+        src = "f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}"
+    started.add(g)
+    out.append(f"acc[{g}] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[{widx}], bb[{p & 1}][{ks}], {src}, 0, 0, 0);  // slot {k}")
+    if last_slot_of[(p, ks)] == k and p + 2 <= NSETS + CARRY - 1:
+        out.append(frag(p + 2, ks))
     for kind, code in ops[k]:
         if kind == "store":
             out.append(f"if constexpr (!(ABL & 8)) {{ {code} }}")
@@ -157,9 +222,14 @@ for k, (sidx, ks, g, dy, dx, kh, first) in enumerate(slots):
         else:
             out.append(f"if constexpr (!(ABL & 1)) {{ {code} }}")
     out.append("NAF_SLOT_PIN;")
+out.append("NAF_SCHED_TAIL_MARK;")
+out += tail
+out.append("#endif")
 
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "naf_amd", "csrc", "stem_conv_sched3.inc")
+if len(sys.argv) > 1:
+    path = sys.argv[1]
 with open(path, "w") as f:
     f.write("\n".join(out) + "\n")
 busy = sum(1 for o in ops if o)
-print(f"wrote {path}: {NSLOT} slots, {busy} carry side work, max micro-ops per slot {max(len(o) for o in ops)}")
+print(f"wrote {path}: order {ORDER}, {NSLOT} slots, {busy} carry side work, max micro-ops per slot {max(len(o) for o in ops)}")

@@ -1,0 +1,91 @@
+// Micro-benchmark: what does side work BETWEEN two v_mfma_f32_32x32x16_bf16 cost when the two MFMAs write the same
+// accumulator (a dependent chain, what input rows 0 and 3 of the 3x3 stem layer's 2-row step are) against MFMAs that
+// rotate over 2 or 3 accumulators?  One wave per SIMD (256 threads, 100 KB of LDS per workgroup), every CU busy.
+// Reports shader cycles per MFMA (s_memtime) and wall time; the ratio of the two clocks calibrates the s_memtime tick.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_chain_probe.hip -o tools/bin/mfma_chain_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+// FILL: 0 nothing, 1 one ds_read_b128, 2 one v_fma, 3 two v_fma, 4 four v_fma, 5 one ds_read_b128 + two v_fma,
+//       6 six v_fma
+template <int NACC, int FILL>
+__global__ __launch_bounds__(256, 1) void k(float* out, long long* ticks, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x16_t acc[NACC];
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    bf16x8_t A[4], B[4];
+    for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < 8; ++i) {
+            A[q][i] = (__bf16)(((threadIdx.x * 37 + i * 11 + q * 5) % 97) * 0.01f - 0.5f);
+            B[q][i] = (__bf16)(((blockIdx.x * 13 + threadIdx.x * 7 + i * 3 + q) % 89) * 0.01f - 0.4f);
+        }
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = threadIdx.x * 0.001f + i;
+    f32x4_t* lds = reinterpret_cast<f32x4_t*>(smem);
+    lds[threadIdx.x] = f32x4_t{f[0], f[1], f[2], f[3]};
+    __syncthreads();
+    f32x4_t r4[4] = {};
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    const long long w0 = (long long)__builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 144; ++m) {
+            acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m & 3], B[(m >> 1) & 3], acc[m % NACC], 0, 0, 0);
+            if (FILL == 1 || FILL == 5) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(r4[m & 3]) : "v"((threadIdx.x & 63) * 16 + (m & 3) * 1024));
+            }
+            constexpr int NF = FILL == 2 ? 1 : (FILL == 3 || FILL == 5) ? 2 : FILL == 4 ? 4 : FILL == 6 ? 6 : 0;
+#pragma unroll
+            for (int q = 0; q < NF; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[(q + m) & 7]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const long long t1 = (long long)__builtin_readcyclecounter();
+    const long long w1 = (long long)__builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+    for (int i = 0; i < 8; ++i) s += f[i];
+    for (int q = 0; q < 4; ++q) s += r4[q][0] + r4[q][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { ticks[blockIdx.x * 2] = t1 - t0; ticks[blockIdx.x * 2 + 1] = w1 - w0; }
+}
+
+template <int NACC, int FILL>
+void run(float* out, long long* ticks, int iters) {
+    auto kern = k<NACC, FILL>;
+    const size_t lds = 100 * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, 0, out, ticks, 4);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, 0, out, ticks, iters);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    long long h[512]; CK(hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost));
+    double tk = 0, rt = 0;
+    for (int i = 0; i < 256; ++i) { tk += h[2 * i]; rt += h[2 * i + 1]; }
+    tk /= 256; rt /= 256;
+    const double n = iters * 144.0;
+    printf("accs=%d fill=%d iters=%4d : %7.2f memtime ticks/MFMA  %6.2f ns/MFMA wall  (%6.1f TF)  memtime tick = %.3f ns (100 MHz realtime)  kernel %.3f ms\n",
+           NACC, FILL, iters, tk / n, ms * 1e6 / n, 256.0 * 4 * 32768.0 / (ms * 1e6 / n) / 1e3, rt * 10.0 / tk, ms);
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 64;
+    float* out; long long* ticks;
+    CK(hipMalloc(&out, 256 * 256 * 4)); CK(hipMalloc(&ticks, 512 * 8));
+    run<1, 0>(out, ticks, iters); run<1, 1>(out, ticks, iters); run<1, 2>(out, ticks, iters); run<1, 3>(out, ticks, iters);
+    run<1, 4>(out, ticks, iters); run<1, 5>(out, ticks, iters); run<1, 6>(out, ticks, iters);
+    run<2, 0>(out, ticks, iters); run<2, 1>(out, ticks, iters); run<2, 2>(out, ticks, iters); run<2, 3>(out, ticks, iters);
+    run<2, 4>(out, ticks, iters); run<2, 5>(out, ticks, iters); run<2, 6>(out, ticks, iters);
+    run<3, 0>(out, ticks, iters); run<3, 1>(out, ticks, iters); run<3, 3>(out, ticks, iters); run<3, 4>(out, ticks, iters);
+    run<3, 5>(out, ticks, iters); run<3, 6>(out, ticks, iters);
+    return 0;
+}
