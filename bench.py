@@ -143,8 +143,11 @@ def cpu_baseline(C, ksz, lr, out, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 on one GPU = ~0.5 s of device time, so that "
+                    "a utilisation sampler sees the timed region; 10 on several GPUs, where a step is the whole 64-image batch)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-phase-events", action="store_true", help="do not record the per-phase events inside naf_forward "
+                    "(A/B: what the seven extra event records cost)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: G1 on one GPU, G3 on several")
     ap.add_argument("--per-gpu-batch", type=int, default=1, help="single-GPU runs: images per step")
     ap.add_argument("--total-batch", type=int, default=64, help="multi-GPU runs: images of the whole job, sharded over the ranks")
@@ -165,6 +168,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.steps is None:
+        args.steps = 200 if world == 1 else 10
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -225,6 +230,7 @@ def main():
         feats = torch.randn(B, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
 
     timer = EventTimer()
+    timer.phases = not args.no_phase_events
     ops.KERNEL_TIMER = timer
 
     if args.attention_only:
@@ -267,10 +273,56 @@ def main():
         el = time.perf_counter() - t0
         timer.enabled = False
 
+    ranks_info = weak = None
     if world > 1:
+        my_el = el
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        # Proof that the job ran on `world` DISTINCT GPUs: every rank reports the device it computed on (UUID / PCI bus id
+        # from the driver) and its own time for the timed region; under RCCL the identities must differ.
+        prop = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": prop.name,
+                 "uuid": str(getattr(prop, "uuid", "")) or None,
+                 "pci": (f"{getattr(prop, 'pci_domain_id', 0):04x}:{getattr(prop, 'pci_bus_id', -1):02x}:{getattr(prop, 'pci_device_id', 0):02x}"
+                         if hasattr(prop, "pci_bus_id") else None),
+                 "images": B, "ms_per_step": round(my_el * 1e3 / args.steps, 3)}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, ident)
+        if backend == "nccl":
+            ids = [(r["uuid"], r["pci"]) for r in ranks_info]
+            if any(i != (None, None) for i in ids) and len(set(ids)) != world:
+                raise SystemExit(f"bench.py: {world} ranks on {len(set(ids))} distinct GPUs: {ids}")
+        # Weak-scaling leg beside the strong one: every rank runs `micro_batch` images (one micro-batch, the same per-GPU work
+        # at every N) between barriers; afterwards rank 0 runs the same alone.  Raw times only.
+        wb = min(args.micro_batch, B)
+        if wb > 0:
+            with torch.no_grad():
+                for rep in range(2):
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    tw = time.perf_counter()
+                    for _ in range(3):
+                        ow = model(image[:wb], feats[:wb], size)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    w_all = (time.perf_counter() - tw) / 3
+                    del ow
+                w_solo = 0.0
+                if rank == 0:
+                    torch.cuda.synchronize()
+                    tw = time.perf_counter()
+                    for _ in range(3):
+                        ow = model(image[:wb], feats[:wb], size)
+                    torch.cuda.synchronize()
+                    w_solo = (time.perf_counter() - tw) / 3
+                    del ow
+                dist.barrier()
+            tt = torch.tensor([w_all], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            weak = {"images_per_gpu": wb, "ms_all_ranks_busy": round(float(tt.item()) * 1e3, 3),
+                    "ms_rank0_alone": round(w_solo * 1e3, 3) if rank == 0 else None,
+                    "mpix_per_s_all_ranks": round(world * wb * out * out / float(tt.item()) / 1e6, 2)}
 
     one_gpu_ms = None
     if world > 1 and not args.no_single_gpu_reference:
@@ -317,6 +369,23 @@ def main():
                     # 2 * k^2 * (256 + C) FLOP per output pixel, dense bf16 MFMA peak 2.5 PFLOP/s
                     "mfma_tflops": round(2.0 * ksz * ksz * (256 + C) * mb * out * out / (xna_ms * 1e-3) / 1e12, 1),
                     "mfma_frac": round(2.0 * ksz * ksz * (256 + C) * mb * out * out / (xna_ms * 1e-3) / 2.5e15, 4)}
+        m = lambda k: timer.mean_ms(k)
+        r4 = lambda v: round(v, 4) if v else None
+        phases = {k: r4(m(k)) for k in ("stem", "stem_conv0", "stem_conv1", "stem_conv3", "rope_pool", "attention", "xna_mfma")}
+        if m("branch0_layers"):
+            # single-call mode: naf_forward records events at its phase boundaries (naf_forward_args.phase_events).  Branch 0 is
+            # the 1x1 branch (`encoder`), branch 1 the 3x3 branch (`sem_encoder`); a branch's block layers are nlayer launches of
+            # one kernel, so the per-launch figures are the phase / nlayer.  rope_pool includes the 9 us value packing.
+            nl = 2 * len(list(model.image_encoder.encoder)[1:])
+            phases.update({"stem_conv0_1x1_stats": r4(m("branch0_conv0")), "stem_conv0_3x3": r4(m("branch1_conv0")),
+                           "stem_layers_1x1": r4(m("branch0_layers")), "stem_layers_3x3": r4(m("branch1_layers")),
+                           "stem_conv1": r4(m("branch0_layers") / nl), "stem_conv3": r4(m("branch1_layers") / nl),
+                           "layers_per_branch": nl, "source": "hipEvents recorded inside the one naf_forward call"})
+        if roof and m("rope_pool"):
+            # a separate RoPE / key-pooling pass is overhead against the achieved fraction, not algorithmic traffic
+            t_pre = (xna_ms + m("rope_pool")) * 1e-3
+            roof["prepass_ms"] = r4(m("rope_pool"))
+            roof["frac_with_prepass"] = round(alg / t_pre / 1e9 / HBM_PEAK_GBS, 4)
         line = {
             "metric": "upsampled Mpixels/sec (NAF forward)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -335,11 +404,12 @@ def main():
                                 + (", hipGraph replay" if args.graph else ""),
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
             "roofline": roof,
-            "phases_ms": {k: (round(timer.mean_ms(k), 4) if timer.mean_ms(k) else None)
-                          for k in ("stem", "stem_conv0", "stem_conv1", "stem_conv3", "rope_pool", "attention", "xna_mfma")},
+            "phases_ms": phases,
             "launches_per_step": {k: timer.count(k) // max(1, args.steps) for k in ("stem_conv0", "stem_conv1", "stem_conv3")},
         }
         if world > 1:
+            line["ranks"] = ranks_info
+            line["weak_leg"] = weak
             line["scatter_ms"] = round(scatter_ms, 3)
             line["one_gpu_ms"] = round(one_gpu_ms, 3) if one_gpu_ms else None
             line["speedup_vs_1"] = round(one_gpu_ms / ms_step, 3) if one_gpu_ms else None

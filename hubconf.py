@@ -13,7 +13,9 @@ CHECKPOINT_URL = "https://github.com/valeoai/NAF/releases/download/model/naf_rel
 
 
 def naf(pretrained: bool = True, device="cpu"):
-    """NAF (Neighborhood Attention Filtering) upsampler on MI355X-native HIP kernels.
+    """NAF upsampler on MI355X-native HIP kernels -- the FORWARD NEEDS A ROCm DEVICE: with the reference's default
+    ``device="cpu"`` the module is built and loaded, but calling it raises RuntimeError until it is moved (``.to("cuda")``);
+    there is no CPU path in this library (pass ``device="cuda"``).
 
     Builds the default model (dim 256, 4 heads, kernel 9) and, if ``pretrained``, loads the reference's
     released weights (identical ``state_dict`` keys, strict).  The model can be constructed and

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 103 /* major*10000 + minor*100 + patch */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -395,6 +395,7 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
  *             values, queries / index tables where needed); the library still owns no memory
  *   events    optional hipEvent_t handles recorded on the stream around the attention kernel
  *             (events[0] before, events[1] after) so that a caller can time it; NULL entries are skipped
+ *             (phase_events, at the end of the struct, does the same for every phase of the call)
  * An image more than 4x the output is first shrunk (naf_preshrink_image), an image larger than the output has its
  * guidance pooled (naf_pool_guidance; an output larger than the image is the same adaptive pooling), exactly as
  * naf.py:37-49 does; `logits` adds the reference's return_weights output.  Other widths return
@@ -430,6 +431,12 @@ typedef struct naf_forward_args {
     float scale; /* <= 0: Dq^-0.5 */
     int64_t image_stride[4];
     int64_t feat_stride[4];
+    /* optional hipEvent_t handles recorded on the stream at the phase boundaries of the forward (NULL entries skipped), so that a
+     * caller can time the phases of the ONE call: [0] start, [1] after branch 0's first convolution, [2] after branch 0's block
+     * layers, [3] after branch 1's first convolution, [4] after branch 1's block layers and the guidance pooling (= end of the
+     * conv stem), [5] after RoPE / key pooling, value packing and index tables (= start of the attention kernel), [6] after the
+     * attention kernel, [7] reserved.  Appended in 0.1.3 (naf_version() >= 103): callers that zero-initialise the struct need no change. */
+    void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);
 /* 1 when naf_forward serves these arguments, 0 when not (then NAF_ERR_UNSUPPORTED), negative naf_status if invalid. */

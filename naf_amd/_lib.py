@@ -131,7 +131,7 @@ class ForwardArgs(C.Structure):
         ("nlayer", C.c_int32), ("image_dtype", C.c_int32), ("feat_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("C", C.c_int32),
         ("heads", C.c_int32), ("ksize", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("heads_rope", C.c_int32), ("reserved", C.c_int32), ("gn_eps", C.c_float), ("scale", C.c_float),
-        ("image_stride", I64x4), ("feat_stride", I64x4),
+        ("image_stride", I64x4), ("feat_stride", I64x4), ("phase_events", C.c_void_p * 8),
     ]
 
 

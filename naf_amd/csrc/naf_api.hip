@@ -461,6 +461,13 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     }
     void* bufs[2] = {ws + L.buf0, ws + L.buf1};
     char* cat = ws + L.cat;
+    auto mark = [&](int i) -> bool {   // phase_events[i] on the stream, if the caller asked for it
+        if (a->phase_events[i] == nullptr) return true;
+        if (hipEventRecord(static_cast<hipEvent_t>(a->phase_events[i]), s) == hipSuccess) return true;
+        naf_set_error("naf_forward: hipEventRecord(phase_events[%d]) failed", i);
+        return false;
+    };
+    if (!mark(0)) return NAF_ERR_LAUNCH;
     // the image the stem runs on: the caller's, or its bilinear pre-shrink (naf.py:39-48) when it is more than 4x the output
     const void* simg = a->image;
     int simg_dtype = a->image_dtype;
@@ -488,6 +495,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
         int rc = naf_stem_conv0_fwd(&c0, stream);
         if (rc != NAF_OK) return rc;
+        if (!mark(1 + 2 * br)) return NAF_ERR_LAUNCH;
         const void* cur = bufs[0];
         for (int l = 0; l < a->nlayer; ++l) {
             const bool last = l == a->nlayer - 1;
@@ -505,6 +513,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
             if (rc != NAF_OK) return rc;
             cur = c.y;
         }
+        if (br == 0 && !mark(2)) return NAF_ERR_LAUNCH;
     }
     // keys: pooled RoPE'd guidance; queries: rotated on load by the attention kernel where the geometry allows it
     // (row tiles), otherwise written here
@@ -512,6 +521,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         const int prc = naf_pool_guidance(ws + L.guide, cat, a->B, SH, SW, L.Ho, L.Wo, 256, stream);
         if (prc != NAF_OK) return prc;
     }
+    if (!mark(4)) return NAF_ERR_LAUNCH;
     naf_rope_pool_args rp{};
     rp.x = ws + L.guide; rp.q = L.fused ? nullptr : static_cast<void*>(ws + L.q); rp.k_lr = ws + L.keys; rp.tab_y = a->tab_y; rp.tab_x = a->tab_x;
     const int hrope = a->heads_rope > 0 ? a->heads_rope : a->heads;
@@ -531,6 +541,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         if (rc == NAF_OK) rc = naf_axis_index_table_device(reinterpret_cast<int32_t*>(ws + L.idx_x), L.Wo, a->w, a->ksize, stream);
         if (rc != NAF_OK) return rc;
     }
+    if (!mark(5)) return NAF_ERR_LAUNCH;
     if (a->events[0] && hipEventRecord(static_cast<hipEvent_t>(a->events[0]), s) != hipSuccess) {
         naf_set_error("naf_forward: hipEventRecord failed");
         return NAF_ERR_LAUNCH;
@@ -541,6 +552,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         naf_set_error("naf_forward: hipEventRecord failed");
         return NAF_ERR_LAUNCH;
     }
+    if (!mark(6)) return NAF_ERR_LAUNCH;
     return NAF_OK;
 }
 

@@ -110,14 +110,26 @@ __global__ __launch_bounds__(NWG * 64) void stem_conv0_generic_kernel(const Stem
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
                 *reinterpret_cast<bf16x8_t*>(p.y + (int64_t)b * p.ys[0] + (int64_t)yy * p.ys[1] + (int64_t)xx * p.ys[2] + ch * 8) = o;
             }
+        }
+        if (p.stats_out != nullptr) {
+            // all 64 lanes of a wave hold the SAME channels (different pixels): reduce across the wave first, then one LDS
+            // atomic per channel and wave (64 lanes on one LDS address serialise)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(&s1c[ch * 8 + e], acc[e]);
-                atomicAdd(&s2c[ch * 8 + e], acc[e] * acc[e]);
+                float a = inside ? acc[e] : 0.f, q = a * a;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o);
+                    q += __shfl_xor(q, o);
+                }
+                if ((tid & 63) == 0) {
+                    atomicAdd(&s1c[ch * 8 + e], a);
+                    atomicAdd(&s2c[ch * 8 + e], q);
+                }
             }
         }
     }
-    publish_stats(s1c, s2c, C, p.stats_out, b);
+    if (p.stats_out != nullptr) publish_stats(s1c, s2c, C, p.stats_out, b);
 }
 
 // ---- GroupNorm -> SiLU -> Conv2d(C -> C) --------------------------------------------------------------------------------

@@ -79,10 +79,18 @@ def broadcast_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, devi
     (world x the bytes of ``scatter_batch`` on the wire, but a single ring-pipelined collective; useful when every rank
     needs the whole batch anyway, e.g. for a later gather-free evaluation)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    buf = full.contiguous() if rank == src else torch.empty(tuple(shape), dtype=dtype, device=device)
+    via_host = dist.get_backend() == "gloo" and torch.device(device).type != "cpu"
+    final_device, device = device, ("cpu" if via_host else device)
+    if rank == src:
+        if full is None or tuple(full.shape) != tuple(shape) or full.dtype != dtype:
+            raise ValueError(f"broadcast_batch: rank {src} must pass the full tensor of shape {tuple(shape)} and dtype {dtype}")
+        buf = full.contiguous().to(device)
+    else:
+        buf = torch.empty(tuple(shape), dtype=dtype, device=device)
     dist.broadcast(buf, src=src)
     lo, hi = shard_range(int(shape[0]), rank, world)
-    return buf[lo:hi]
+    # a private copy of the slice: a view would keep the whole batch alive on every rank (and alias rank src's input)
+    return buf[lo:hi].to(final_device, copy=True)
 
 
 def gather_scalars(values: Sequence[float], device) -> List[List[float]]:

@@ -239,7 +239,7 @@ class _HipStem(torch.autograd.Function):
         B, _, H, W = image.shape
         dev = g.device
         hid = 128
-        gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16)                       # [B, H, W, 256], channels contiguous
+        gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()          # [B, H, W, 256]; a no-op for a channels-last gradient
         grads = []
         dimage = None
         need_img = ctx.needs_input_grad[1]
@@ -523,13 +523,17 @@ class GraphedForward:
         cur = torch.cuda.current_stream(image.device)
         side = torch.cuda.Stream(device=image.device)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):                       # warm-up outside the capture: caches, lazy module init
-            for _ in range(max(1, warmup)):
-                model(self.image, self.features, self.output_size)
-        cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = model(self.image, self.features, self.output_size)
+        # Always the fused inference forward, whatever mode the module is in: ``hubconf.naf()`` hands out a train-mode
+        # module like the reference, and ``model(...)`` would then dispatch to ``forward_train`` (torch stem with saved
+        # activations, a random RoPE jitter draw and an output with a grad_fn frozen into the graph).
+        with torch.no_grad():
+            with torch.cuda.stream(side):                   # warm-up outside the capture: caches, lazy module init
+                for _ in range(max(1, warmup)):
+                    model._forward_inference(self.image, self.features, self.output_size)
+            cur.wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model._forward_inference(self.image, self.features, self.output_size)
         # The captured launches dereference device memory the graph does not own: the forward plan's workspace and
         # argument block, the RoPE tables, the packed bf16 weights.  They live in single-slot caches of the model that a
         # later eager call with other shapes (or a parameter update) replaces; hold them here so that a replay never
@@ -737,7 +741,8 @@ class NAF(nn.Module):
             # default-width model trains through this library's own differentiable stem (bf16 activations, HIP backward kernels)
             amp = False
             if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-                amp = "hip" if self.image_encoder._hip_stem_default_width() else True
+                enc = self.image_encoder
+                amp = "hip" if (enc.stem_impl == "hip" and enc._hip_stem_default_width()) else True
             return self.forward_train(image, features, output_size, amp=amp)
         with torch.no_grad():
             return self._forward_inference(image, features, output_size, return_weights)
@@ -763,13 +768,22 @@ class NAF(nn.Module):
             plan = self._forward_plan(image, features, output_size)
             if plan is not None:
                 timer = ops.KERNEL_TIMER
-                ev = None
+                ev = pe = None
                 if timer is not None and getattr(timer, "enabled", False):
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     for e in ev:
                         e.record()          # creates the underlying hipEvent_t; naf_forward re-records it around the kernel
                     timer.pairs.setdefault("xna_mfma", []).append(ev)
-                return plan.run(image, features, ev, return_logits=bool(return_weights))
+                    if getattr(timer, "phases", True):
+                        # the phases of the ONE call (naf_forward_args.phase_events): both stem branches, first convolution and
+                        # block layers apart, the RoPE / key-pooling pre-pass, the attention
+                        pe = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+                        for e in pe:
+                            e.record()
+                        for name, i, j in (("stem", 0, 4), ("branch0_conv0", 0, 1), ("branch0_layers", 1, 2), ("branch1_conv0", 2, 3),
+                                           ("branch1_layers", 3, 4), ("rope_pool", 4, 5), ("attention", 5, 6)):
+                            timer.pairs.setdefault(name, []).append((pe[i], pe[j]))
+                return plan.run(image, features, ev, return_logits=bool(return_weights), phase_events=pe)
         fuse_for = None
         if features.shape[1] % self.upsampler.num_heads == 0:
             fuse_for = (features.shape[1] // self.upsampler.num_heads,

@@ -644,7 +644,7 @@ class ForwardPlan:
         self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype,
                     (Ho, Wo))
 
-    def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False):
+    def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False, phase_events=None):
         a = self.args
         dev = image.device
         # the workspace belongs to the plan (one allocation per geometry, not per call); like the reference's RoPE cache
@@ -657,6 +657,8 @@ class ForwardPlan:
         a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes
         a.events[0] = events[0].cuda_event if events else None
         a.events[1] = events[1].cuda_event if events else None
+        for i in range(8):     # naf_forward_args.phase_events: hipEvent_t handles at the phase boundaries of the one call
+            a.phase_events[i] = phase_events[i].cuda_event if (phase_events and i < len(phase_events)) else None
         logits = None
         if return_logits:
             logits = torch.empty((self.shape_out[0], a.heads, self.shape_out[1], self.shape_out[2], a.ksize * a.ksize),

@@ -48,6 +48,9 @@ def test_struct_layout_matches_header(built_lib):
     assert a == C.sizeof(_lib.RopePoolArgs) and b == C.sizeof(_lib.XnaArgs)
     assert c == C.sizeof(_lib.StemConv0Args) and e == C.sizeof(_lib.StemConvArgs)
     assert f == C.sizeof(_lib.XnaBwdArgs) and g == C.sizeof(_lib.ForwardArgs)
+    # phase_events was appended (0.1.3): the last 8 pointers of the struct, older fields where they were
+    assert _lib.ForwardArgs.phase_events.offset == g - 8 * C.sizeof(C.c_void_p)
+    assert _lib.ForwardArgs.feat_stride.offset == g - 8 * C.sizeof(C.c_void_p) - 32
 
 
 def test_training_struct_layouts_match_header(built_lib):

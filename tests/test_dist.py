@@ -52,6 +52,13 @@ def _worker(rank, world, port, ret):
         assert torch.equal(img, expect)
         img_b = nd.broadcast_batch(full_img, (N, 3, 4, 4), torch.float32, "cpu", src=0)
         assert torch.equal(img_b, expect)
+        # a private slice: not a view of the whole batch (which would stay alive on every rank), not rank 0's input
+        assert img_b.untyped_storage().nbytes() == img_b.numel() * 4
+        if rank == 0:
+            assert img_b.data_ptr() != full_img.data_ptr()
+            for bad in (None, full_img[:-1], full_img.double()):         # missing / wrong shape / wrong dtype on the owner
+                with pytest.raises(ValueError):
+                    nd.broadcast_batch(bad, (N, 3, 4, 4), torch.float32, "cpu", src=0)
         empty = nd.scatter_batch(torch.zeros(0, 2) if rank == 0 else None, (0, 2), torch.float32, "cpu", src=0)
         assert empty.shape == (0, 2)
 

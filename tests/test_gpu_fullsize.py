@@ -257,6 +257,15 @@ def test_bench_multi_rank_path_dry_run(dev):
     assert j["config"]["workload"].startswith("G3") and "DRY RUN" in j["data"]
     assert j["value"] > 0 and j["one_gpu_ms"] > 0 and j["speedup_vs_1"] > 0 and j["scatter_ms"] > 0
     assert j["roofline"]["kernel_ms"] > 0 and j["cpu_baseline"] is None
+    # the line proves what ran where: one entry per rank with the device it computed on and its own step time (under RCCL
+    # the identities must be distinct -- bench.py exits otherwise; in this dry run the ranks share the GPU), a weak-scaling
+    # leg beside the strong one, and the phases of the single call
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and all(r["images"] == 3 and r["ms_per_step"] > 0 and r["name"] for r in j["ranks"])
+    assert all("uuid" in r and "pci" in r for r in j["ranks"])
+    assert j["weak_leg"]["images_per_gpu"] == 3 and j["weak_leg"]["ms_all_ranks_busy"] > 0 and j["weak_leg"]["ms_rank0_alone"] > 0
+    ph = j["phases_ms"]
+    assert ph["stem"] > 0 and ph["rope_pool"] > 0 and ph["attention"] > 0 and ph["stem_conv3"] > 0 and ph["stem_conv1"] > 0
+    assert 0 < j["roofline"]["frac_with_prepass"] < j["roofline"]["frac"]
 
 
 @pytest.mark.parametrize("dim,shape", [(96, (1, 40, 56)), (128, (2, 33, 47)), (512, (1, 24, 40)), (32, (1, 20, 24))])

@@ -995,6 +995,49 @@ def test_captured_forward_replays_bit_exactly(dev, hw, lr, C, ksz):
     assert torch.equal(g(img2, ft2), m(img2, ft2, hw))
 
 
+def test_capture_from_a_train_mode_module_is_the_inference_forward(dev):
+    """``hubconf.naf()`` returns a train-mode module (like the reference); capturing from it must record the
+    fused inference forward -- not ``forward_train`` (torch stem with saved activations, a RoPE jitter draw frozen into the
+    graph, an output with a grad_fn) -- and replays must equal the eval-mode forward bit for bit."""
+    p = O.make_params(seed=5)
+    m = _load_model(dev, p, kernel_size=3)
+    img = O.hash_normal((1, 3, 64, 64), 811).to(dev)
+    ft = O.hash_normal((1, 128, 4, 4), 812).to(dev)
+    want = m(img, ft, (64, 64))
+    m.train()
+    assert any(q.requires_grad for q in m.parameters()) and torch.is_grad_enabled()
+    g = m.capture(img, ft, (64, 64))
+    out = g()
+    assert out.grad_fn is None and not out.requires_grad
+    assert torch.equal(out, want)
+    assert torch.equal(g(), want)                                     # no per-replay randomness in the graph
+
+
+def test_generic_conv0_without_statistics(dev):
+    """the C ABI allows ``stats_out == NULL`` for the first convolution; the general-width kernel used to publish
+    its sums unconditionally (device fault).  Same output with and without the statistics buffer."""
+    from naf_amd import ops
+    B, H, W, Cc = 1, 19, 23, 48
+    img = O.hash_normal((B, 3, H, W), 821).to(dev)
+    for ks in (1, 3):
+        w = O.hash_normal((Cc, 3, ks, ks), 822 + ks).to(dev).contiguous()
+        b = O.hash_normal((Cc,), 824).to(dev)
+        y0 = torch.empty((B, H, W, Cc), dtype=torch.bfloat16, device=dev)
+        y1 = torch.empty_like(y0)
+        st = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+        ops.stem_conv0(img, w, b, y0, None)
+        ops.stem_conv0(img, w, b, y1, st)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        yf = y1.float()
+        import torch.nn.functional as F
+        x = F.pad(img, (1, 1, 1, 1), mode="reflect") if ks == 3 else img
+        r = F.conv2d(x.double(), w.double(), b.double()).float()        # [B, Cc, H, W]
+        assert_close(yf.permute(0, 3, 1, 2).cpu(), r.cpu(), 1e-5, 2.0 ** -7, f"conv0 k{ks}")
+        rs = torch.stack([r.double().view(B, 8, -1).sum(-1), (r.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1)
+        assert torch.allclose(st.cpu(), rs.cpu(), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("img_hw,lr,C,ksz", [
     ((50, 70), (5, 7), 32, 3),     # ratio 10: integer, but tiles straddle rows (generic tile loop, queries materialised)
     ((50, 70), (6, 9), 24, 3),     # non-integer ratio: table-driven attention
