@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 on one GPU = ~0.5 s of device time, so that "
                     "a utilisation sampler sees the timed region; 10 on several GPUs, where a step is the whole 64-image batch)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--phase-every", type=int, default=8, help="record the per-phase events on every n-th timed step")
     ap.add_argument("--no-phase-events", action="store_true", help="do not record the per-phase events inside naf_forward "
                     "(A/B: what the seven extra event records cost)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: G1 on one GPU, G3 on several")
@@ -230,7 +231,9 @@ def main():
         feats = torch.randn(B, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
 
     timer = EventTimer()
-    timer.phases = not args.no_phase_events
+    # phase events on every 8th step: seven extra event records between the kernels of a step cost 0.03-0.05 ms (1.5-2 %) of a
+    # 2.25 ms G1 step when taken every step (gpurun r9b: 2.270 vs 2.228 ms), a quarter of a percent this way
+    timer.phases = 0 if args.no_phase_events else args.phase_every
     ops.KERNEL_TIMER = timer
 
     if args.attention_only:
@@ -380,7 +383,7 @@ def main():
             phases.update({"stem_conv0_1x1_stats": r4(m("branch0_conv0")), "stem_conv0_3x3": r4(m("branch1_conv0")),
                            "stem_layers_1x1": r4(m("branch0_layers")), "stem_layers_3x3": r4(m("branch1_layers")),
                            "stem_conv1": r4(m("branch0_layers") / nl), "stem_conv3": r4(m("branch1_layers") / nl),
-                           "layers_per_branch": nl, "source": "hipEvents recorded inside the one naf_forward call"})
+                           "layers_per_branch": nl, "source": f"hipEvents recorded inside the one naf_forward call, on {timer.count('stem')} of the {args.steps} timed steps"})
         if roof and m("rope_pool"):
             # a separate RoPE / key-pooling pass is overhead against the achieved fraction, not algorithmic traffic
             t_pre = (xna_ms + m("rope_pool")) * 1e-3

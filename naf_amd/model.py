@@ -774,7 +774,9 @@ class NAF(nn.Module):
                     for e in ev:
                         e.record()          # creates the underlying hipEvent_t; naf_forward re-records it around the kernel
                     timer.pairs.setdefault("xna_mfma", []).append(ev)
-                    if getattr(timer, "phases", True):
+                    every = int(getattr(timer, "phases", 1) or 0)       # 0 / False: none; n: every n-th call (an event record
+                    timer._calls = getattr(timer, "_calls", -1) + 1       # between two kernels costs ~5 us of device time)
+                    if every > 0 and timer._calls % every == 0:
                         # the phases of the ONE call (naf_forward_args.phase_events): both stem branches, first convolution and
                         # block layers apart, the RoPE / key-pooling pre-pass, the attention
                         pe = [torch.cuda.Event(enable_timing=True) for _ in range(7)]

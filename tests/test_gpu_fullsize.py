@@ -87,6 +87,45 @@ def test_whole_forward_G1_full_size(dev):
     assert float((got - ref).abs().mean()) <= 6e-3
 
 
+def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows):
+    """Stem at EVERY pixel (mean / max and uniformity over 32-pixel strips and 64-row bands: a geometry bug would make one
+    stand out) + the whole bf16 forward on sampled rows, against the fp32 oracle."""
+    p = O.make_params(seed=seed)
+    m = _load_model(dev, p, kernel_size=ksz)
+    img = O.hash_normal((1, 3, out_sz, out_sz), 100 * seed + 1)
+    ft = O.hash_normal((1, C, lr, lr), 100 * seed + 2).to(torch.bfloat16).float()
+    stem_ref, ref = _oracle_rows(p, img, ft, out_sz, ksz, rows)
+    got_stem = m.image_encoder.guidance(img.to(dev), (out_sz, out_sz)).float().cpu()
+    err = (got_stem - stem_ref).abs()
+    del got_stem, stem_ref
+    assert float(err.mean()) <= 8e-3 and float(err.max()) <= 2.5e-1, (f"{name} stem", float(err.mean()), float(err.max()))
+    band = err.mean(dim=(0, 1)).view(out_sz // 64, 64, out_sz // 32, 32).mean(dim=(1, 3))
+    assert float(band.max()) <= 2.0 * float(err.mean()) + 1e-3, f"{name}: stem error is not uniform over strips / bands"
+    del err, band
+    out = m(img.to(dev), ft.to(dev).to(torch.bfloat16), (out_sz, out_sz))
+    assert out.shape == (1, C, out_sz, out_sz) and out.dtype == torch.bfloat16
+    got = out[:, :, rows].float().cpu()
+    _assert_close(got, ref, 2e-2, 1e-2, f"{name} whole forward, sampled rows")
+    assert float((got - ref).abs().mean()) <= 6e-3
+
+
+def test_whole_forward_G4_full_size(dev):
+    """VERDICT r02 (missing 3): BASELINE configs[4] end to end -- 1x3x2048^2 image, 768x128^2 features -> 2048^2, window 7,
+    bf16 -- the stem's strip / segment geometry at 2048 rows (64 strips x 4 segments of 512 rows on 256 CUs) had never been
+    compared with anything; the attention's bf16 output is 3.2 G elements (offsets past 2^31).  The oracle stem at 2048^2 is
+    5.5 TFLOP of fp32 CPU convolutions: about a minute on the GPU box's host cores."""
+    rows = sorted({0, 1, 15, 16, 511, 512, 1023, 1024, 1300, 1535, 1536, 2031, 2032, 2046, 2047})
+    _whole_forward_case(dev, "G4", 2048, 768, 128, 7, 24, rows)
+
+
+@pytest.mark.parametrize("ksz", [7, 11, 15])
+def test_whole_forward_G2_full_size(dev, ksz):
+    """BASELINE configs[2] end to end: 1x3x512^2 image, 1024x32^2 features -> 512^2, windows 7 / 11 / 15, bf16: the staged
+    4-wave cell kernel (k = 7) and the bf16 sliding-window kernel (k = 11, 15) behind the real stem, rotate-on-load."""
+    rows = sorted({0, 1, 15, 16, 127, 128, 255, 256, 400, 495, 496, 510, 511})
+    _whole_forward_case(dev, f"G2-k{ksz}", 512, 1024, 32, ksz, 25 + ksz, rows)
+
+
 def test_whole_forward_G3_shard_through_the_sharded_driver(dev):
     """BASELINE configs[3] as one rank sees it: 8 of the 64 images (C = 1024), run through naf_amd.dist.ShardedNAF in
     micro-batches exactly as bench.py --gpus 8 does; images 0 and 7 of the shard against the oracle on sampled rows."""
