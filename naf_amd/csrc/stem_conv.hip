@@ -25,6 +25,7 @@
 //     (4 px x 256 B = 1 KiB contiguous per wave instruction).
 //   * per-workgroup fp32 partial sums of y and y^2 per GroupNorm group -> fp64 atomics.
 #include "stem_conv_kernel.h"
+#include "stem_rows_kernel.h"
 
 template <int KS>
 static size_t stem_conv_lds() {
@@ -61,8 +62,23 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         naf_set_error("naf_stem_conv_fwd: grid out of range");
         return NAF_ERR_INVALID;
     }
-    const size_t lds = stem_conv_lds<3>();
     const bool plain = a->stats_in == nullptr;   // no GroupNorm / SiLU in front of the convolution (data-gradient pass)
+    static const bool old_kernel = [] { const char* e = naf_knob("NAF_STEM3_OLD"); return e != nullptr && atoi(e) != 0; }();
+    if (!old_kernel) {
+        // row-streaming kernel (round 3): segments a multiple of four rows (its body is four input rows)
+        seg_h = ((seg_h + 3) / 4) * 4;
+        p.seg_h = seg_h;
+        p.segs_y = (a->H + seg_h - 1) / seg_h;
+        const int64_t nbr = strips * p.segs_y;
+        const void* fn = reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES) != hipSuccess) {
+            naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", stem_rows::LDS_BYTES);
+            return NAF_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(stem_rows::stem_conv_rows_kernel<0>, dim3((uint32_t)nbr), dim3(256), stem_rows::LDS_BYTES, s, p);
+        return naf_check_launch("stem_conv_rows_kernel");
+    }
+    const size_t lds = stem_conv_lds<3>();
     const void* fn = plain ? reinterpret_cast<const void*>(stem_conv_kernel<3, 0, true>) : reinterpret_cast<const void*>(stem_conv_kernel<3>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", lds);

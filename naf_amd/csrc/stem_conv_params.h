@@ -1,0 +1,17 @@
+// Launch parameters shared by the 3x3 stem-layer kernels (stem_rows_kernel.h, stem_conv_kernel.h).
+#pragma once
+#include "naf_common.h"
+
+struct StemConvParams {
+    const bf16_t* x;       // [B, H, W, 128] channels contiguous, strides below
+    bf16_t* y;             // [B, H, W, >=128] (may be a 128-channel slice of a wider tensor)
+    const bf16_t* w;       // packed [KS*KS][128 oc][128 ic]
+    const float* bias;     // [128]
+    const float* gamma;    // [128] GroupNorm weight applied to x
+    const float* beta;     // [128]
+    const double* stats_in;  // [B][8][2] sum, sum^2 of x over (H, W, 16 ch); NULL: no GroupNorm / SiLU (plain convolution)
+    double* stats_out;       // [B][8][2] of y, or nullptr
+    int32_t B, H, W, tiles_x, segs_y, seg_h;
+    float eps;
+    int64_t xs[3], ys[3];  // element strides {b, y, x}
+};

@@ -1,0 +1,324 @@
+// GroupNorm -> SiLU -> Conv3x3(128 -> 128, reflect), weight-stationary on the matrix pipe, ROW-STREAMING (round 3).
+// Kernel of naf_stem_conv_fwd for ksize 3 (convolutions.py:52-61); a header so that tools/stem_probe.hip can instantiate
+// ablation variants.
+//
+// Why this shape.  The chip is power-limited under this layer (tools/mfma_chain_probe.hip: the matrix pipe issues every
+// 32.3 cycles whatever sits between two MFMAs, and the clock drops to 1.4-1.8 GHz), so what buys time is energy per pixel:
+// LDS reads and side instructions, not issue slots.  The round-1/2 kernel (stem_conv_kernel.h) computed two output rows per
+// step from four input rows: a B fragment (16 input channels x 32 pixels of one input row at one tap column) fed 1.5 MFMAs on
+// average.  Here ONE input row is streamed per row-step and every fragment feeds the three output rows it touches --
+// MFMAs (tap row 2 -> output row r-1, tap row 1 -> r, tap row 0 -> r+1) back to back from the same registers: 24 fragment
+// reads per 72 MFMAs (was 48), and an input row is read from the LDS exactly once per wave.
+//   * wave w owns output channels [32w, 32w+32) and keeps all its weights in registers (9 taps x 8 k-steps x 4 = 288);
+//   * three accumulators are live (rows r-1, r, r+1) and a fourth is in its epilogue (row r-2): the four names rotate with
+//     period 4 input rows, so the generated body (tools/gen_stem_rows.py -> stem_rows_sched.inc) covers four input rows =
+//     two "double-steps" of 144 MFMAs with one barrier each; an accumulator is re-initialised with the conv bias straight
+//     from the LDS (no VALU) after its epilogue;
+//   * ring of 8 input rows in the LDS: a batch of two rows is loaded (global -> registers) three double-steps ahead,
+//     normalised + activated + written two double-steps ahead, so the rows a double-step reads have been in the ring for
+//     a whole double-step and the first fragments of the next double-step are requested before the barrier;
+//   * results leave through an LDS tile as whole 256-byte pixel rows, GroupNorm sums of the output from the fp32
+//     accumulators (rows outside the segment are masked by a multiplier, not by branches).
+#pragma once
+#include <type_traits>
+
+#include "naf_common.h"
+#include "stem_conv_params.h"
+
+namespace stem_rows {
+constexpr int C = 128;          // channels in == out
+constexpr int TW = 32;          // strip width (pixels)
+constexpr int PXE = C + 8;      // LDS elements per pixel (272 B: conflict-free ds_read_b128 fragments)
+constexpr int PXR = 40;         // pixels stored per ring row (34 are read: 32 + halo; 2 rows = 80 px = 5 load pieces per thread)
+constexpr int ROWE = PXR * PXE; // elements per ring row
+constexpr int RING = 8;         // ring rows
+constexpr int NLD = 5;          // 16-byte load pieces per thread per batch of two rows
+constexpr int NST = 4;          // 16-byte store pieces per thread per output tile of two rows
+constexpr int NB = 3;           // B-fragment register buffers (a fragment is requested 4 fragments = 12 MFMAs ahead)
+constexpr size_t LDS_BYTES = (size_t)(RING * ROWE + 2 * 2 * TW * PXE) * 2 + 3 * C * sizeof(float);
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return min(max(i, 0), n - 1);
+}
+
+// ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue, 4 no
+// LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);                     // [RING][PXR][PXE]
+    bf16_t* otile = ring + RING * ROWE;                                 // [2][2*TW][PXE]
+    float* cvec = reinterpret_cast<float*>(otile + 2 * 2 * TW * PXE);   // [3][128]: bias, GN scale, GN shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n32 = lane & 31, half = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int seg = bid % p.segs_y;
+    const int b = bid / p.segs_y;
+    const int sx = tx * TW;
+    const int sy = seg * p.seg_h;
+    const int sy_end = min(p.H, sy + p.seg_h);
+    // input rows sy-1 .. sy_end (relative 0 .. rows+1); output row `rel` is complete after input row rel+1 and has its
+    // epilogue during input row rel+2: rows+3 row-steps, rounded up to whole bodies of four
+    const int nbody = (sy_end - sy + 3 + 3) / 4;
+    const bool plain = p.stats_in == nullptr;   // no GroupNorm, no SiLU: y = conv(x) (+ bias) -- the data-gradient pass
+
+    const int chunk = tid & 15, pl = tid >> 4;
+    if (tid < C) {
+        if (plain) {
+            cvec[tid] = p.bias ? p.bias[tid] : 0.f;
+            cvec[C + tid] = 1.f;
+            cvec[2 * C + tid] = 0.f;
+        } else {
+            const int g = tid >> 4;  // 16 channels per group
+            const double n = (double)p.H * (double)p.W * 16.0;
+            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float gmm = p.gamma[tid];
+            cvec[tid] = p.bias[tid];
+            cvec[C + tid] = gmm * rstd;
+            cvec[2 * C + tid] = p.beta[tid] - (float)mean * gmm * rstd;
+        }
+    }
+    __syncthreads();
+
+    // GroupNorm scale / shift of this thread's 8 input channels; activation: out = y * rcp(dconst + exp2(y * c2)) with
+    // (c2, dconst) = (-log2 e, 1) = SiLU, or (0, 0) = identity (plain mode: exp2(0) = 1, rcp(1) = 1)
+    f32x2_t gav[4], gbv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gav[e] = f32x2_t{cvec[C + chunk * 8 + 2 * e], cvec[C + chunk * 8 + 2 * e + 1]};
+        gbv[e] = f32x2_t{cvec[2 * C + chunk * 8 + 2 * e], cvec[2 * C + chunk * 8 + 2 * e + 1]};
+    }
+    const float c2 = plain ? 0.f : -1.4426950408889634f;
+    const float dconst = plain ? 0.f : 1.f;
+    const char* xbu = reinterpret_cast<const char*>(p.x + (int64_t)b * p.xs[0]);
+    char* ybu = reinterpret_cast<char*>(p.y + (int64_t)b * p.ys[0]);
+
+    // Load piece n of a batch of two rows is ring pixel (rr, px) = divmod(pl + 16 n, PXR): its image column is fixed for the
+    // whole kernel (reflect padding = coordinate map), only the row advances; pixels past the 34 the MFMAs read are padding
+    // (clamped, never consumed), which keeps every piece unconditional.
+    uint32_t col_off[NLD];   // bytes from the row base
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int i = pl + 16 * n;
+        const int px = i % PXR;
+        col_off[n] = (uint32_t)(reflect(sx - 1 + px, p.W) * (int)p.xs[2] + chunk * 8) * 2u;
+    }
+    // ring offset (elements) of piece n relative to the batch's first ring row: pieces 0, 1, 3, 4 are c_off0 plus a constant
+    // (pixel pl + 16 n of the 80 never wraps for them), piece 2 straddles the two rows (pl < 8: row 0, pixel 32 + pl)
+    const int c_off0 = pl * PXE + chunk * 8;
+    const int c_off2 = (pl < 8 ? (32 + pl) * PXE : ROWE + (pl - 8) * PXE) + chunk * 8;
+    constexpr int C_OFF_CONST[NLD] = {0, 16 * PXE, 0, ROWE + 8 * PXE, ROWE + 24 * PXE};
+    auto c_off = [&](int n) __attribute__((always_inline)) { return n == 2 ? c_off2 : c_off0 + C_OFF_CONST[n]; };
+    // store piece n = tile pixel pl + 16 n: tile offset st_lds0 + 16 n PXE, image-row byte offset st_goff0 (+ 16 pixels for odd n)
+    const int st_lds0 = pl * PXE + chunk * 8;
+    const uint32_t st_goff0 = (uint32_t)((sx + pl) * (int)p.ys[2] + chunk * 8) * 2u;
+    const int64_t st_px16 = (int64_t)16 * p.ys[2] * 2;   // uniform: bytes of 16 pixels of an output row
+    u32x4_t ld[NLD];
+    // batch bt = input rows (relative) 2 bt, 2 bt + 1 = image rows reflect(sy - 1 + 2 bt + rr)
+    auto issue_one = [&](int bt, int n) __attribute__((always_inline)) {
+        const int rr = (pl + 16 * n) / PXR;
+        const int row = reflect(sy - 1 + 2 * bt + rr, p.H);
+        ld[n] = *reinterpret_cast<const u32x4_t*>(xbu + (int64_t)row * p.xs[1] * 2 + col_off[n]);
+    };
+    auto commit_one = [&](int bt, int n) __attribute__((always_inline)) {   // prologue only (the loop's commits are scheduled)
+        const int slot = (2 * bt) % RING;
+        const bf16x8_t v = __builtin_bit_cast(bf16x8_t, ld[n]);
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = fmaf((float)v[e], gav[e >> 1][e & 1], gbv[e >> 1][e & 1]);
+            o[e] = (bf16_t)(y * __builtin_amdgcn_rcpf(dconst + __builtin_amdgcn_exp2f(y * c2)));
+        }
+        *reinterpret_cast<bf16x8_t*>(ring + slot * ROWE + c_off(n)) = o;
+    };
+
+    // prologue: batches 0, 1 (input rows 0..3) into ring slots 0..3, batch 2 in flight
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) issue_one(k, n);
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) commit_one(k, n);
+    }
+    __syncthreads();
+    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t wreg[72];
+    {
+        const bf16_t* wp = p.w + (size_t)(wave * 32 + n32) * C + half * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
+    }
+    // The weights are consumed by asm MFMAs inside the loop: without this wait hipcc cannot prove them resident at the loop
+    // header and guards every use with a vmcnt wait sized for the loop's own loads and stores (which then never overlap).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) issue_one(2, n);
+
+    f32x2_t s1p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}}, s2p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};  // GroupNorm sums (pairs)
+    const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before the tap-column shift)
+
+    // Accumulator row 4j + r of a 32x32 tile = output channel 32 wave + 8 j + 4 half + r.  All four start as the bias (finite
+    // values: rows outside the segment are computed like the others and masked out of the sums by a multiplier).
+    f32x16_t acc[4];
+    auto acc_init = [&](int nm, int j) __attribute__((always_inline)) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(cvec + wave * 32 + 8 * j + 4 * half);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nm][j * 4 + r] = bv[r];
+    };
+#pragma unroll
+    for (int nm = 0; nm < 4; ++nm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_init(nm, j);
+
+    const float lane_m = sx + n32 < p.W ? 1.f : 0.f;   // EDGE: pixels of the strip past the image do not count in the sums
+    bf16x8_t bb[NB] = {};
+    // fragment f of a row: tap column f / 8, k-step f % 8.  base = ring row base (elements) of the row
+    auto load_frag = [&](int base, int f, bf16x8_t& dst) __attribute__((always_inline)) {
+        if (ABL & 4) return;
+        dst = *reinterpret_cast<const bf16x8_t*>(ring + base + (f >> 3) * PXE + lane_b + (f & 7) * 16);
+    };
+#pragma unroll
+    for (int f = 0; f < NB; ++f) load_frag(0, f, bb[f]);
+
+    // One body = four input rows = two double-steps.  EDGE: per-lane / per-row validity checks on the stores.
+    auto body = [&](int it, auto edge) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge)::value;
+        const int cur = (it & 1) * 4 * ROWE, oth = ((it + 1) & 1) * 4 * ROWE;   // ring rows 4 it .. 4 it + 3 / the four after
+        // D: double-step index inside the body (0 | 1); d = 2 it + D is the global double-step: it reads input rows 2d, 2d+1,
+        // commits batch d + 2, loads batch d + 3, stores the tile of double-step d - 1 and runs the epilogues of output rows
+        // 2d - 2, 2d - 1 (relative; image row = sy - 1 + relative)
+        auto dstep = [&](auto Dtag) __attribute__((always_inline)) {
+            constexpr int D = decltype(Dtag)::value;
+            const int d = 2 * it + D;
+            // commit target: batch d + 2 = ring rows (4 it + 2 D + 4) % 8
+            bf16_t* commit_base = ring + (D == 0 ? oth : oth + 2 * ROWE);
+            const bf16_t* prev_tile = otile + ((d + 1) & 1) * (2 * TW * PXE);
+            bf16_t* ot = otile + (d & 1) * (2 * TW * PXE);
+            // Uniform values of the double-step; the schedule computes each next to its first use (all of them at the top would
+            // be ~60 scalar instructions in front of the first MFMA).
+            //   prev_row*: rows the previous double-step's tile goes to: relative 2d - 4 + g; anything above the segment (the
+            //     first two double-steps' tiles hold rows -4 .. 0) lands on image row sy, which this workgroup rewrites
+            //     afterwards with the real row (same lanes, same addresses, program order)
+            //   next_row*: the image rows of batch d + 3;  mrow*: sums mask of the output rows whose epilogue runs here
+            char *prev_row0 = nullptr, *prev_row1 = nullptr;
+            const char *next_row0 = nullptr, *next_row1 = nullptr;
+            float mrow[2] = {0.f, 0.f};
+            auto u_prev = [&](int g) __attribute__((always_inline)) {
+                char* r = ybu + (int64_t)max(sy - 5 + 2 * d + g, sy) * p.ys[1] * 2;
+                (g ? prev_row1 : prev_row0) = r;
+            };
+            auto u_next = [&](int g) __attribute__((always_inline)) {
+                const char* r = xbu + (int64_t)reflect(sy - 1 + 2 * (d + 3) + g, p.H) * p.xs[1] * 2;
+                (g ? next_row1 : next_row0) = r;
+            };
+            auto u_mask = [&](int g) __attribute__((always_inline)) {
+                const int orow = sy - 3 + 2 * d + g;
+                mrow[g] = (orow >= sy && orow < sy_end) ? 1.f : 0.f;
+            };
+            auto st_ok = [&](int n) __attribute__((always_inline)) {
+                const int opx = pl + 16 * n;
+                const int g = opx / TW, px = opx - g * TW;
+                const int orow = sy - 5 + 2 * d + g;
+                return (orow < sy_end) && (sx + px < p.W);
+            };
+            // epilogue slice: accumulator rows 4j..4j+3 of accumulator `nm` (output row g of this double-step's tile) ->
+            // GroupNorm sums, bf16, LDS tile
+            auto epi = [&](int nm, int g, int j) __attribute__((always_inline)) {
+                if (ABL & 2) {
+                    asm volatile("" ::"v"(acc[nm][j * 4]), "v"(acc[nm][j * 4 + 1]), "v"(acc[nm][j * 4 + 2]), "v"(acc[nm][j * 4 + 3]));
+                    return;
+                }
+                const f32x2_t v0 = f32x2_t{acc[nm][j * 4], acc[nm][j * 4 + 1]}, v1 = f32x2_t{acc[nm][j * 4 + 2], acc[nm][j * 4 + 3]};
+                bf16x4_t o;
+                o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
+                f32x2_t mv = f32x2_t{mrow[g], mrow[g]};
+                if constexpr (EDGE) mv = mv * lane_m;
+                s1p[j >> 1] += (v0 + v1) * mv;
+                s2p[j >> 1] += (v0 * v0 + v1 * v1) * mv;
+                *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
+            };
+            f32x2_t cy[4], cu[4];
+            uint32_t co[4];
+            u32x4_t stv = {0u, 0u, 0u, 0u};
+#define NAF_MFMA(accv, wv, bv, wcls) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : wcls(wv), "v"(bv))
+#define NAF_PIN1(a) asm volatile("" : "+v"(a))
+#define NAF_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define NAF_SLOT_PIN                                          \
+    do {                                                      \
+        if constexpr (!(ABL & 64)) __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+            if constexpr (D == 0) {
+#define NAF_ROWS_D 0
+#include "stem_rows_sched.inc"
+#undef NAF_ROWS_D
+            } else {
+#define NAF_ROWS_D 1
+#include "stem_rows_sched.inc"
+#undef NAF_ROWS_D
+            }
+#undef NAF_SLOT_PIN
+#undef NAF_PIN1
+#undef NAF_PIN2
+#undef NAF_MFMA
+            if (!(ABL & 32)) __syncthreads();
+        };
+        dstep(std::integral_constant<int, 0>{});
+        dstep(std::integral_constant<int, 1>{});
+    };
+
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool edge = (sx + TW > p.W) || ((sy_end - sy) % 4 != 0);
+    if (!edge) {
+        for (int it = 0; it < nbody; ++it) body(it, F{});
+    } else {
+        for (int it = 0; it < nbody; ++it) body(it, T{});
+    }
+    // the last double-step's tile: output rows (relative) 4 nbody - 4 + g; at most the first is inside the segment
+    {
+        const bf16_t* lt = otile + ((2 * nbody - 1) & 1) * (2 * TW * PXE);
+#pragma unroll
+        for (int n = 0; n < NST; ++n) {
+            const int opx = pl + 16 * n;
+            const int g = opx / TW, px = opx - g * TW;
+            const int orow = sy - 1 + 4 * nbody - 4 + g;
+            if (!(ABL & 8) && orow >= sy && orow < sy_end && sx + px < p.W) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lt + st_lds0 + 16 * n * PXE);
+                *reinterpret_cast<u32x4_t*>(ybu + (int64_t)orow * p.ys[1] * 2 + (n & 1) * st_px16 + st_goff0) = v;
+            }
+        }
+    }
+
+    if (p.stats_out) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float a = s1p[g][0] + s1p[g][1], q = s2p[g][0] + s2p[g][1];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_xor(a, o);
+                q += __shfl_xor(q, o);
+            }
+            if (lane == 0) {
+                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 0], (double)a);
+                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 1], (double)q);
+            }
+        }
+    }
+}
+}  // namespace stem_rows

@@ -12,7 +12,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
 
 // FILL: 0 nothing, 1 one ds_read_b128, 2 one v_fma, 3 two v_fma, 4 four v_fma, 5 one ds_read_b128 + two v_fma,
-//       6 six v_fma
+//       6 six v_fma, 7 one v_pk_fma_f32, 8 two v_pk_fma_f32, 9 one v_exp_f32, 10 one v_exp_f32 + one v_rcp_f32,
+//       11 two v_pk_mul_f32 + two v_fma (what a 2-element GroupNorm+SiLU slice looks like packed), 12 one v_cvt_pk_bf16_f32,
+//       13 one ds_write_b128, 14 two v_exp + two v_rcp
 template <int NACC, int FILL>
 __global__ __launch_bounds__(256, 1) void k(float* out, long long* ticks, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -26,6 +28,10 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* ticks, int it
         }
     float f[8];
     for (int i = 0; i < 8; ++i) f[i] = threadIdx.x * 0.001f + i;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t g2[4];
+    for (int i = 0; i < 4; ++i) g2[i] = f32x2_t{f[i] * 0.5f, f[i + 4] * 0.25f};
+    unsigned cv[2] = {0u, 0u};
     f32x4_t* lds = reinterpret_cast<f32x4_t*>(smem);
     lds[threadIdx.x] = f32x4_t{f[0], f[1], f[2], f[3]};
     __syncthreads();
@@ -39,9 +45,24 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* ticks, int it
             if (FILL == 1 || FILL == 5) {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(r4[m & 3]) : "v"((threadIdx.x & 63) * 16 + (m & 3) * 1024));
             }
-            constexpr int NF = FILL == 2 ? 1 : (FILL == 3 || FILL == 5) ? 2 : FILL == 4 ? 4 : FILL == 6 ? 6 : 0;
+            constexpr int NF = FILL == 2 ? 1 : (FILL == 3 || FILL == 5 || FILL == 11) ? 2 : FILL == 4 ? 4 : FILL == 6 ? 6 : 0;
 #pragma unroll
             for (int q = 0; q < NF; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[(q + m) & 7]));
+            constexpr int NPK = FILL == 7 ? 1 : FILL == 8 ? 2 : 0;
+#pragma unroll
+            for (int q = 0; q < NPK; ++q) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(g2[(q + m) & 3]));
+            if (FILL == 11) {
+                asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(g2[m & 3]));
+                asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(g2[(m + 1) & 3]));
+            }
+            if (FILL == 9 || FILL == 10 || FILL == 14) asm volatile("v_exp_f32 %0, %0" : "+v"(f[m & 7]));
+            if (FILL == 10 || FILL == 14) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[(m + 1) & 7]));
+            if (FILL == 14) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(f[(m + 2) & 7]));
+                asm volatile("v_rcp_f32 %0, %0" : "+v"(f[(m + 3) & 7]));
+            }
+            if (FILL == 12) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(cv[m & 1]) : "v"(f[m & 7]), "v"(f[(m + 1) & 7]));
+            if (FILL == 13) asm volatile("ds_write_b128 %0, %1" :: "v"((threadIdx.x & 63) * 16 + 8192 + (m & 3) * 1024), "v"(r4[m & 3]) : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -51,7 +72,8 @@ __global__ __launch_bounds__(256, 1) void k(float* out, long long* ticks, int it
     float s = 0;
     for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
     for (int i = 0; i < 8; ++i) s += f[i];
-    for (int q = 0; q < 4; ++q) s += r4[q][0] + r4[q][3];
+    for (int q = 0; q < 4; ++q) s += r4[q][0] + r4[q][3] + g2[q][0] + g2[q][1];
+    s += (float)(cv[0] ^ cv[1]);
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { ticks[blockIdx.x * 2] = t1 - t0; ticks[blockIdx.x * 2 + 1] = w1 - w0; }
 }
@@ -81,6 +103,13 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 64;
     float* out; long long* ticks;
     CK(hipMalloc(&out, 256 * 256 * 4)); CK(hipMalloc(&ticks, 512 * 8));
+    if (argc > 2) {   // the instruction-price list beside MFMAs (3 rotating accumulators, as in the row-streaming stem layer)
+        run<3, 0>(out, ticks, iters); run<3, 2>(out, ticks, iters); run<3, 3>(out, ticks, iters); run<3, 4>(out, ticks, iters);
+        run<3, 7>(out, ticks, iters); run<3, 8>(out, ticks, iters); run<3, 9>(out, ticks, iters); run<3, 10>(out, ticks, iters);
+        run<3, 14>(out, ticks, iters); run<3, 11>(out, ticks, iters); run<3, 12>(out, ticks, iters); run<3, 1>(out, ticks, iters);
+        run<3, 13>(out, ticks, iters); run<3, 0>(out, ticks, iters);
+        return 0;
+    }
     run<1, 0>(out, ticks, iters); run<1, 1>(out, ticks, iters); run<1, 2>(out, ticks, iters); run<1, 3>(out, ticks, iters);
     run<1, 4>(out, ticks, iters); run<1, 5>(out, ticks, iters); run<1, 6>(out, ticks, iters);
     run<2, 0>(out, ticks, iters); run<2, 1>(out, ticks, iters); run<2, 2>(out, ticks, iters); run<2, 3>(out, ticks, iters);

@@ -1,0 +1,96 @@
+// Stand-alone A/B + ablation probe: the row-streaming 3x3 stem layer (stem_rows_kernel.h, round 3) against the two-row-step
+// kernel of rounds 1-2 (stem_conv_kernel.h), interleaved on one lease, same tensors.  Not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inaf_amd/csrc tools/stem_rows_probe.hip -o tools/bin/stem_rows_probe
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "stem_conv_kernel.h"
+#include "stem_rows_kernel.h"
+
+void naf_set_error(const char* fmt, ...) { (void)fmt; }
+int naf_check_launch(const char* what) { (void)what; return 0; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+static hipEvent_t ev_a, ev_b;
+template <typename K>
+float time_kernel(K kern, size_t lds, StemConvParams p, int nb, int reps) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, p);
+    CK(hipEventRecord(ev_a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, p);
+    CK(hipEventRecord(ev_b)); CK(hipEventSynchronize(ev_b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, ev_a, ev_b));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int H = argc > 1 ? atoi(argv[1]) : 1024, W = argc > 2 ? atoi(argv[2]) : 1024, reps = argc > 3 ? atoi(argv[3]) : 10;
+    const int rounds = argc > 4 ? atoi(argv[4]) : 3;
+    CK(hipEventCreate(&ev_a)); CK(hipEventCreate(&ev_b));
+    const size_t n = (size_t)H * W * 128;
+    std::vector<uint16_t> hx(n);
+    uint32_t st = 777u;
+    for (auto& v : hx) { st = st * 1664525u + 1013904223u; union { float f; uint32_t u; } c; c.f = ((st >> 8) & 0xffff) / 32768.0f - 1.f; v = (uint16_t)(c.u >> 16); }
+    bf16_t *x, *y, *y2, *w; float *vec; double* stats;
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&y, n * 2)); CK(hipMalloc(&y2, n * 2)); CK(hipMalloc(&w, 9 * 128 * 128 * 2)); CK(hipMalloc(&vec, 3 * 128 * 4));
+    CK(hipMalloc(&stats, 8192 * 8)); CK(hipMemset(stats, 0, 8192 * 8));
+    CK(hipMemcpy(x, hx.data(), n * 2, hipMemcpyHostToDevice));
+    {   // weights: small values so that outputs stay O(1)
+        std::vector<uint16_t> hw(9 * 128 * 128);
+        for (auto& v : hw) { st = st * 1664525u + 1013904223u; union { float f; uint32_t u; } c; c.f = (((st >> 8) & 0xffff) / 32768.0f - 1.f) * 0.03f; v = (uint16_t)(c.u >> 16); }
+        CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
+    std::vector<float> hv(3 * 128, 0.5f);
+    for (int i = 0; i < 128; ++i) { hv[i] = 0.01f * (i % 7); hv[128 + i] = 1.0f + 0.01f * (i % 5); hv[256 + i] = 0.02f * (i % 3); }
+    CK(hipMemcpy(vec, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+    std::vector<double> hs(32);
+    for (int g = 0; g < 8; ++g) { hs[2 * g] = 0.0; hs[2 * g + 1] = (double)H * W * 16 * 0.33; }
+    CK(hipMemcpy(stats, hs.data(), 16 * 8, hipMemcpyHostToDevice));
+    StemConvParams p;
+    p.x = x; p.y = y; p.w = w; p.bias = vec; p.gamma = vec + 128; p.beta = vec + 256; p.stats_in = stats; p.stats_out = stats + 16;
+    p.B = 1; p.H = H; p.W = W; p.eps = 1e-5f;
+    p.xs[0] = (int64_t)n; p.xs[1] = (int64_t)W * 128; p.xs[2] = 128;
+    p.ys[0] = (int64_t)n; p.ys[1] = (int64_t)W * 128; p.ys[2] = 128;
+    p.tiles_x = (W + 31) / 32;
+    int segs = (256 + p.tiles_x - 1) / p.tiles_x;
+    int seg_h = (H + segs - 1) / segs; seg_h = ((seg_h + 3) / 4) * 4;
+    p.seg_h = seg_h; p.segs_y = (H + seg_h - 1) / seg_h;
+    const int nb = p.tiles_x * p.segs_y;
+    printf("image %dx%d, %d workgroups (%d strips x %d segments of %d rows); %d launches per timing, %d rounds\n", H, W, nb, p.tiles_x, p.segs_y, seg_h, reps, rounds);
+    using G = StemGeom<3>;
+    const size_t lds_old = (size_t)(G::RING * G::ROWE + 2 * RS * TW * PXE) * 2 + 3 * C * sizeof(float);
+    const size_t lds_new = stem_rows::LDS_BYTES;
+    const double flops = (double)H * W * 2 * 1152 * 128;
+    // parity of the two kernels on the same input (bf16 outputs; GroupNorm sums)
+    {
+        StemConvParams q = p; q.y = y2; q.stats_out = stats + 32;
+        CK(hipMemset(stats + 16, 0, 32 * 8));
+        time_kernel(stem_conv_kernel<3, 0, false>, lds_old, p, nb, 0);
+        time_kernel(stem_rows::stem_conv_rows_kernel<0>, lds_new, q, nb, 0);
+        CK(hipDeviceSynchronize());
+        std::vector<uint16_t> a(n), b(n);
+        CK(hipMemcpy(a.data(), y, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), y2, n * 2, hipMemcpyDeviceToHost));
+        size_t diff = 0; double maxd = 0;
+        for (size_t i = 0; i < n; ++i) if (a[i] != b[i]) {
+            ++diff; union { float f; uint32_t u; } c0, c1; c0.u = (uint32_t)a[i] << 16; c1.u = (uint32_t)b[i] << 16;
+            const double dd = fabs((double)c0.f - (double)c1.f); if (dd > maxd) maxd = dd;
+            if (diff <= 5) printf("   differ at px %zu ch %zu: old %.5f new %.5f\n", i / 128, i % 128, c0.f, c1.f);
+        }
+        double s[32]; CK(hipMemcpy(s, stats + 16, 32 * 8, hipMemcpyDeviceToHost));
+        printf("parity old vs new: %zu of %zu bf16 outputs differ (max |d| %.3e); sums old %.6e %.6e new %.6e %.6e\n", diff, n, maxd, s[0], s[1], s[16], s[17]);
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const float t_old = time_kernel(stem_conv_kernel<3, 0, false>, lds_old, p, nb, reps);
+        const float t_new = time_kernel(stem_rows::stem_conv_rows_kernel<0>, lds_new, p, nb, reps);
+        printf("round %d: two-row-step kernel %.4f ms (%.0f TF)   row-streaming kernel %.4f ms (%.0f TF)\n", r, t_old, flops / t_old / 1e9, t_new, flops / t_new / 1e9);
+    }
+    struct { const char* name; float ms; } abl[8];
+    int na = 0;
+#define RUN(A, NAME) abl[na].name = NAME; abl[na++].ms = time_kernel(stem_rows::stem_conv_rows_kernel<A>, lds_new, p, nb, reps);
+    RUN(0, "full") RUN(1, "no commit (GN+SiLU, ring writes)") RUN(2, "no epilogue") RUN(8, "no row stores") RUN(16, "no global loads")
+    RUN(27, "LDS reads + MFMA + barrier") RUN(31, "MFMA + barrier only") RUN(64, "full, no slot pins")
+    for (int i = 0; i < na; ++i) printf("row-streaming %-40s %.4f ms  %7.1f TFLOP/s\n", abl[i].name, abl[i].ms, flops / abl[i].ms / 1e9);
+    return 0;
+}
