@@ -23,6 +23,10 @@ ARCH = "gfx950"
 # of the register file; the weight-stationary 3x3 stem layer fills all 512 registers and keeps the default.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 NO_VGPR_FORM = {"stem_conv.hip"}
+# Per-file flags.  stem_conv.hip: the schedule's GroupNorm / SiLU / sums arithmetic is written as plain f32 operations on purpose
+# -- a packed v_pk_*_f32 beside an MFMA stalls the matrix pipe ~16 cycles (profiles/r03_mfma_filler_prices.txt) -- and the SLP
+# vectoriser would pack adjacent ones again.
+EXTRA_FLAGS = {"stem_conv.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -49,7 +53,7 @@ def _compile(src: str, force: bool, hdr_mtime: float, extra) -> str:
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(spath), hdr_mtime):
         return obj
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall",
-           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", *([] if src in NO_VGPR_FORM else VGPR_FORM), *extra, "-c", spath, "-o", obj]
+           "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}", *([] if src in NO_VGPR_FORM else VGPR_FORM), *EXTRA_FLAGS.get(src, []), *extra, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -70,12 +70,14 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
         p.seg_h = seg_h;
         p.segs_y = (a->H + seg_h - 1) / seg_h;
         const int64_t nbr = strips * p.segs_y;
-        const void* fn = reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0>);
+        const void* fn = plain ? reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0, true>)
+                               : reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0, false>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES) != hipSuccess) {
             naf_set_error("naf_stem_conv_fwd: cannot reserve %zu bytes of LDS", stem_rows::LDS_BYTES);
             return NAF_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(stem_rows::stem_conv_rows_kernel<0>, dim3((uint32_t)nbr), dim3(256), stem_rows::LDS_BYTES, s, p);
+        if (plain) hipLaunchKernelGGL((stem_rows::stem_conv_rows_kernel<0, true>), dim3((uint32_t)nbr), dim3(256), stem_rows::LDS_BYTES, s, p);
+        else hipLaunchKernelGGL((stem_rows::stem_conv_rows_kernel<0, false>), dim3((uint32_t)nbr), dim3(256), stem_rows::LDS_BYTES, s, p);
         return naf_check_launch("stem_conv_rows_kernel");
     }
     const size_t lds = stem_conv_lds<3>();

@@ -46,8 +46,10 @@ __device__ __forceinline__ int reflect(int i, int n) {
 }
 
 // ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue, 4 no
-// LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins
-template <int ABL = 0>
+// LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins, 128 cycle counter
+// PLAIN: no GroupNorm, no SiLU -- y = conv(x) (+ bias if given): the data gradient of a layer is this kernel on the output
+// gradient with the flipped, transposed weights (stats_in == NULL in the C ABI); the ring commit is then a copy.
+template <int ABL = 0, bool PLAIN = false>
 __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);                     // [RING][PXR][PXE]
@@ -67,11 +69,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     // input rows sy-1 .. sy_end (relative 0 .. rows+1); output row `rel` is complete after input row rel+1 and has its
     // epilogue during input row rel+2: rows+3 row-steps, rounded up to whole bodies of four
     const int nbody = (sy_end - sy + 3 + 3) / 4;
-    const bool plain = p.stats_in == nullptr;   // no GroupNorm, no SiLU: y = conv(x) (+ bias) -- the data-gradient pass
 
     const int chunk = tid & 15, pl = tid >> 4;
     if (tid < C) {
-        if (plain) {
+        if constexpr (PLAIN) {
             cvec[tid] = p.bias ? p.bias[tid] : 0.f;
             cvec[C + tid] = 1.f;
             cvec[2 * C + tid] = 0.f;
@@ -91,16 +92,15 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     }
     __syncthreads();
 
-    // GroupNorm scale / shift of this thread's 8 input channels; activation: out = y * rcp(dconst + exp2(y * c2)) with
-    // (c2, dconst) = (-log2 e, 1) = SiLU, or (0, 0) = identity (plain mode: exp2(0) = 1, rcp(1) = 1)
-    f32x2_t gav[4], gbv[4];
+    // GroupNorm scale / shift of this thread's 8 input channels, both times log2(e):  ys = log2e * GroupNorm(x) and
+    // SiLU = ys * rcp(log2e + log2e * exp2(-ys))  [= y / (1 + exp(-y))]
+    constexpr float kL = 1.4426950408889634f;
+    float gav[8], gbv[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        gav[e] = f32x2_t{cvec[C + chunk * 8 + 2 * e], cvec[C + chunk * 8 + 2 * e + 1]};
-        gbv[e] = f32x2_t{cvec[2 * C + chunk * 8 + 2 * e], cvec[2 * C + chunk * 8 + 2 * e + 1]};
+    for (int e = 0; e < 8; ++e) {
+        gav[e] = cvec[C + chunk * 8 + e] * kL;
+        gbv[e] = cvec[2 * C + chunk * 8 + e] * kL;
     }
-    const float c2 = plain ? 0.f : -1.4426950408889634f;
-    const float dconst = plain ? 0.f : 1.f;
     const char* xbu = reinterpret_cast<const char*>(p.x + (int64_t)b * p.xs[0]);
     char* ybu = reinterpret_cast<char*>(p.y + (int64_t)b * p.ys[0]);
 
@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         const int px = i % PXR;
         col_off[n] = (uint32_t)(reflect(sx - 1 + px, p.W) * (int)p.xs[2] + chunk * 8) * 2u;
     }
+    // Piece 2 straddles the batch's two rows (pl < 8: row 0, pixel 32 + pl; else row 1, pixel pl - 8).  Two consecutive input
+    // rows are one row stride apart in memory -- in either order under reflect padding --, so its lanes address the LOWER of
+    // the two row pointers plus, for the lanes whose row is the higher one, the row stride (one address mode for all loads:
+    // scalar base + 32-bit lane offset).
+    const bool straddle_hi = pl + 32 >= PXR;
+    const uint32_t col_off_s1 = col_off[2] + (uint32_t)(p.xs[1] * 2);
     // ring offset (elements) of piece n relative to the batch's first ring row: pieces 0, 1, 3, 4 are c_off0 plus a constant
     // (pixel pl + 16 n of the 80 never wraps for them), piece 2 straddles the two rows (pl < 8: row 0, pixel 32 + pl)
     const int c_off0 = pl * PXE + chunk * 8;
@@ -125,6 +131,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     const uint32_t st_goff0 = (uint32_t)((sx + pl) * (int)p.ys[2] + chunk * 8) * 2u;
     const int64_t st_px16 = (int64_t)16 * p.ys[2] * 2;   // uniform: bytes of 16 pixels of an output row
     u32x4_t ld[NLD];
+    u32x4_t ld_dummy[(ABL & 256) ? NLD : 1] = {};   // probe (ABL & 256): the loop's loads land here and are never consumed
+#define NAF_LD_DST(n) ((ABL & 256) ? ld_dummy[(ABL & 256) ? (n) : 0] : ld[n])
     // batch bt = input rows (relative) 2 bt, 2 bt + 1 = image rows reflect(sy - 1 + 2 bt + rr)
     auto issue_one = [&](int bt, int n) __attribute__((always_inline)) {
         const int rr = (pl + 16 * n) / PXR;
@@ -133,12 +141,16 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     };
     auto commit_one = [&](int bt, int n) __attribute__((always_inline)) {   // prologue only (the loop's commits are scheduled)
         const int slot = (2 * bt) % RING;
+        if constexpr (PLAIN) {
+            *reinterpret_cast<u32x4_t*>(ring + slot * ROWE + c_off(n)) = ld[n];
+            return;
+        }
         const bf16x8_t v = __builtin_bit_cast(bf16x8_t, ld[n]);
         bf16x8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float y = fmaf((float)v[e], gav[e >> 1][e & 1], gbv[e >> 1][e & 1]);
-            o[e] = (bf16_t)(y * __builtin_amdgcn_rcpf(dconst + __builtin_amdgcn_exp2f(y * c2)));
+        for (int e = 0; e < 8; ++e) {   // the schedule's arithmetic, operation for operation
+            const float ys = __builtin_fmaf((float)v[e], gav[e], gbv[e]);
+            o[e] = (bf16_t)(ys * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-ys), kL, kL)));
         }
         *reinterpret_cast<bf16x8_t*>(ring + slot * ROWE + c_off(n)) = o;
     };
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #pragma unroll
     for (int n = 0; n < NLD; ++n) issue_one(2, n);
 
-    f32x2_t s1p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}}, s2p[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};  // GroupNorm sums (pairs)
+    float s1p[2] = {0.f, 0.f}, s2p[2] = {0.f, 0.f};  // GroupNorm sums of the wave's two groups (plain f32: no packed VALU beside MFMAs)
     const int lane_b = n32 * PXE + half * 8;  // B-fragment lane offset inside a ring row (before the tap-column shift)
 
     // Accumulator row 4j + r of a 32x32 tile = output channel 32 wave + 8 j + 4 half + r.  All four start as the bias (finite
@@ -217,7 +229,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             //     afterwards with the real row (same lanes, same addresses, program order)
             //   next_row*: the image rows of batch d + 3;  mrow*: sums mask of the output rows whose epilogue runs here
             char *prev_row0 = nullptr, *prev_row1 = nullptr;
-            const char *next_row0 = nullptr, *next_row1 = nullptr;
+            const char *next_row0 = nullptr, *next_row1 = nullptr, *next_lo = nullptr;
+            bool next_flip = false;   // the batch's second row lies BELOW its first in memory (reflected border)
             float mrow[2] = {0.f, 0.f};
             auto u_prev = [&](int g) __attribute__((always_inline)) {
                 char* r = ybu + (int64_t)max(sy - 5 + 2 * d + g, sy) * p.ys[1] * 2;
@@ -226,6 +239,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             auto u_next = [&](int g) __attribute__((always_inline)) {
                 const char* r = xbu + (int64_t)reflect(sy - 1 + 2 * (d + 3) + g, p.H) * p.xs[1] * 2;
                 (g ? next_row1 : next_row0) = r;
+                if (g) {
+                    next_flip = next_row1 < next_row0;
+                    next_lo = next_flip ? next_row1 : next_row0;
+                }
             };
             auto u_mask = [&](int g) __attribute__((always_inline)) {
                 const int orow = sy - 3 + 2 * d + g;
@@ -237,28 +254,60 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
                 const int orow = sy - 5 + 2 * d + g;
                 return (orow < sy_end) && (sx + px < p.W);
             };
+// the MFMA opens its slot: without the barrier behind it hipcc is free to put the slot's side work in FRONT of it, i.e. into the
+// previous gap, and two gaps' worth of transcendentals then sit between one pair of MFMAs
+#define NAF_MFMA(accv, wv, bv, wcls)                                                                              \
+    do {                                                                                                          \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : wcls(wv), "v"(bv));              \
+        if constexpr (!(ABL & 64)) __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+// 16 bytes into the ring as two ds_write_b64: a ds_write_b128 beside an MFMA stalls the matrix pipe ~21 cycles, a ds_write_b64 does
+// not (profiles/r03_mfma_filler_prices.txt).  volatile: hipcc does not fuse volatile stores back into one ds_write_b128, and --
+// unlike asm stores -- still counts them in its lgkmcnt bookkeeping (uncounted LDS operations make every fragment wait cover two
+// operations too many, i.e. wait for fragments requested a slot ago).
+#define NAF_LDS_WRITE_2X64(ptr, a0, a1, a2, a3)                                                   \
+    do {                                                                                          \
+        bf16_t* d_ = (ptr);                                                                       \
+        *((volatile NAF_LDS u32x2_t*)(d_)) = u32x2_t{a0, a1};                                     \
+        *((volatile NAF_LDS u32x2_t*)(d_ + 4)) = u32x2_t{a2, a3};                                 \
+    } while (0)
+#define NAF_PIN1(a) asm volatile("" : "+v"(a))
+#define NAF_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
             // epilogue slice: accumulator rows 4j..4j+3 of accumulator `nm` (output row g of this double-step's tile) ->
-            // GroupNorm sums, bf16, LDS tile
-            auto epi = [&](int nm, int g, int j) __attribute__((always_inline)) {
+            // GroupNorm sums, bf16, LDS tile; three micro-ops of four plain VALU instructions each
+            float e_a = 0.f, e_q = 0.f;
+            auto epi0 = [&](int nm, int g, int j) __attribute__((always_inline)) {
                 if (ABL & 2) {
                     asm volatile("" ::"v"(acc[nm][j * 4]), "v"(acc[nm][j * 4 + 1]), "v"(acc[nm][j * 4 + 2]), "v"(acc[nm][j * 4 + 3]));
                     return;
                 }
-                const f32x2_t v0 = f32x2_t{acc[nm][j * 4], acc[nm][j * 4 + 1]}, v1 = f32x2_t{acc[nm][j * 4 + 2], acc[nm][j * 4 + 3]};
                 bf16x4_t o;
-                o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
-                f32x2_t mv = f32x2_t{mrow[g], mrow[g]};
-                if constexpr (EDGE) mv = mv * lane_m;
-                s1p[j >> 1] += (v0 + v1) * mv;
-                s2p[j >> 1] += (v0 * v0 + v1 * v1) * mv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[nm][j * 4 + r];
                 *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
+                e_a = acc[nm][j * 4] + acc[nm][j * 4 + 1];
+                NAF_PIN1(e_a);
             };
-            f32x2_t cy[4], cu[4];
+            auto epi1 = [&](int nm, int g, int j) __attribute__((always_inline)) {
+                if (ABL & 2) return;
+                e_a += acc[nm][j * 4 + 2];
+                e_a += acc[nm][j * 4 + 3];
+                e_q = acc[nm][j * 4] * acc[nm][j * 4];
+                e_q = __builtin_fmaf(acc[nm][j * 4 + 1], acc[nm][j * 4 + 1], e_q);
+                NAF_PIN2(e_a, e_q);
+            };
+            auto epi2 = [&](int nm, int g, int j) __attribute__((always_inline)) {
+                if (ABL & 2) return;
+                e_q = __builtin_fmaf(acc[nm][j * 4 + 2], acc[nm][j * 4 + 2], e_q);
+                e_q = __builtin_fmaf(acc[nm][j * 4 + 3], acc[nm][j * 4 + 3], e_q);
+                const float m = EDGE ? mrow[g] * lane_m : mrow[g];
+                s1p[j >> 1] = __builtin_fmaf(e_a, m, s1p[j >> 1]);
+                s2p[j >> 1] = __builtin_fmaf(e_q, m, s2p[j >> 1]);
+                NAF_PIN2(s1p[j >> 1], s2p[j >> 1]);
+            };
+            float cy[8], cu[8];
             uint32_t co[4];
             u32x4_t stv = {0u, 0u, 0u, 0u};
-#define NAF_MFMA(accv, wv, bv, wcls) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : wcls(wv), "v"(bv))
-#define NAF_PIN1(a) asm volatile("" : "+v"(a))
-#define NAF_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #define NAF_SLOT_PIN                                          \
     do {                                                      \
         if constexpr (!(ABL & 64)) __builtin_amdgcn_sched_barrier(0); \
@@ -276,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #undef NAF_PIN1
 #undef NAF_PIN2
 #undef NAF_MFMA
+#undef NAF_LDS_WRITE_2X64
             if (!(ABL & 32)) __syncthreads();
         };
         dstep(std::integral_constant<int, 0>{});
@@ -285,10 +335,20 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     using T = std::true_type;
     using F = std::false_type;
     const bool edge = (sx + TW > p.W) || ((sy_end - sy) % 4 != 0);
+    long long tm0 = 0;
+    if constexpr ((ABL & 128) != 0) tm0 = (long long)__builtin_readcyclecounter();
     if (!edge) {
         for (int it = 0; it < nbody; ++it) body(it, F{});
     } else {
         for (int it = 0; it < nbody; ++it) body(it, T{});
+    }
+    if constexpr ((ABL & 256) != 0) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) asm volatile("" ::"v"(ld_dummy[n]));
+    }
+    if constexpr ((ABL & 128) != 0) {   // probe: shader cycles per double-step of this wave (stats_out + 64 .. are scratch there)
+        const long long tm1 = (long long)__builtin_readcyclecounter();
+        if (lane == 0 && blockIdx.x < 64) p.stats_out[64 + blockIdx.x * 4 + wave] = (double)(tm1 - tm0) / (2.0 * nbody);
     }
     // the last double-step's tile: output rows (relative) 4 nbody - 4 + g; at most the first is inside the segment
     {
@@ -308,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     if (p.stats_out) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            float a = s1p[g][0] + s1p[g][1], q = s2p[g][0] + s2p[g][1];
+            float a = s1p[g], q = s2p[g];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 a += __shfl_xor(a, o);

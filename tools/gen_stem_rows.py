@@ -21,7 +21,11 @@ import sys
 NB = 3                      # B-fragment buffers
 NLD, NST = 5, 4
 NSLOT = 144
-CAP = int(os.environ.get("NAF_ROWS_CAP", "4"))
+# Placement budget per MFMA gap, in issue cycles of one wave (profiles/r03_mfma_filler_prices.txt: a v_mfma_f32_32x32x16_bf16 issues
+# every 32 cycles; beside it a plain VALU costs ~5.3 cycles of the wave's issue, a transcendental ~9, LDS / scalar / VMEM
+# instructions a few): what does not fit the gap delays the next MFMA.
+CAP = float(os.environ.get("NAF_ROWS_CAP", "25"))
+V, TR, LR, LW, SA, VL, VS = 5.3, 9.0, 4.0, 5.0, 2.0, 8.0, 10.0   # plain VALU, transcendental, ds_read, ds_write_b64, SALU, load, store
 
 def build(D):
     load = [0] * NSLOT                      # non-MFMA instructions already in the slot
@@ -31,7 +35,7 @@ def build(D):
     # fragment requests: behind the last use (u == 2) of every fragment
     for k in range(NSLOT):
         if k % 3 == 2:
-            load[k] += 1
+            load[k] += LR
 
     def place(cost, earliest, where=None):
         k = max(0, earliest)
@@ -45,36 +49,36 @@ def build(D):
     for tt in range(2):
         nm = (2 * D + tt + 2) & 3
         k = 72 * tt + 3            # its last MFMA was slot 69 of the row before
-        ku = place(2, k - 2)
+        ku = place(6 * SA, k - 2)
         ops[ku].append(("uni", f"u_mask({tt});"))
         for j in range(4):
-            k = place(4, k + 1)    # 8 instructions: two slots' worth; occupy this slot and the next
-            load[min(k + 1, NSLOT - 1)] += 4 if k + 1 < NSLOT else 0
-            ops[k].append(("epi", f"epi({nm}, {tt}, {j});"))
-            k += 1
+            # 12 plain instructions per slice, emitted as three micro-ops in consecutive slots
+            for part in range(3):
+                k = place((3 * V + LW) if part == 0 else 4 * V, k + 1)
+                ops[k].append(("epi", f"epi{part}({nm}, {tt}, {j});"))
         # bias back into the accumulator: it is `sta` (tap row 0) of the next input row
         for j in range(4):
-            k = place(1, k + 1)
+            k = place(LR, k + 1)
             ops[k].append(("epi", f"acc_init({nm}, {j});"))
         assert k < 72 * (tt + 1) - 4, "accumulator re-initialisation too late"
 
     # ---- row stores of the previous tile ----
     k = 40
     for n in range(NST):
-        k = place(1, k + 1)
+        k = place(LR, k + 1)
         if n % 2 == 0:      # the row pointer of this tile row, just ahead of its first store
-            ku = place(3, max(k - 3, 0))
+            ku = place(10 * SA, max(k - 3, 0))
             ops[ku].append(("uni", f"u_prev({n // 2});"))
             k = max(k, ku)
         pre[k].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds0 + {16 * n} * PXE);"))
-        k2 = place(1, k + 2)
-        ops[k2].append(("store", f"if (!EDGE || st_ok({n})) *reinterpret_cast<u32x4_t*>(prev_row{n // 2} + {'st_px16 + ' if n % 2 else ''}st_goff0) = stv;"))
+        k2 = place(VS + V, k + 6)     # the tile read has to come back first: LDS latency, in order behind the fragment reads
+        ops[k2].append(("store", f"if (!EDGE || st_ok({n})) {{ uint32_t o_ = st_goff0; NAF_PIN1(o_); *reinterpret_cast<u32x4_t*>(prev_row{n // 2} + {'st_px16 + ' if n % 2 else ''}o_) = stv; }}"))
         k = k2
 
     # ---- commits (one variable set: piece n+1 starts after piece n has stored) ----
     start = 1
     for n in range(NLD):
-        start = max(start, 1 + 28 * n)      # spread the pieces over the double-step
+        start = max(start, 1 + 27 * n)      # spread the pieces over the double-step
         cy, cu, co = "cy", "cu", "co"
         t = {}
         def put(name, cost, earliest, code, kind="commit"):
@@ -83,29 +87,41 @@ def build(D):
             t[name] = k
             return k
         if n in (0, 2):      # image-row pointers of batch d + 3: rows 0 / 1 are first needed by the reloads of pieces 0 / 2
-            ku = place(3, max(start - 1, 0))
+            ku = place(12 * SA, max(start - 1, 0))
             ops[ku].append(("uni", f"u_next({n // 2});"))
+        # Plain (non-packed) f32 VALU only: a v_pk_*_f32 beside an MFMA stalls the matrix pipe ~16 cycles, a plain v_fma does
+        # not (profiles/r03_mfma_filler_prices.txt).  ys = log2(e) * GroupNorm(x) (the scale is folded into gav / gbv), so
+        # SiLU(y) = ys * rcp(log2e + log2e * exp2(-ys)): the exp2's negation is an input modifier, the "1 +" an fma.
         for p in range(4):
             a_earliest = start if p == 0 else t[f"A{p - 1}"]
-            put(f"A{p}", 2, a_earliest,
-                f"{{ const uint32_t w_ = ld[{n}][{p}]; {cy}[{p}] = f32x2_t{{__uint_as_float(w_ << 16), __uint_as_float(w_ & 0xffff0000u)}}; NAF_PIN1({cy}[{p}]); }}")
+            put(f"A{p}", 2 * V, a_earliest,
+                f"{{ const uint32_t w_ = ld[{n}][{p}]; cy[{2 * p}] = __uint_as_float(w_ << 16); cy[{2 * p + 1}] = __uint_as_float(w_ & 0xffff0000u); "
+                f"NAF_PIN2(cy[{2 * p}], cy[{2 * p + 1}]); }}")
         # the piece's registers are free again: reload them with the same piece of batch d + 3
         r_lo, r_hi = (16 * n) // 40, (16 * n + 15) // 40
-        base = f"next_row{r_lo}" if r_lo == r_hi else f"(pl + {16 * n} >= PXR ? next_row1 : next_row0)"
-        put("L", 1, t["A3"], f"ld[{n}] = *reinterpret_cast<const u32x4_t*>({base} + col_off[{n}]);", kind="load")
+        ops[t["A0"]].append(("copy", f"NAF_LDS_WRITE_2X64(commit_base + c_off({n}), ld[{n}][0], ld[{n}][1], ld[{n}][2], ld[{n}][3]);"))
+        if r_lo == r_hi:
+            put("L", VL + V, t["A3"],
+                f"{{ uint32_t o_ = col_off[{n}]; NAF_PIN1(o_); NAF_LD_DST({n}) = *reinterpret_cast<const u32x4_t*>(next_row{r_lo} + o_); }}", kind="load")
+        else:   # the piece that straddles the batch's two rows: one base (the lower row), the row stride in the lane's offset
+            put("L", VL + 2 * V, t["A3"],
+                f"{{ uint32_t o_ = (straddle_hi != next_flip) ? col_off_s1 : col_off[{n}]; NAF_PIN1(o_); "
+                f"NAF_LD_DST({n}) = *reinterpret_cast<const u32x4_t*>(next_lo + o_); }}", kind="load")
         for p in range(4):
-            put(f"B{p}", 2, t[f"A{p}"] + 1,
-                f"{{ {cy}[{p}] = {cy}[{p}] * gav[{p}] + gbv[{p}]; {cu}[{p}] = {cy}[{p}] * c2; NAF_PIN2({cy}[{p}], {cu}[{p}]); }}")
-            put(f"C{p}", 2, t[f"B{p}"] + 1,
-                f"{{ {cu}[{p}] = f32x2_t{{__builtin_amdgcn_exp2f({cu}[{p}][0]), __builtin_amdgcn_exp2f({cu}[{p}][1])}}; NAF_PIN1({cu}[{p}]); }}")
-            put(f"D{p}", 1, t[f"C{p}"] + 2, f"{{ {cu}[{p}] = {cu}[{p}] + dconst; NAF_PIN1({cu}[{p}]); }}")
-            put(f"E{p}", 2, t[f"D{p}"] + 1,
-                f"{{ {cu}[{p}] = f32x2_t{{__builtin_amdgcn_rcpf({cu}[{p}][0]), __builtin_amdgcn_rcpf({cu}[{p}][1])}}; NAF_PIN1({cu}[{p}]); }}")
-            put(f"F{p}", 2, t[f"E{p}"] + 2,
-                f"{{ const f32x2_t r_ = {cy}[{p}] * {cu}[{p}]; bf16x2_t o_; o_[0] = (bf16_t)r_[0]; o_[1] = (bf16_t)r_[1]; "
-                f"{co}[{p}] = __builtin_bit_cast(uint32_t, o_); NAF_PIN1({co}[{p}]); }}")
-        g = put("G", 1, max(t[f"F{p}"] for p in range(4)) + 1,
-                f"*reinterpret_cast<u32x4_t*>(commit_base + c_off({n})) = u32x4_t{{{co}[0], {co}[1], {co}[2], {co}[3]}};")
+            a, b = 2 * p, 2 * p + 1
+            put(f"B{p}", 2 * V, t[f"A{p}"] + 1,
+                f"{{ cy[{a}] = __builtin_fmaf(cy[{a}], gav[{a}], gbv[{a}]); cy[{b}] = __builtin_fmaf(cy[{b}], gav[{b}], gbv[{b}]); NAF_PIN2(cy[{a}], cy[{b}]); }}")
+            for q, e in enumerate((a, b)):     # one transcendental per micro-op: two of them and anything else overfill a gap
+                put(f"C{p}{q}", TR, t[f"B{p}"] + 1, f"{{ cu[{e}] = __builtin_amdgcn_exp2f(-cy[{e}]); NAF_PIN1(cu[{e}]); }}")
+            put(f"D{p}", 2 * V, max(t[f"C{p}0"], t[f"C{p}1"]) + 2,
+                f"{{ cu[{a}] = __builtin_fmaf(cu[{a}], kL, kL); cu[{b}] = __builtin_fmaf(cu[{b}], kL, kL); NAF_PIN2(cu[{a}], cu[{b}]); }}")
+            for q, e in enumerate((a, b)):
+                put(f"E{p}{q}", TR, t[f"D{p}"] + 1, f"{{ cu[{e}] = __builtin_amdgcn_rcpf(cu[{e}]); NAF_PIN1(cu[{e}]); }}")
+            put(f"F{p}", 3 * V, max(t[f"E{p}0"], t[f"E{p}1"]) + 2,
+                f"{{ const float r0_ = cy[{a}] * cu[{a}], r1_ = cy[{b}] * cu[{b}]; bf16x2_t o_; o_[0] = (bf16_t)r0_; o_[1] = (bf16_t)r1_; "
+                f"co[{p}] = __builtin_bit_cast(uint32_t, o_); NAF_PIN1(co[{p}]); }}")
+        g = put("G", 2 * LW + 2 * V, max(t[f"F{p}"] for p in range(4)) + 1,
+                f"NAF_LDS_WRITE_2X64(commit_base + c_off({n}), co[0], co[1], co[2], co[3]);")
         start = g + 1
     last_commit = start
 
@@ -149,8 +165,10 @@ def build(D):
                 out.append(code)
             elif kind == "load":
                 out.append(f"if constexpr (!(ABL & 16)) {{ {code} }}")
+            elif kind == "copy":
+                out.append(f"if constexpr (PLAIN && !(ABL & 1)) {{ {code} }}")
             else:
-                out.append(f"if constexpr (!(ABL & 1)) {{ {code} }}")
+                out.append(f"if constexpr (!PLAIN && !(ABL & 1)) {{ {code} }}")
         out.append("NAF_SLOT_PIN;")
     return out, load, last_commit
 
@@ -170,4 +188,4 @@ if len(sys.argv) > 1:
     path = sys.argv[1]
 with open(path, "w") as fh:
     fh.write("\n".join(text) + "\n")
-print(f"wrote {path}: 2 x {NSLOT} slots, cap {CAP}; (max per slot, total side instructions, commits done by slot): {stats}")
+print(f"wrote {path}: 2 x {NSLOT} slots, cap {CAP} cycles; (max per slot, total side cycles, commits done by slot): {[(round(a, 1), round(b), c) for a, b, c in stats]}")

@@ -86,11 +86,19 @@ int main(int argc, char** argv) {
         const float t_new = time_kernel(stem_rows::stem_conv_rows_kernel<0>, lds_new, p, nb, reps);
         printf("round %d: two-row-step kernel %.4f ms (%.0f TF)   row-streaming kernel %.4f ms (%.0f TF)\n", r, t_old, flops / t_old / 1e9, t_new, flops / t_new / 1e9);
     }
-    struct { const char* name; float ms; } abl[8];
+    struct { const char* name; float ms; double cyc; } abl[16];
     int na = 0;
-#define RUN(A, NAME) abl[na].name = NAME; abl[na++].ms = time_kernel(stem_rows::stem_conv_rows_kernel<A>, lds_new, p, nb, reps);
-    RUN(0, "full") RUN(1, "no commit (GN+SiLU, ring writes)") RUN(2, "no epilogue") RUN(8, "no row stores") RUN(16, "no global loads")
-    RUN(27, "LDS reads + MFMA + barrier") RUN(31, "MFMA + barrier only") RUN(64, "full, no slot pins")
-    for (int i = 0; i < na; ++i) printf("row-streaming %-40s %.4f ms  %7.1f TFLOP/s\n", abl[i].name, abl[i].ms, flops / abl[i].ms / 1e9);
+    auto cycles = [&]() {   // mean shader cycles per double-step over the first 64 workgroups' waves (ABL & 128 variants)
+        double h[256]; CK(hipMemcpy(h, stats + 16 + 64, sizeof(h), hipMemcpyDeviceToHost));
+        double a = 0; for (int i = 0; i < 256; ++i) a += h[i];
+        return a / 256;
+    };
+#define RUN(A, NAME) abl[na].name = NAME; abl[na].ms = time_kernel(stem_rows::stem_conv_rows_kernel<(A) | 128>, lds_new, p, nb, reps); abl[na++].cyc = cycles();
+    RUN(0, "full") RUN(64, "full, no slot pins") RUN(1, "no commit (GN+SiLU, ring writes)") RUN(2, "no epilogue") RUN(8, "no row stores") RUN(16, "no global loads")
+    RUN(24, "no global loads, no row stores") RUN(27, "LDS reads + MFMA + barrier") RUN(31, "MFMA + barrier only") RUN(27 + 64, "LDS reads + MFMA + barrier, no pins")
+    RUN(256, "full, loads issued but never consumed") RUN(25, "epilogue + LDS reads + MFMA") RUN(26, "commit + LDS reads + MFMA") RUN(0, "full")
+    for (int i = 0; i < na; ++i)
+        printf("row-streaming %-40s %.4f ms  %7.1f TFLOP/s  %7.0f cycles per double-step (144 MFMAs = 4608)  => %.2f GHz\n", abl[i].name, abl[i].ms,
+               flops / abl[i].ms / 1e9, abl[i].cyc, abl[i].cyc * 2.0 * ((p.seg_h + 6) / 4) / (abl[i].ms * 1e6));
     return 0;
 }
