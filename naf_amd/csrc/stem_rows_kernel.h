@@ -156,16 +156,18 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     };
 
     // prologue: batches 0, 1 (input rows 0..3) into ring slots 0..3, batch 2 in flight
+    u32x4_t ld1[NLD];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int n = 0; n < NLD; ++n) issue_one(0, n);
 #pragma unroll
-        for (int n = 0; n < NLD; ++n) issue_one(k, n);
-#pragma unroll
-        for (int n = 0; n < NLD; ++n) commit_one(k, n);
+    for (int n = 0; n < NLD; ++n) {
+        const int rr = (pl + 16 * n) / PXR;
+        ld1[n] = *reinterpret_cast<const u32x4_t*>(xbu + (int64_t)reflect(sy - 1 + 2 + rr, p.H) * p.xs[1] * 2 + col_off[n]);
     }
-    __syncthreads();
-    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic
     __builtin_amdgcn_sched_barrier(0);
+    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic.  Requested behind
+    // the prologue's input loads (memory operations retire in order: the prologue must not wait for 295 KB of weights) and
+    // ahead of its arithmetic; they land in AGPRs (the asm MFMAs' operand class), so that arithmetic does not compete with them.
     bf16x8_t wreg[72];
     {
         const bf16_t* wp = p.w + (size_t)(wave * 32 + n32) * C + half * 8;
@@ -175,6 +177,14 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             for (int ks = 0; ks < 8; ++ks)
                 wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) commit_one(0, n);
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) ld[n] = ld1[n];
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) commit_one(1, n);
+    __syncthreads();
     // The weights are consumed by asm MFMAs inside the loop: without this wait hipcc cannot prove them resident at the loop
     // header and guards every use with a vmcnt wait sized for the loop's own loads and stores (which then never overlap).
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
