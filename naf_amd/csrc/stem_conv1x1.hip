@@ -44,6 +44,9 @@ constexpr int C1 = 128, WROW = C1 + 8, OROW1 = C1 + 8;
 #ifndef NAF_C1X1_NW
 #define NAF_C1X1_NW 4
 #endif
+#ifndef NAF_C1_ABL
+#define NAF_C1_ABL 0   // measurement builds only (tools/c1x1_ablation.sh): 1 no GroupNorm/SiLU arithmetic, 2 no MFMAs, 4 no sums, 8 no stores, 16 no loads
+#endif
 constexpr int NW1 = NAF_C1X1_NW;   // waves per workgroup: they share one LDS copy of the weights; 4 waves x 2 workgroups per CU measured faster than 12 x 1 (0.119 vs 0.128 ms): the layer is VALU/transcendental-bound, not latency-bound
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         // GroupNorm affine + SiLU in registers, then into the wave's LDS tile as [px][ch]
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            if constexpr (PLAIN) {
+            if constexpr (PLAIN || (NAF_C1_ABL & 1)) {
                 *reinterpret_cast<u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8) = raw[it];
                 continue;
             }
@@ -263,8 +266,9 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         // have the MFMA / epilogue / store part of this group to land and are consumed by the next transform, whose
         // vmcnt wait then leaves this group's eight stores in flight).
         __builtin_amdgcn_sched_barrier(0);
+        // (a second register set with the group AFTER next in flight was measured in round 3: +-0, gpurun r9s)
         if constexpr (IMG) load_taps(g + gstride, sv);
-        else load_group(g + gstride, raw);
+        else if constexpr (!(NAF_C1_ABL & 16)) load_group(g + gstride, raw);
         __builtin_amdgcn_sched_barrier(0);
         // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each
 #pragma unroll
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const bf16x8_t wa = *reinterpret_cast<const bf16x8_t*>(wl + (m * 32 + n32) * WROW + ks * 16 + half * 8);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bf, acc[m], 0, 0, 0);
+                if constexpr (!(NAF_C1_ABL & 2)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bf, acc[m], 0, 0, 0);
+                else asm volatile("" ::"v"(wa), "v"(bf));
             }
         }
         // epilogue: bias, GroupNorm sums, bf16 -> the wave's LDS tile (a lane outside the image adds zeros)
@@ -289,8 +294,10 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                     bf16x4_t o;
                     o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
                     const f32x2_t w0 = FULL ? v0 : v0 * vmask, w1 = FULL ? v1 : v1 * vmask;
-                    s1p[m * 2 + (j >> 1)] += w0 + w1;
-                    s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
+                    if constexpr (!(NAF_C1_ABL & 4)) {
+                        s1p[m * 2 + (j >> 1)] += w0 + w1;
+                        s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
+                    }
                     *reinterpret_cast<bf16x4_t*>(otw + n32 * OROW1 + 32 * m + 8 * j + 4 * half) = o;
                 }
             // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
@@ -300,7 +307,8 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8);
-                    *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + lane_y) = v;
+                    if constexpr (!(NAF_C1_ABL & 8)) *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + lane_y) = v;
+                    else asm volatile("" ::"v"(v));
                 }
                 return;
             }
