@@ -117,8 +117,12 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         const int gc = g < ngroups ? g : ngroups - 1;
         if (DENSE || (xdense && gc < nfull)) {
             const char* xg = reinterpret_cast<const char*>(p.x + b * p.xs[0] + (int64_t)gc * 32 * p.xs[2]);
+            // scalar base + 32-bit lane offset addressing: the asm keeps the offset's zero-extension next to the access (hoisted out
+            // of the loop as a 64-bit pair, every access becomes a v_lshl_add_u64 plus a 64-bit-address instruction)
+            uint32_t lx = lane_x;
+            asm volatile("" : "+v"(lx));
 #pragma unroll
-            for (int it = 0; it < 8; ++it) raw[it] = *reinterpret_cast<const u32x4_t*>(xg + (int64_t)it * 8 * p.xs[2] + lane_x);
+            for (int it = 0; it < 8; ++it) raw[it] = *reinterpret_cast<const u32x4_t*>(xg + (uint32_t)(lx + (uint32_t)(it * 8 * (int)p.xs[2])));
             return;
         }
         if constexpr (!DENSE) {
@@ -304,10 +308,12 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             bf16_t* yb = p.y + b * p.ys[0];
             if (FULL && (DENSE || ydense)) {
                 char* yg = reinterpret_cast<char*>(yb + (int64_t)g * 32 * p.ys[2]);
+                uint32_t ly = lane_y;
+                asm volatile("" : "+v"(ly));
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8);
-                    if constexpr (!(NAF_C1_ABL & 8)) *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + lane_y) = v;
+                    if constexpr (!(NAF_C1_ABL & 8)) *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + ly) = v;
                     else asm volatile("" ::"v"(v));
                 }
                 return;

@@ -1,4 +1,4 @@
-// Launch parameters shared by the 3x3 stem-layer kernels (stem_rows_kernel.h, stem_conv_kernel.h).
+// Launch parameters of the 3x3 stem-layer kernel (stem_rows_kernel.h; tools/stem_rows_probe.hip fills them by hand).
 #pragma once
 #include "naf_common.h"
 

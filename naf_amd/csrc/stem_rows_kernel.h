@@ -1,5 +1,5 @@
 // GroupNorm -> SiLU -> Conv3x3(128 -> 128, reflect), weight-stationary on the matrix pipe, ROW-STREAMING (round 3).
-// Kernel of naf_stem_conv_fwd for ksize 3 (convolutions.py:52-61); a header so that tools/stem_probe.hip can instantiate
+// Kernel of naf_stem_conv_fwd for ksize 3 (convolutions.py:52-61); a header so that tools/stem_rows_probe.hip can instantiate
 // ablation variants.
 //
 // Why this shape.  The chip is power-limited under this layer (tools/mfma_chain_probe.hip: the matrix pipe issues every

@@ -1,12 +1,12 @@
-// Stand-alone A/B + ablation probe: the row-streaming 3x3 stem layer (stem_rows_kernel.h, round 3) against the two-row-step
-// kernel of rounds 1-2 (stem_conv_kernel.h), interleaved on one lease, same tensors.  Not part of the library.
+// Stand-alone ablation probe of the row-streaming 3x3 stem layer (stem_rows_kernel.h): time and shader cycles per double-step with
+// parts of the step switched off.  Not part of the library.  (Round 3 also ran the two-row-step kernel of rounds 1-2 beside it,
+// interleaved on one lease: profiles/r03_stem_rows_probe.txt.)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Inaf_amd/csrc tools/stem_rows_probe.hip -o tools/bin/stem_rows_probe
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 
-#include "stem_conv_kernel.h"
 #include "stem_rows_kernel.h"
 
 void naf_set_error(const char* fmt, ...) { (void)fmt; }
@@ -59,33 +59,9 @@ int main(int argc, char** argv) {
     p.seg_h = seg_h; p.segs_y = (H + seg_h - 1) / seg_h;
     const int nb = p.tiles_x * p.segs_y;
     printf("image %dx%d, %d workgroups (%d strips x %d segments of %d rows); %d launches per timing, %d rounds\n", H, W, nb, p.tiles_x, p.segs_y, seg_h, reps, rounds);
-    using G = StemGeom<3>;
-    const size_t lds_old = (size_t)(G::RING * G::ROWE + 2 * RS * TW * PXE) * 2 + 3 * C * sizeof(float);
     const size_t lds_new = stem_rows::LDS_BYTES;
     const double flops = (double)H * W * 2 * 1152 * 128;
-    // parity of the two kernels on the same input (bf16 outputs; GroupNorm sums)
-    {
-        StemConvParams q = p; q.y = y2; q.stats_out = stats + 32;
-        CK(hipMemset(stats + 16, 0, 32 * 8));
-        time_kernel(stem_conv_kernel<3, 0, false>, lds_old, p, nb, 0);
-        time_kernel(stem_rows::stem_conv_rows_kernel<0>, lds_new, q, nb, 0);
-        CK(hipDeviceSynchronize());
-        std::vector<uint16_t> a(n), b(n);
-        CK(hipMemcpy(a.data(), y, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), y2, n * 2, hipMemcpyDeviceToHost));
-        size_t diff = 0; double maxd = 0;
-        for (size_t i = 0; i < n; ++i) if (a[i] != b[i]) {
-            ++diff; union { float f; uint32_t u; } c0, c1; c0.u = (uint32_t)a[i] << 16; c1.u = (uint32_t)b[i] << 16;
-            const double dd = fabs((double)c0.f - (double)c1.f); if (dd > maxd) maxd = dd;
-            if (diff <= 5) printf("   differ at px %zu ch %zu: old %.5f new %.5f\n", i / 128, i % 128, c0.f, c1.f);
-        }
-        double s[32]; CK(hipMemcpy(s, stats + 16, 32 * 8, hipMemcpyDeviceToHost));
-        printf("parity old vs new: %zu of %zu bf16 outputs differ (max |d| %.3e); sums old %.6e %.6e new %.6e %.6e\n", diff, n, maxd, s[0], s[1], s[16], s[17]);
-    }
-    for (int r = 0; r < rounds; ++r) {
-        const float t_old = time_kernel(stem_conv_kernel<3, 0, false>, lds_old, p, nb, reps);
-        const float t_new = time_kernel(stem_rows::stem_conv_rows_kernel<0>, lds_new, p, nb, reps);
-        printf("round %d: two-row-step kernel %.4f ms (%.0f TF)   row-streaming kernel %.4f ms (%.0f TF)\n", r, t_old, flops / t_old / 1e9, t_new, flops / t_new / 1e9);
-    }
+    (void)y2; (void)rounds;
     struct { const char* name; float ms; double cyc; } abl[16];
     int na = 0;
     auto cycles = [&]() {   // mean shader cycles per double-step over the first 64 workgroups' waves (ABL & 128 variants)
