@@ -107,12 +107,58 @@ void run_ord(char* o, const char* q, int reps, const char* name) {
     float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 53 * 1024, 0, o, q, grid); }, reps);
     printf("order %-44s %.4f ms %7.1f GB/s\n", name, ms, 2.0 * 1024 * 1024 * (256 + 768) / ms / 1e6);
 }
+
+// a workgroup that owns ALL FOUR heads of a cell.  Every pixel row of the cell then leaves as 16 px x 1536 B
+// = 24 KB contiguous (the (cell, head) decomposition writes 384-byte pieces of 1536-byte pixel rows) and the queries arrive as
+// whole 512-byte pixels.  NW waves, a wave takes pixel rows w, w + NW, ...; G: cells per XCD turn of the dispatch order
+// (0 = plain dispatch order); LDSKB bounds the residency the way four resident K/V windows would (4 x 27 KB).
+template <int NW, int G, int LDSKB>
+__global__ __launch_bounds__(NW * 64) void k_allheads(char* __restrict__ out, const char* __restrict__ q, uint32_t nblocks) {
+    constexpr int lr = 64, d = 16, qpx = 512, opx = 1536;
+    extern __shared__ char lds_[];
+    if (LDSKB && threadIdx.x == 9999) lds_[0] = 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t L = blockIdx.x;
+    if (G > 0) { const uint32_t xcd = L & 7u, idx = L >> 3; L = ((idx / G) * 8u + xcd) * G + idx % G; }
+    const int cx = L % lr, cy = L / lr;
+    const int64_t qrow = (int64_t)lr * d * qpx, orow = (int64_t)lr * d * opx;
+    for (int t = wave; t < d; t += NW) {
+        const int64_t y = (int64_t)cy * d + t, x0 = (int64_t)cx * d;
+        // 16 px x 512 B of queries = 8 KB = 8 x 1 KB wave loads
+        const char* qp = q + y * qrow + x0 * qpx + lane * 16;
+        u32x4_t a = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a ^= *reinterpret_cast<const u32x4_t*>(qp + c * 1024);
+        // 16 px x 1536 B = 24 KB contiguous = 24 x 1 KB wave stores
+        char* ob = out + y * orow + x0 * opx + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) *reinterpret_cast<u32x4_t*>(ob + c * 1024) = a;
+    }
+}
+template <int NW, int G, int LDSKB>
+void run_allheads(char* o, const char* q, int reps) {
+    const uint32_t grid = 64 * 64;
+    auto kern = k_allheads<NW, G, LDSKB>;
+    if (LDSKB) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSKB * 1024));
+    float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDSKB * 1024, 0, o, q, grid); }, reps);
+    printf("all-heads-of-a-cell wg: %2d waves, groups of %2d cells per XCD turn, lds %3d KiB: %.4f ms %7.1f GB/s\n", NW, G, LDSKB, ms,
+           2.0 * 1024 * 1024 * (256 + 768) / ms / 1e6);
+}
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const size_t nq = (size_t)1024 * 1024 * 512, no = (size_t)1024 * 1024 * 1536;
     char *q, *o;
     CK(hipMalloc(&q, nq)); CK(hipMalloc(&o, no));
     CK(hipMemset(q, 1, nq));
+    if (argc > 2 && argv[2][0] == 'a') {   // all four heads of a cell per workgroup, beside the shipped (cell, head) order on the same lease
+        for (int r = 0; r < 3; ++r) {
+            run_ord<2, 16>(o, q, reps, "(cell, head) workgroups, groups of 16 [the shipped kernel's shape]");
+            run_allheads<4, 0, 0>(o, q, reps); run_allheads<4, 4, 0>(o, q, reps); run_allheads<4, 16, 0>(o, q, reps);
+            run_allheads<8, 0, 0>(o, q, reps); run_allheads<8, 4, 0>(o, q, reps); run_allheads<16, 4, 0>(o, q, reps);
+            run_allheads<4, 4, 53>(o, q, reps); run_allheads<8, 4, 78>(o, q, reps); run_allheads<8, 4, 140>(o, q, reps); run_allheads<16, 4, 140>(o, q, reps);
+        }
+        return 0;
+    }
     if (argc > 2) {
         for (int r = 0; r < 2; ++r) {
             run_ord<0, 1>(o, q, reps, "(cy, cx, head) dispatch order");
