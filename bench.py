@@ -357,7 +357,7 @@ def main():
             if os.path.exists(tpath):
                 try:
                     ent = json.load(open(tpath)).get(args.workload)
-                    if isinstance(ent, dict):        # PMC bytes of ONE image's launch (profiles/r02_pmc_hbm_traffic.txt) x images per launch
+                    if isinstance(ent, dict):        # PMC bytes of ONE image's launch (profiles/r03_pmc_hbm_traffic.txt) x images per launch
                         traffic, kname = int(ent["bytes"]) * mb, ent.get("kernel", kname)
                     elif ent is not None:
                         traffic = int(ent) * mb
@@ -365,7 +365,7 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r02_pmc_hbm_traffic.txt" if traffic else None,
+                    "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r03_pmc_hbm_traffic.txt" if traffic else None,
                     "kernel": kname,
                     "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
                     # the same kernel against the matrix pipe (large windows approach the MFMA ridge):
