@@ -218,8 +218,14 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #pragma unroll
     for (int f = 0; f < NB; ++f) load_frag(0, f, bb[f]);
 
+    // loop-carried uniform row pointers / masks of the double-steps (see u_all)
+    char *prev_row0 = ybu, *prev_row1 = ybu;
+    const char *next_row0 = xbu, *next_row1 = xbu, *next_lo = xbu;
+    bool next_flip = false;   // the batch's second row lies BELOW its first in memory (reflected border)
+    float mrow[2] = {0.f, 0.f};
+    const int64_t in_step = p.xs[1] * 4, out_step = p.ys[1] * 4;   // two rows, in bytes
     // One body = four input rows = two double-steps.  EDGE: per-lane / per-row validity checks on the stores.
-    auto body = [&](int it, auto edge) __attribute__((always_inline)) {
+    auto body = [&](int it, auto edge, auto first_half_only) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge)::value;
         const int cur = (it & 1) * 4 * ROWE, oth = ((it + 1) & 1) * 4 * ROWE;   // ring rows 4 it .. 4 it + 3 / the four after
         // D: double-step index inside the body (0 | 1); d = 2 it + D is the global double-step: it reads input rows 2d, 2d+1,
@@ -232,31 +238,31 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             bf16_t* commit_base = ring + (D == 0 ? oth : oth + 2 * ROWE);
             const bf16_t* prev_tile = otile + ((d + 1) & 1) * (2 * TW * PXE);
             bf16_t* ot = otile + (d & 1) * (2 * TW * PXE);
-            // Uniform values of the double-step; the schedule computes each next to its first use (all of them at the top would
-            // be ~60 scalar instructions in front of the first MFMA).
+            // Uniform values of the double-step (loop-carried scalars, declared in front of the loop):
             //   prev_row*: rows the previous double-step's tile goes to: relative 2d - 4 + g; anything above the segment (the
             //     first two double-steps' tiles hold rows -4 .. 0) lands on image row sy, which this workgroup rewrites
             //     afterwards with the real row (same lanes, same addresses, program order)
             //   next_row*: the image rows of batch d + 3;  mrow*: sums mask of the output rows whose epilogue runs here
-            char *prev_row0 = nullptr, *prev_row1 = nullptr;
-            const char *next_row0 = nullptr, *next_row1 = nullptr, *next_lo = nullptr;
-            bool next_flip = false;   // the batch's second row lies BELOW its first in memory (reflected border)
-            float mrow[2] = {0.f, 0.f};
-            auto u_prev = [&](int g) __attribute__((always_inline)) {
-                char* r = ybu + (int64_t)max(sy - 5 + 2 * d + g, sy) * p.ys[1] * 2;
-                (g ? prev_row1 : prev_row0) = r;
-            };
-            auto u_next = [&](int g) __attribute__((always_inline)) {
-                const char* r = xbu + (int64_t)reflect(sy - 1 + 2 * (d + 3) + g, p.H) * p.xs[1] * 2;
-                (g ? next_row1 : next_row0) = r;
-                if (g) {
+            // In the interior of the image and of the segment every pointer simply advances by two rows (8 scalar adds); only
+            // the first four double-steps, and the ones whose batch reaches the bottom border or whose epilogue rows leave the
+            // segment, recompute them with reflect / clamp (~60 scalar multiplies and selects: as much issue time as the five
+            // loads and four stores of a double-step cost all together before round 3 made this incremental).
+            auto u_all = [&]() __attribute__((always_inline)) {
+                const bool steady = d >= 4 && (sy + 2 * d + 6 <= p.H - 1) && (sy - 2 + 2 * d < sy_end);
+                if (__builtin_expect(steady, 1)) {
+                    next_row0 += in_step; next_row1 += in_step; next_lo += in_step;
+                    prev_row0 += out_step; prev_row1 += out_step;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        (g ? prev_row1 : prev_row0) = ybu + (int64_t)max(sy - 5 + 2 * d + g, sy) * p.ys[1] * 2;
+                        (g ? next_row1 : next_row0) = xbu + (int64_t)reflect(sy - 1 + 2 * (d + 3) + g, p.H) * p.xs[1] * 2;
+                        const int orow = sy - 3 + 2 * d + g;
+                        mrow[g] = (orow >= sy && orow < sy_end) ? 1.f : 0.f;
+                    }
                     next_flip = next_row1 < next_row0;
                     next_lo = next_flip ? next_row1 : next_row0;
                 }
-            };
-            auto u_mask = [&](int g) __attribute__((always_inline)) {
-                const int orow = sy - 3 + 2 * d + g;
-                mrow[g] = (orow >= sy && orow < sy_end) ? 1.f : 0.f;
             };
             auto st_ok = [&](int n) __attribute__((always_inline)) {
                 const int opx = pl + 16 * n;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             if (!(ABL & 32)) __syncthreads();
         };
         dstep(std::integral_constant<int, 0>{});
-        dstep(std::integral_constant<int, 1>{});
+        if constexpr (!decltype(first_half_only)::value) dstep(std::integral_constant<int, 1>{});
     };
 
     using T = std::true_type;
@@ -348,9 +354,13 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     long long tm0 = 0;
     if constexpr ((ABL & 128) != 0) tm0 = (long long)__builtin_readcyclecounter();
     if (!edge) {
-        for (int it = 0; it < nbody; ++it) body(it, F{});
+        // Whole strip, rows a multiple of four: the last body stops after its first double-step (input rows R, R + 1 for R rows:
+        // the last real output row R is complete then) and the epilogue of that row runs below without the two drain row-steps
+        // a whole body would spend on it (132 row-steps for 128 rows -> 130).
+        for (int it = 0; it < nbody - 1; ++it) body(it, F{}, F{});
+        body(nbody - 1, F{}, T{});
     } else {
-        for (int it = 0; it < nbody; ++it) body(it, T{});
+        for (int it = 0; it < nbody; ++it) body(it, T{}, F{});
     }
     if constexpr ((ABL & 256) != 0) {
 #pragma unroll
@@ -358,10 +368,45 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     }
     if constexpr ((ABL & 128) != 0) {   // probe: shader cycles per double-step of this wave (stats_out + 64 .. are scratch there)
         const long long tm1 = (long long)__builtin_readcyclecounter();
-        if (lane == 0 && blockIdx.x < 64) p.stats_out[64 + blockIdx.x * 4 + wave] = (double)(tm1 - tm0) / (2.0 * nbody);
+        if (lane == 0 && blockIdx.x < 64) p.stats_out[64 + blockIdx.x * 4 + wave] = (double)(tm1 - tm0) / (edge ? 2.0 * nbody : 2.0 * nbody - 1.0);
     }
-    // the last double-step's tile: output rows (relative) 4 nbody - 4 + g; at most the first is inside the segment
-    {
+    if (!edge) {
+        // tail of a whole segment (R = sy_end - sy rows, R % 4 == 0): output row R (relative) = image row sy_end - 1 sits complete in
+        // accumulator 0 (R & 3); tile 0 holds rows R - 2, R - 1 from the last double-step's epilogues.  Epilogue of the last row
+        // into tile 1, then both tiles leave.
+        bf16_t* t1 = otile + (2 * TW * PXE);
+        if (!(ABL & 2)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4_t o;
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[0][j * 4 + r];
+                    o[r] = (bf16_t)v;
+                    a += v;
+                    q = __builtin_fmaf(v, v, q);
+                }
+                s1p[j >> 1] += a;
+                s2p[j >> 1] += q;
+                *reinterpret_cast<bf16x4_t*>(t1 + n32 * PXE + wave * 32 + 8 * j + 4 * half) = o;
+            }
+        }
+        __syncthreads();
+        if (!(ABL & 8)) {
+#pragma unroll
+            for (int n = 0; n < NST; ++n) {   // tile 0: rows sy_end - 3, sy_end - 2
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otile + st_lds0 + 16 * n * PXE);
+                *reinterpret_cast<u32x4_t*>(ybu + (int64_t)(sy_end - 3 + n / 2) * p.ys[1] * 2 + (n & 1) * st_px16 + st_goff0) = v;
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {     // tile 1, first row: image row sy_end - 1
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(t1 + st_lds0 + 16 * n * PXE);
+                *reinterpret_cast<u32x4_t*>(ybu + (int64_t)(sy_end - 1) * p.ys[1] * 2 + (n & 1) * st_px16 + st_goff0) = v;
+            }
+        }
+    } else {
+        // the last double-step's tile: output rows (relative) 4 nbody - 4 + g; at most the first is inside the segment
         const bf16_t* lt = otile + ((2 * nbody - 1) & 1) * (2 * TW * PXE);
 #pragma unroll
         for (int n = 0; n < NST; ++n) {

@@ -45,12 +45,14 @@ def build(D):
         load[k] += cost
         return k
 
+    # ---- the double-step's uniform row pointers and masks: first thing behind the first MFMA ----
+    load[0] += 10 * SA
+    ops[0].append(("uni", "u_all();"))
+
     # ---- epilogues: output row tt of the tile = accumulator (2 D + tt + 2) & 3, during input row tt ----
     for tt in range(2):
         nm = (2 * D + tt + 2) & 3
         k = 72 * tt + 3            # its last MFMA was slot 69 of the row before
-        ku = place(6 * SA, k - 2)
-        ops[ku].append(("uni", f"u_mask({tt});"))
         for j in range(4):
             # 12 plain instructions per slice, emitted as three micro-ops in consecutive slots
             for part in range(3):
@@ -66,10 +68,6 @@ def build(D):
     k = 40
     for n in range(NST):
         k = place(LR, k + 1)
-        if n % 2 == 0:      # the row pointer of this tile row, just ahead of its first store
-            ku = place(10 * SA, max(k - 3, 0))
-            ops[ku].append(("uni", f"u_prev({n // 2});"))
-            k = max(k, ku)
         pre[k].append(("store", f"stv = *reinterpret_cast<const u32x4_t*>(prev_tile + st_lds0 + {16 * n} * PXE);"))
         k2 = place(VS + V, k + 6)     # the tile read has to come back first: LDS latency, in order behind the fragment reads
         ops[k2].append(("store", f"if (!EDGE || st_ok({n})) {{ uint32_t o_ = st_goff0; NAF_PIN1(o_); *reinterpret_cast<u32x4_t*>(prev_row{n // 2} + {'st_px16 + ' if n % 2 else ''}o_) = stv; }}"))
@@ -86,9 +84,6 @@ def build(D):
             ops[k].append((kind, code))
             t[name] = k
             return k
-        if n in (0, 2):      # image-row pointers of batch d + 3: rows 0 / 1 are first needed by the reloads of pieces 0 / 2
-            ku = place(12 * SA, max(start - 1, 0))
-            ops[ku].append(("uni", f"u_next({n // 2});"))
         # Plain (non-packed) f32 VALU only: a v_pk_*_f32 beside an MFMA stalls the matrix pipe ~16 cycles, a plain v_fma does
         # not (profiles/r03_mfma_filler_prices.txt).  ys = log2(e) * GroupNorm(x) (the scale is folded into gav / gbv), so
         # SiLU(y) = ys * rcp(log2e + log2e * exp2(-ys)): the exp2's negation is an input modifier, the "1 +" an fma.
