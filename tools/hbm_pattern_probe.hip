@@ -144,12 +144,57 @@ void run_allheads(char* o, const char* q, int reps) {
     printf("all-heads-of-a-cell wg: %2d waves, groups of %2d cells per XCD turn, lds %3d KiB: %.4f ms %7.1f GB/s\n", NW, G, LDSKB, ms,
            2.0 * 1024 * 1024 * (256 + 768) / ms / 1e6);
 }
+
+// The shipped (cell, head) shape once more, but every access as scalar base + 32-bit lane offset (the wave index through
+// readfirstlane, so that hipcc keeps the row bases in SGPRs) instead of a 64-bit address per lane.
+template <int G>
+__global__ __launch_bounds__(256) void k_ord_saddr(char* __restrict__ out, const char* __restrict__ q, uint32_t nblocks) {
+    constexpr int lr = 64, d = 16, heads = 4, qpx = 512, opx = 1536;
+    extern __shared__ char lds_[];
+    if (threadIdx.x == 9999) lds_[0] = 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t L = blockIdx.x;
+    { const uint32_t xcd = L & 7u, idx = L >> 3; L = ((idx / G) * 8u + xcd) * G + idx % G; }
+    const int head = L % heads; L /= heads;
+    const int cx = L % lr, cy = L / lr;
+    const int64_t qrow = (int64_t)lr * d * qpx, orow = (int64_t)lr * d * opx;
+    const uint32_t qoff = (uint32_t)((lane & 15) * qpx + (lane >> 4) * 16);
+    uint32_t ooff[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const int i = c * 64 + lane, px = i / 24, ch = i - px * 24; ooff[c] = (uint32_t)(px * opx + ch * 16); }
+    for (int t = wave; t < d; t += 4) {
+        const int64_t y = (int64_t)cy * d + t, x0 = (int64_t)cx * d;
+        const char* qp = q + y * qrow + x0 * qpx + head * 128;          // uniform
+        uint32_t qo = qoff; asm volatile("" : "+v"(qo));
+        u32x4_t a = *reinterpret_cast<const u32x4_t*>(qp + qo);
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qp + 64 + qo);
+        a ^= b;
+        char* ob = out + y * orow + x0 * opx + head * 384;               // uniform
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { uint32_t o = ooff[c]; asm volatile("" : "+v"(o)); *reinterpret_cast<u32x4_t*>(ob + o) = a; }
+    }
+}
+template <int G>
+void run_ord_saddr(char* o, const char* q, int reps) {
+    const uint32_t grid = 64 * 64 * 4;
+    auto kern = k_ord_saddr<G>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024));
+    float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 53 * 1024, 0, o, q, grid); }, reps);
+    printf("order (cell, head), groups of %2d, scalar base + 32-bit lane offsets        %.4f ms %7.1f GB/s\n", G, ms, 2.0 * 1024 * 1024 * (256 + 768) / ms / 1e6);
+}
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     const size_t nq = (size_t)1024 * 1024 * 512, no = (size_t)1024 * 1024 * 1536;
     char *q, *o;
     CK(hipMalloc(&q, nq)); CK(hipMalloc(&o, no));
     CK(hipMemset(q, 1, nq));
+    if (argc > 2 && argv[2][0] == 's') {   // addressing form of the shipped shape
+        for (int r = 0; r < 4; ++r) {
+            run_ord<2, 16>(o, q, reps, "(cell, head), groups of 16, 64-bit lane addresses");
+            run_ord_saddr<16>(o, q, reps);
+        }
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'a') {   // all four heads of a cell per workgroup, beside the shipped (cell, head) order on the same lease
         for (int r = 0; r < 3; ++r) {
             run_ord<2, 16>(o, q, reps, "(cell, head) workgroups, groups of 16 [the shipped kernel's shape]");
