@@ -1172,6 +1172,35 @@ def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
     assert m._forward_plan(img, ft, (96, 128)) is None
 
 
+def test_single_call_forward_phase_events(dev):
+    """naf_forward_args.phase_events (round 3): events recorded at the phase boundaries of the ONE call are in stream order, their
+    phases add up to the call, the result is the same with and without them, and NULL entries are skipped."""
+    from naf_amd import ops
+    p = O.make_params(seed=44)
+    m = _load_model(dev, p, kernel_size=7)
+    img = O.hash_normal((1, 3, 256, 256), 971).to(dev)
+    ft = O.hash_normal((1, 128, 16, 16), 972).to(dev).to(torch.bfloat16)
+    plan = m._forward_plan(img, ft, (256, 256))
+    assert plan is not None
+    base = plan.run(img, ft).clone()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    for e in ev:
+        e.record()
+    torch.cuda.synchronize()
+    out = plan.run(img, ft, phase_events=ev)
+    torch.cuda.synchronize()
+    assert torch.equal(out, base)
+    gaps = [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
+    assert all(g >= 0.0 for g in gaps), gaps
+    total = ev[0].elapsed_time(ev[6])
+    assert total > 0.0 and abs(sum(gaps) - total) <= 1e-3 + 0.05 * total
+    assert gaps[3] > gaps[2] and gaps[5] > 0.0          # the 3x3 branch's layers outweigh its first convolution; attention ran
+    sparse = [None, None, ev[2], None, ev[4]]           # only some boundaries asked for
+    assert torch.equal(plan.run(img, ft, phase_events=sparse), base)
+    torch.cuda.synchronize()
+    assert ev[2].elapsed_time(ev[4]) > 0.0
+
+
 @pytest.mark.parametrize("hw,lr,C,ksz,path", [
     ((70, 84), (5, 6), 128, 5, "mfma"),        # 14x14 cells: cell kernel, queries materialised (tiles straddle rows)
     ((64, 64), (28, 28), 128, 9, "union"),     # non-integer ratio: index tables built on the device

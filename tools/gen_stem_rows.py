@@ -10,10 +10,13 @@ pinned behind the MFMA of its slot (sched_barrier + asm register anchors), a few
 The body is two double-steps (D = 0, 1) of 144 MFMA slots = 2 input rows x 24 fragments x 3 output rows.  Input row t
 (t = 2 D + tt, names mod 4) feeds accumulator (t-1)&3 with tap row 2 (that output row is finished by it), t&3 with tap row 1
 and (t+1)&3 with tap row 0 (that row starts here, from the conv bias); accumulator (t+2)&3 -- output row t-2 -- has its
-epilogue during row t and is then re-initialised with the bias straight from the LDS.  Side work of a double-step: GroupNorm +
-SiLU + ring write of the five 16-byte pieces of batch d+2, their reload with batch d+3 right after they are unpacked, the four
-row-store pieces of the previous tile, eight epilogue slices.  Placement: greedy, earliest slot with room (CAP non-MFMA
-instructions per slot), respecting the dependency gaps below.
+epilogue during row t and is then re-initialised with the bias straight from the LDS.  Side work of a double-step: the scalar
+row pointers / masks (u_all, slot 0), GroupNorm + SiLU + ring write of the five 16-byte pieces of batch d+2 (plain f32 VALU only,
+ONE transcendental per micro-op), their reload with batch d+3 right after they are unpacked, the four row-store pieces of the
+previous tile (tile read six slots ahead of its store), eight epilogue slices of three micro-ops each.  Placement: greedy, earliest
+slot whose ISSUE-CYCLE budget (CAP cycles of the 32 an MFMA lasts) still has room, costs from profiles/r03_mfma_filler_prices.txt
+(plain VALU 5.3, transcendental 9, LDS / scalar / VMEM a few), respecting the dependency gaps below.  The MFMA macro of the kernel
+puts a sched_barrier behind every MFMA and NAF_SLOT_PIN one behind every slot, so what is placed here is what issues there.
 """
 import os
 import sys
