@@ -140,6 +140,45 @@ def cpu_baseline(C, ksz, lr, out, budget_s=25.0):
     return res
 
 
+def measure_traffic_live(workload, per_gpu_batch, timeout_s=90):
+    """HBM bytes of ONE launch of the attention kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
+    share a pass: TCC slot limit) of this very script on 3 steps, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
+    tallies 128-byte read requests at 64 bytes: x2).  Returns (bytes, kernel name) or None when rocprofv3 is not available or a
+    pass fails -- the caller then falls back to the number committed in profiles/traffic.json and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    vals, kname = {}, None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="naf_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--per-gpu-batch", str(per_gpu_batch), "--steps", "3",
+                   "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "xna_" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        got.append(float(row["Counter_Value"]))
+                        kname = row["Kernel_Name"].split("(")[0][:90]
+            if not got:
+                return None
+            vals[ctr] = sum(got) / len(got)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(vals["WRITE_SIZE"] * 1024 + 2 * vals["FETCH_SIZE"] * 1024), kname
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +196,8 @@ def main():
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="multi-GPU runs: skip rank 0's solo run of the whole batch")
     ap.add_argument("--cpu-baseline-budget", type=float, default=25.0, help="seconds of host time for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc sub-runs "
+                    "(two passes of ~15 s after the timed region, one GPU only); use the number committed in profiles/traffic.json")
     ap.add_argument("--attention-only", action="store_true", help="time only RoPE'd-Q -> output (scope A)")
     ap.add_argument("--no-fuse-rope", action="store_true", help="materialise the rotated queries (A/B against rotate-on-load)")
     ap.add_argument("--no-fuse-conv0", action="store_true", help="store the 1x1 branch's conv0 activation (A/B against recompute)")
@@ -352,9 +393,14 @@ def main():
         roof = None
         if xna_ms:
             ach = alg / (xna_ms * 1e-3) / 1e9
-            traffic, kname = None, "xna_mfma_kernel"
+            traffic, kname, tsrc = None, "xna_mfma_kernel", None
+            if world == 1 and not args.no_live_traffic and not args.attention_only and not args.graph:
+                live = measure_traffic_live(args.workload, B)
+                if live is not None:
+                    traffic, kname = live
+                    tsrc = "measured in this run: rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean per launch of the attention kernel"
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if traffic is None and os.path.exists(tpath):
                 try:
                     ent = json.load(open(tpath)).get(args.workload)
                     if isinstance(ent, dict):        # PMC bytes of ONE image's launch (profiles/r03_pmc_hbm_traffic.txt) x images per launch
@@ -365,7 +411,7 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r03_pmc_hbm_traffic.txt" if traffic else None,
+                    "traffic_source": tsrc or ("committed constant: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r03_pmc_hbm_traffic.txt" if traffic else None),
                     "kernel": kname,
                     "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
                     # the same kernel against the matrix pipe (large windows approach the MFMA ridge):

@@ -11,9 +11,9 @@ R=$PWD
 out=$R/gpurun_out/r03prof
 rm -rf $out; mkdir -p $out
 python bench.py > $out/bench_line.json 2> $out/bench.err
-python bench.py --no-cpu-baseline --phase-every 1 > $out/bench_line_all_phases.json 2>> $out/bench.err
+python bench.py --no-cpu-baseline --no-live-traffic --phase-every 1 > $out/bench_line_all_phases.json 2>> $out/bench.err
 tail -1 $out/bench_line.json | cut -c1-400
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --no-cpu-baseline > $out/trace.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --no-cpu-baseline --no-live-traffic > $out/trace.log 2>&1)
 grep '^{"metric"' $out/trace.log | tail -1 > $out/bench_line_under_rocprof.json
 f=$(ls $out/trace/*/*kernel_stats.csv | head -1)
 python3 - "$f" > $out/kernel_stats.csv <<'PY'
@@ -27,7 +27,7 @@ cat $out/kernel_stats.csv
 for w in G1 G2-k7 G2-k11 G2-k15 G3 G4 REF448; do
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$out/pmc_${w}_$c
-    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $d.log 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > $d.log 2>&1)
   done
 done
 python3 - $out > $out/pmc_hbm_traffic.txt <<'PY'

@@ -10,7 +10,7 @@ mkdir -p $out
 i=0
 for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/p$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1) || echo "pass $i failed"
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/p$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > $out/p$i.log 2>&1) || echo "pass $i failed"
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
