@@ -274,16 +274,30 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         if constexpr (IMG) load_taps(g + gstride, sv);
         else if constexpr (!(NAF_C1_ABL & 16)) load_group(g + gstride, raw);
         __builtin_amdgcn_sched_barrier(0);
-        // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each
+        // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each.  The five fragment
+        // reads of k-step ks + 1 are requested BEFORE the four MFMAs of k-step ks (two register sets, pinned by sched_barriers):
+        // left to itself hipcc issues each weight fragment right in front of its MFMA, i.e. every second MFMA waits a whole LDS
+        // round trip (round 3: the 32 MFMAs of a group took ~3x their 1024 cycles).
+        {
+            bf16x8_t bfr[2], war[2][4];
+            auto frag = [&](int ks, int slot) __attribute__((always_inline)) {
+                bfr[slot] = *reinterpret_cast<const bf16x8_t*>(otw + n32 * OROW1 + ks * 16 + half * 8);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(otw + n32 * OROW1 + ks * 16 + half * 8);
+                for (int m = 0; m < 4; ++m) war[slot][m] = *reinterpret_cast<const bf16x8_t*>(wl + (m * 32 + n32) * WROW + ks * 16 + half * 8);
+            };
+            frag(0, 0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const bf16x8_t wa = *reinterpret_cast<const bf16x8_t*>(wl + (m * 32 + n32) * WROW + ks * 16 + half * 8);
-                if constexpr (!(NAF_C1_ABL & 2)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, bf, acc[m], 0, 0, 0);
-                else asm volatile("" ::"v"(wa), "v"(bf));
+            for (int ks = 0; ks < 8; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < 8) frag(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if constexpr (!(NAF_C1_ABL & 2)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(war[ks & 1][m], bfr[ks & 1], acc[m], 0, 0, 0);
+                    else asm volatile("" ::"v"(war[ks & 1][m]), "v"(bfr[ks & 1]));
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: bias, GroupNorm sums, bf16 -> the wave's LDS tile (a lane outside the image adds zeros)
         const bool full = DENSE || g < nfull;
