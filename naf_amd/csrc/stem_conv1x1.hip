@@ -49,8 +49,15 @@ constexpr int C1 = 128, WROW = C1 + 8, OROW1 = C1 + 8;
 #endif
 constexpr int NW1 = NAF_C1X1_NW;   // waves per workgroup: they share one LDS copy of the weights; 4 waves x 2 workgroups per CU measured faster than 12 x 1 (0.119 vs 0.128 ms): the layer is VALU/transcendental-bound, not latency-bound
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+constexpr float kLog2e = 1.4426950408889634f;
 }  // namespace
+
+#ifdef NAF_C1_TIMING   // tools/c1x1_probe.hip: s_memtime sums per wave and phase (every timer drains the wave's LDS queue: a measurement build)
+__device__ unsigned long long g_c1_tim[4096 * 8];
+#define C1_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define C1_T(i) do { } while (0)
+#endif
 
 // DENSE: rows are dense in x and y and H*W is a multiple of 32 -> every group is complete, one uniform base + one
 // constant lane offset per access, a branch-free loop body (which also keeps hipcc's vmcnt waits exact).
@@ -59,6 +66,9 @@ __device__ __forceinline__ float silu1(float v) { return v * __builtin_amdgcn_rc
 template <bool IMG, typename T, bool DENSE, bool PLAIN = false>
 __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_kernel(const StemConv1Params p) {
     static_assert(!(IMG && PLAIN), "the recomputed-conv0 input exists for the forward layer only");
+#ifdef NAF_C1_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* wl = reinterpret_cast<bf16_t*>(smem);                           // [128][WROW] weights
     bf16_t* ot = wl + C1 * WROW;                                            // [NW1 waves][32][OROW1]
@@ -68,31 +78,6 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: group indices and base addresses stay scalar
     const int n32 = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;  // one image per grid row: GroupNorm statistics are per image
-
-    // set-up: weights -> LDS (row stride padded: conflict-free ds_read_b128 A fragments), per-batch GN vectors
-    for (int i = tid; i < C1 * (C1 / 8); i += NW1 * 64) {
-        const int oc = i >> 4, c = i & 15;
-        *reinterpret_cast<u32x4_t*>(wl + oc * WROW + c * 8) = *reinterpret_cast<const u32x4_t*>(p.w + oc * C1 + c * 8);
-    }
-    if (tid < C1) {
-        const int c = tid, g = c >> 4;
-        if constexpr (PLAIN) {
-            cvec[c] = p.bias ? p.bias[c] : 0.f;
-        } else {
-            const double n = (double)p.H * (double)p.W * 16.0;
-            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
-            const double mean = s1 / n;
-            double var = s2 / n - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-            const float gmm = p.gamma[c];
-            cvec[c] = p.bias[c];
-            cvec[C1 + c] = gmm * rstd;
-            cvec[2 * C1 + c] = p.beta[c] - (float)mean * gmm * rstd;
-            if constexpr (IMG) cvec[3 * C1 + c] = p.b0[c];
-        }
-    }
-    __syncthreads();
 
     // Work -> memory map.  Round 1: group g = blockIdx.x * NW1 + wave, then += gridDim.x * NW1 (a persistent grid-stride walk).
     // Persistent grid-stride loops stream at 4.2-4.9 TB/s on these boxes, block-contiguous ranges handed out in dispatch order at
@@ -140,6 +125,46 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         }
         }
     };
+    // set-up: weights -> LDS (row stride padded: conflict-free ds_read_b128 A fragments), per-batch GN vectors.  The weight chunks
+    // are REQUESTED first, the wave's first group right behind them, and only then are the chunks written to the LDS: the first
+    // group's HBM round trip runs under the staging, the GroupNorm constants' fp64 arithmetic and the barrier instead of after
+    // them (round 3: set-up was 8.7 % of a wave's lifetime, tools/c1x1_probe.hip).
+    constexpr int WCH = C1 * (C1 / 8), WIT = (WCH + NW1 * 64 - 1) / (NW1 * 64);
+    u32x4_t wst[WIT];
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+        const int ci = min(tid + i * NW1 * 64, WCH - 1);
+        wst[i] = *reinterpret_cast<const u32x4_t*>(p.w + (ci >> 4) * C1 + (ci & 15) * 8);
+    }
+    u32x4_t raw[8];
+    if constexpr (!IMG) load_group(gbase + wave, raw);
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+        const int ci = tid + i * NW1 * 64;
+        if (WCH % (NW1 * 64) == 0 || ci < WCH) *reinterpret_cast<u32x4_t*>(wl + (ci >> 4) * WROW + (ci & 15) * 8) = wst[i];
+    }
+    if (tid < C1) {
+        const int c = tid, g = c >> 4;
+        if constexpr (PLAIN) {
+            cvec[c] = p.bias ? p.bias[c] : 0.f;
+        } else {
+            const double n = (double)p.H * (double)p.W * 16.0;
+            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float gmm = p.gamma[c];
+            cvec[c] = p.bias[c];
+            // GroupNorm scale / shift carry log2(e): ys = log2e * GroupNorm(x), SiLU(y) = ys * rcp(log2e + log2e * exp2(-ys))
+            // (the negation is an input modifier, the "1 +" an fma: one packed multiply less per pair than y * rcp(1 + exp2(-log2e y)))
+            cvec[C1 + c] = gmm * rstd * kLog2e;
+            cvec[2 * C1 + c] = (p.beta[c] - (float)mean * gmm * rstd) * kLog2e;
+            if constexpr (IMG) cvec[3 * C1 + c] = p.b0[c];
+        }
+    }
+    __syncthreads();
+
     // GroupNorm scale / shift of this lane's 8 input channels
     float ga[8], gb[8];
 #pragma unroll
@@ -176,18 +201,23 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         sv[1] = (float)ib[o + 2 * p.is[1]];               // k = 2 -> channel 2 (k = 3: zero weight)
     };
 
-    u32x4_t raw[8];
     float sv[2] = {0.f, 0.f};
     int g = gbase + wave;
     if constexpr (IMG) load_taps(g, sv);
-    else load_group(g, raw);
     // First group landed BEFORE the loop is entered: otherwise the loop header inherits "8 loads in flight, nothing
     // younger" from this path, and the per-register waits at the top of every iteration (vmcnt(7..0)) also wait for the
     // previous group's eight stores.  With nothing pending here they become vmcnt(15..8).
     if constexpr (IMG) asm volatile("; conv1x1 first group landed" ::"v"(sv[0]), "v"(sv[1]));
     else asm volatile("; conv1x1 first group landed" ::"v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
+    C1_T(0);
     for (; g < ngroups; g += gstride) {
         const int n0 = g * 32;
+#ifdef NAF_C1_TIMING
+        if constexpr (!IMG) {   // the group's eight loads have landed (the previous group's eight stores may still be in flight)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            C1_T(1);
+        }
+#endif
         const float* cv = cvec;
 
         // accumulators start as the conv bias (row 4 j + i of tile m = channel 32 m + 8 j + 4 half + i): 16 ds_read_b128 ahead of
@@ -232,8 +262,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                             xb[1] = (bf16_t)v[1];
                             const f32x2_t x = {(float)xb[0], (float)xb[1]};
                             const f32x2_t y = x * f32x2_t{gaj[2 * e], gaj[2 * e + 1]} + f32x2_t{gbj[2 * e], gbj[2 * e + 1]};
-                            f32x2_t u = y * -1.4426950408889634f;
-                            u = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+                            const f32x2_t u = f32x2_t{__builtin_amdgcn_exp2f(-y[0]), __builtin_amdgcn_exp2f(-y[1])} * kLog2e + kLog2e;
                             const f32x2_t r = y * f32x2_t{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
                             o[2 * e] = (bf16_t)r[0];
                             o[2 * e + 1] = (bf16_t)r[1];
@@ -256,9 +285,8 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             for (int e = 0; e < 4; ++e) {
                 const uint32_t w = raw[it][e];
                 const f32x2_t x = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
-                const f32x2_t y = x * f32x2_t{ga[2 * e], ga[2 * e + 1]} + f32x2_t{gb[2 * e], gb[2 * e + 1]};
-                f32x2_t u = y * -1.4426950408889634f;
-                u = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+                const f32x2_t y = x * f32x2_t{ga[2 * e], ga[2 * e + 1]} + f32x2_t{gb[2 * e], gb[2 * e + 1]};   // log2e * GroupNorm(x)
+                const f32x2_t u = f32x2_t{__builtin_amdgcn_exp2f(-y[0]), __builtin_amdgcn_exp2f(-y[1])} * kLog2e + kLog2e;
                 const f32x2_t r = y * f32x2_t{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
                 o[2 * e] = (bf16_t)r[0];
                 o[2 * e + 1] = (bf16_t)r[1];
@@ -269,6 +297,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         // The input registers are free again: refill them with the NEXT group now (no second register set; the loads
         // have the MFMA / epilogue / store part of this group to land and are consumed by the next transform, whose
         // vmcnt wait then leaves this group's eight stores in flight).
+        C1_T(2);
         __builtin_amdgcn_sched_barrier(0);
         // (a second register set with the group AFTER next in flight was measured in round 3: +-0, gpurun r9s)
         if constexpr (IMG) load_taps(g + gstride, sv);
@@ -299,6 +328,10 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef NAF_C1_TIMING
+        asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+        C1_T(3);
+#endif
         // epilogue: bias, GroupNorm sums, bf16 -> the wave's LDS tile (a lane outside the image adds zeros)
         const bool full = DENSE || g < nfull;
         auto epilogue = [&](auto fullc) __attribute__((always_inline)) {
@@ -318,6 +351,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                     }
                     *reinterpret_cast<bf16x4_t*>(otw + n32 * OROW1 + 32 * m + 8 * j + 4 * half) = o;
                 }
+            C1_T(4);
             // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
             bf16_t* yb = p.y + b * p.ys[0];
             if (FULL && (DENSE || ydense)) {
@@ -330,6 +364,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                     if constexpr (!(NAF_C1_ABL & 8)) *reinterpret_cast<u32x4_t*>(yg + (int64_t)it * 8 * p.ys[2] + ly) = v;
                     else asm volatile("" ::"v"(v));
                 }
+                C1_T(5);
                 return;
             }
             if constexpr (!(FULL && DENSE)) {
@@ -362,6 +397,10 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     // the (unused) prefetch past the last group lands here, not at some later merge point
     if constexpr (IMG) asm volatile("; conv1x1 loop drained" ::"v"(sv[0]), "v"(sv[1]));
     else asm volatile("; conv1x1 loop drained" ::"v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
+#ifdef NAF_C1_TIMING
+    if (lane == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 8; ++i) g_c1_tim[(blockIdx.x * NW1 + wave) * 8 + i] = tacc[i];
+#endif
     if (p.stats_out) {
         // wave sums -> one set of fp64 atomics per WORKGROUP (atomics on 16 addresses serialise in L2)
         __syncthreads();                      // every wave is done with its LDS tile
