@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 103 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 104 /* major*10000 + minor*100 + patch */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -370,9 +370,16 @@ typedef struct naf_xna_bwd_args {
     int64_t v_stride[4];
     int64_t dout_stride[4];
     int64_t dq_stride[4];
+    void* workspace;         /* version >= 104: device scratch of naf_xna_bwd_workspace_bytes() bytes, 16-byte aligned (NAF_XNA_ROWS) */
+    int64_t workspace_bytes;
 } naf_xna_bwd_args;
-/* NAF_XNA_MFMA or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run; negative naf_status on invalid arguments. */
+/* NAF_XNA_MFMA, NAF_XNA_ROWS or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run; negative naf_status on invalid arguments.
+ * NAF_XNA_ROWS (round 3) is the matrix-core backward of the denoising call (denoising.py:213,301: keys and queries on one grid,
+ * Dq a multiple of 32 up to 512 as in naf_xna_fwd's NAF_XNA_ROWS, Dv <= 32, square window <= 15): it needs idx_y / idx_x like
+ * the table-driven kernel AND `workspace` (per-query softmax statistics, 16 bytes per query); without a workspace the call
+ * runs the table-driven kernel instead.  It writes dk_lr / dv_lr without atomics (read-add-write of zeroed buffers). */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
+size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------

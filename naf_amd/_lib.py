@@ -109,6 +109,7 @@ class XnaBwdArgs(C.Structure):
         ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
         ("scale", C.c_float), ("reserved", C.c_int32),
         ("q_stride", I64x4), ("k_stride", I64x4), ("v_stride", I64x4), ("dout_stride", I64x4), ("dq_stride", I64x4),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -160,6 +161,7 @@ SIGNATURES = {
     "naf_workspace_bytes": (C.c_size_t, [C.POINTER(XnaArgs)]),
     "naf_xna_fwd": (C.c_int, [C.POINTER(XnaArgs), C.c_void_p]),
     "naf_xna_bwd_supported": (C.c_int, [C.POINTER(XnaBwdArgs)]),
+    "naf_xna_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(XnaBwdArgs)]),
     "naf_xna_bwd": (C.c_int, [C.POINTER(XnaBwdArgs), C.c_void_p]),
     "naf_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ForwardArgs)]),
     "naf_forward_supported": (C.c_int, [C.POINTER(ForwardArgs)]),

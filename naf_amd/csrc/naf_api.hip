@@ -302,7 +302,13 @@ static int xna_bwd_validate(const naf_xna_bwd_args* a) {
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a) {
     const int rc = xna_bwd_validate(a);
     if (rc != NAF_OK) return -rc;
-    return naf_xna_bwd_eligible(a) ? NAF_XNA_MFMA : NAF_XNA_GENERIC;
+    if (naf_xna_bwd_eligible(a)) return NAF_XNA_MFMA;
+    return naf_xna_rows_bwd_eligible(a) ? NAF_XNA_ROWS : NAF_XNA_GENERIC;
+}
+
+size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a) {
+    if (a == nullptr || xna_bwd_validate(a) != NAF_OK || naf_xna_bwd_eligible(a) || !naf_xna_rows_bwd_eligible(a)) return 0;
+    return naf_xna_rows_bwd_workspace(a);
 }
 
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
@@ -310,6 +316,9 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
     if (rc != NAF_OK) return rc;
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
     if (naf_xna_bwd_eligible(a)) return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
+    // the denoising call's shapes: matrix cores when the caller brought the tables and the statistics workspace
+    if (naf_xna_rows_bwd_eligible(a) && a->idx_y && a->idx_x && a->workspace && (size_t)a->workspace_bytes >= naf_xna_rows_bwd_workspace(a))
+        return naf_launch_xna_rows_bwd(a, scale, static_cast<hipStream_t>(stream));
     return naf_launch_xna_generic_bwd(a, scale, static_cast<hipStream_t>(stream));
 }
 

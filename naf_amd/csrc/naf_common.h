@@ -42,6 +42,9 @@ int naf_xna_rows_eligible(const naf_xna_args* a);                               
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);   // xna_bwd.hip
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a);                             // xna_bwd.hip
 int naf_launch_xna_generic_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);  // xna_generic.hip
+int naf_launch_xna_rows_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);     // xna_rows_bwd.hip
+int naf_xna_rows_bwd_eligible(const naf_xna_bwd_args* a);                               // xna_rows_bwd.hip
+size_t naf_xna_rows_bwd_workspace(const naf_xna_bwd_args* a);                           // xna_rows_bwd.hip
 int naf_launch_rope_tables(float* ty, float* tx, const float* periods, int np, int Ho, int Wo, hipStream_t s);
 int naf_launch_rope_pool(const naf_rope_pool_args* a, hipStream_t s);             // rope_pool.hip
 int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, int h, int w,

@@ -473,11 +473,28 @@ def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tens
     return lib.naf_xna_bwd_supported(C.byref(a)) == _lib.XNA_MFMA
 
 
+def xna_backward_select(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> str:
+    """Which kernel ``xna_backward`` runs for these shapes: "mfma" (cell kernel), "rows" (row-streaming matrix-core kernel: keys
+    and queries on one grid, the reference's denoising call) or "generic" (table-driven scalar kernel)."""
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    a = _fill_xna_bwd(q, k_lr, v_lr, q, q, q, q, ky, kx, None)      # shape / alignment query only
+    B, heads, Ho, Wo, Dq = q.shape
+    Dv = v_lr.shape[-1]
+    a.dout_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    a.dq_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
+    sel = lib.naf_xna_bwd_supported(C.byref(a))
+    if sel < 0:
+        _lib.check(-sel, "naf_xna_bwd_supported")
+    return {_lib.XNA_MFMA: "mfma", _lib.XNA_ROWS: "rows"}.get(sel, "generic")
+
+
 def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: torch.Tensor, kernel_size, *,
-                 scale: Optional[float] = None):
+                 scale: Optional[float] = None, path: str = "auto"):
     """Gradients of ``xna_forward`` w.r.t. q, k_lr, v_lr given ``dout`` (5-D [B, heads, Ho, Wo, Dv], any strides with
     Dv contiguous; cast to bf16).  Returns (dq bf16 [B,heads,Ho,Wo,Dq] view of a channels-last buffer,
-    dk_lr fp32 [B,heads,h,w,Dq] view, dv_lr fp32 [B,heads,h,w,Dv] view)."""
+    dk_lr fp32 [B,heads,h,w,Dq] view, dv_lr fp32 [B,heads,h,w,Dv] view).  ``path="generic"`` withholds the workspace of the
+    row-streaming kernel, so that shapes it would serve run the table-driven kernel (A/B and tests)."""
     for t, n in ((q, "q"), (k_lr, "k_lr"), (v_lr, "v_lr")):
         _gpu(t, n)
         if t.dtype != torch.bfloat16 or t.dim() != 5 or t.stride(4) != 1:
@@ -498,10 +515,15 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
     sel = lib.naf_xna_bwd_supported(C.byref(a))
     if sel < 0:
         _lib.check(-sel, "naf_xna_bwd_supported")
-    if sel == _lib.XNA_GENERIC:
+    if sel in (_lib.XNA_GENERIC, _lib.XNA_ROWS):
         iy = device_index_table(Ho, h, ky, dev)
         ix = device_index_table(Wo, w, kx, dev)
         a.idx_y, a.idx_x = iy.data_ptr(), ix.data_ptr()
+    if path not in ("auto", "generic"):
+        raise ValueError(f"xna_backward: path must be 'auto' or 'generic', got {path!r}")
+    if sel == _lib.XNA_ROWS and path == "auto":    # matrix-core backward of the denoising shapes: per-query softmax statistics live in a workspace
+        ws = torch.empty(int(lib.naf_xna_bwd_workspace_bytes(C.byref(a))), dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev), _Timed("xna_bwd"):
         rc = lib.naf_xna_bwd(C.byref(a), _stream(q))
     _lib.check(rc, "naf_xna_bwd")

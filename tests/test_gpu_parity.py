@@ -749,7 +749,7 @@ def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
 
 @pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
     (1, 256, 24, 4, (5, 7), (23, 30), 3),       # non-integer ratio (F4 shapes): irregular neighbourhoods, duplicates
-    (1, 96, 3, 1, (12, 10), (12, 10), 5),       # ratio 1, one head of 96, C = 3 (denoising-like)
+    (1, 80, 3, 1, (12, 10), (12, 10), 5),       # ratio 1, one head of 80 (no matrix-core instantiation), C = 3
     (2, 64, 16, 2, (4, 4), (16, 16), (3, 1)),   # rectangular window, Dq = 32, d = 4 (MFMA backward does not serve it)
 ])
 def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_sz, ksz):
@@ -768,6 +768,36 @@ def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_
         scale = float(ref.abs().max())
         err = float((got - ref).abs().max())
         assert err <= tol * scale + 1e-5, f"{name}: max err {err:.3e} (ref max {scale:.3e})"   # dq is rounded to bf16
+
+
+@pytest.mark.parametrize("B,Cq,C,heads,size,ksz", [
+    (1, 96, 3, 1, (12, 10), 5),        # narrower than one 16-query tile
+    (1, 96, 3, 1, (40, 52), 15),       # the denoising call's shape class: one head, RGB values, 15x15 window, ragged last tile
+    (2, 256, 3, 1, (33, 47), 15),      # NAF(dim = 256), batch 2
+    (1, 512, 3, 1, (24, 40), 15),      # NAF(dim = 512): 16 k-steps, 128 accumulator registers, one workgroup per CU
+    (1, 128, 16, 2, (20, 36), 9),      # two heads of 64, 8 value channels per head
+    (1, 64, 32, 1, (17, 17), 7),       # 32 value channels: two channel tiles
+    (1, 192, 24, 1, (15, 31), 15),     # window as tall as the image: every query row sees every key row
+    (1, 384, 3, 1, (16, 64), 3),       # smallest window, whole tiles only
+])
+def test_xna_backward_rows_matches_oracle(dev, B, Cq, C, heads, size, ksz):
+    """The row-streaming matrix-core backward (keys and queries on one grid: denoising.py:213,301) vs autograd through the oracle."""
+    from naf_amd import ops
+    q = bf16r(O.hash_normal((B, Cq, *size), 541))
+    k = bf16r(O.hash_normal((B, Cq, *size), 542))
+    v = bf16r(O.hash_normal((B, C, *size), 543))
+    dout = bf16r(O.hash_normal((B, C, *size), 544))
+    rq, rk, rv = O.xna_backward(q, k, v, dout, ksz, heads)
+    q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, dout))
+    assert ops.xna_backward_select(q5, k5, v5, ksz) == "rows"
+    dq, dk, dv = ops.xna_backward(q5, k5, v5, g5, ksz)
+    back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
+    # P and dS pass through bf16 (relative 2^-8) before the contractions over up to k^2 neighbours
+    for got, ref, name in ((back(dq), rq, "dq"), (back(dk), rk, "dk"), (back(dv), rv, "dv")):
+        scale = float(ref.abs().max())
+        err = (got - ref).abs()
+        assert float(err.max()) <= 2e-2 * scale + 1e-3 and float(err.mean()) <= 3e-3 * scale + 1e-4, \
+            f"{name}: max err {float(err.max()):.3e} mean {float(err.mean()):.3e} (ref max {scale:.3e})"
 
 
 def test_xna_autograd_function(dev):

@@ -20,3 +20,10 @@ for S, Dq, ks in ((128, 96, 15), (256, 96, 15), (256, 256, 15), (256, 512, 15), 
     t = timed(lambda: ops.xna_forward(q, k, v, ks, out_dtype=torch.float32))
     fl = 2.0 * S * S * ks * ks * (Dq + 3)
     print("S %4d Dq %3d k %2d  path %-8s %8.3f ms  %.2f TFLOP/s" % (S, Dq, ks, path, t, fl / t / 1e9))
+    g = torch.randn(1, S, S, 1, 3, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    bsel = ops.xna_backward_select(q, k, v, ks)
+    tb = timed(lambda: ops.xna_backward(q, k, v, g, ks))
+    line = "        backward: %-8s %8.3f ms" % (bsel, tb)
+    if bsel == "rows" and S <= 128:
+        line += "   (table-driven scalar kernel: %8.3f ms)" % timed(lambda: ops.xna_backward(q, k, v, g, ks, path="generic"), n=1)
+    print(line)
