@@ -307,6 +307,50 @@ def test_bench_multi_rank_path_dry_run(dev):
     assert 0 < j["roofline"]["frac_with_prepass"] < j["roofline"]["frac"]
 
 
+def test_denoising_configuration_trains_on_the_matrix_core_backward(dev):
+    """denoising.py:209-220's step -- model(noisy_norm, noisy, (S, S)) in train mode, loss, backward -- at NAF(dim 96, one head,
+    window 15): the attention's backward runs xna_rows_bwd_kernel (round 3; the scalar table-driven kernel before), and every
+    parameter gradient plus the gradient w.r.t. the noisy image agrees with fp32 autograd through the oracle."""
+    from naf_amd import ops
+    dim, S = 96, 40
+    p = O.make_params(dim=dim, heads_rope=1, seed=72)
+    m = _load_model(dev, p, dim=dim, heads_attn=1, heads_rope=1, kernel_size=15)
+    img = O.hash_normal((1, 3, S, S), 7201)
+    noisy = O.hash_normal((1, 3, S, S), 7202)
+    wgt = O.hash_normal((1, 3, S, S), 7203)
+    po = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "periods" not in k) for k, v in p.items()}
+    no = noisy.clone().requires_grad_(True)
+    (O.naf_forward(po, img, no, (S, S), kernel_size=15, heads_attn=1, heads_rope=1) * wgt).sum().backward()
+    seen = []
+    real = ops.xna_backward
+    def spy(q, k, v, g, ks, **kw):
+        seen.append(ops.xna_backward_select(q, k, v, ks))
+        return real(q, k, v, g, ks, **kw)
+    for prm in m.parameters():
+        prm.requires_grad_(True)
+    nd = noisy.to(dev).requires_grad_(True)
+    ops.xna_backward = spy
+    try:
+        out = m.forward_train(img.to(dev), nd, (S, S))
+        (out.float() * wgt.to(dev)).sum().backward()
+    finally:
+        ops.xna_backward = real
+    assert seen == ["rows"], seen
+    checked = 0
+    for name, prm in m.named_parameters():
+        ref = po[name].grad
+        if ref is None:
+            continue
+        got = prm.grad.float().cpu()
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 5e-2 * scale + 1e-3, f"{name}: grad err {err:.3e} vs max {scale:.3e}"
+        checked += 1
+    assert checked >= 20
+    gs = float(no.grad.abs().max())
+    assert float((nd.grad.float().cpu() - no.grad).abs().max()) <= 3e-2 * gs + 1e-3
+
+
 @pytest.mark.parametrize("dim,shape", [(96, (1, 40, 56)), (128, (2, 33, 47)), (512, (1, 24, 40)), (32, (1, 20, 24))])
 def test_stem_of_any_width_runs_on_hip_and_matches_the_oracle(dev, dim, shape):
     """VERDICT r01 (missing 2): hidden widths other than 128 -- the reference's denoising models, NAF(dim = 96 ... 512)
