@@ -474,8 +474,8 @@ def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tens
 
 
 def xna_backward_select(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> str:
-    """Which kernel ``xna_backward`` runs for these shapes: "mfma" (cell kernel), "rows" (row-streaming matrix-core kernel: keys
-    and queries on one grid, the reference's denoising call) or "generic" (table-driven scalar kernel)."""
+    """Which kernel ``xna_backward`` runs for these shapes: "mfma" (cell kernel), "rows" (row-streaming matrix-core kernel: the integer ratios
+    the cell kernel does not take -- the reference's denoising call, its own training geometry, patch-14 backbones) or "generic" (table-driven scalar kernel)."""
     lib = _lib.load()
     ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
     a = _fill_xna_bwd(q, k_lr, v_lr, q, q, q, q, ky, kx, None)      # shape / alignment query only

@@ -782,22 +782,45 @@ def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_
 ])
 def test_xna_backward_rows_matches_oracle(dev, B, Cq, C, heads, size, ksz):
     """The row-streaming matrix-core backward (keys and queries on one grid: denoising.py:213,301) vs autograd through the oracle."""
+    _rows_backward_case(dev, B, Cq, C, heads, size, size, ksz)
+
+
+def _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz):
     from naf_amd import ops
-    q = bf16r(O.hash_normal((B, Cq, *size), 541))
-    k = bf16r(O.hash_normal((B, Cq, *size), 542))
-    v = bf16r(O.hash_normal((B, C, *size), 543))
-    dout = bf16r(O.hash_normal((B, C, *size), 544))
+    q = bf16r(O.hash_normal((B, Cq, *out_sz), 541))
+    k = bf16r(O.hash_normal((B, Cq, *lr), 542))
+    v = bf16r(O.hash_normal((B, C, *lr), 543))
+    dout = bf16r(O.hash_normal((B, C, *out_sz), 544))
     rq, rk, rv = O.xna_backward(q, k, v, dout, ksz, heads)
     q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, dout))
     assert ops.xna_backward_select(q5, k5, v5, ksz) == "rows"
     dq, dk, dv = ops.xna_backward(q5, k5, v5, g5, ksz)
     back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
-    # P and dS pass through bf16 (relative 2^-8) before the contractions over up to k^2 neighbours
+    # P and dS pass through bf16 (relative 2^-8) before the contractions over up to d^2 k^2 (query, key) pairs
     for got, ref, name in ((back(dq), rq, "dq"), (back(dk), rk, "dk"), (back(dv), rv, "dv")):
         scale = float(ref.abs().max())
         err = (got - ref).abs()
         assert float(err.max()) <= 2e-2 * scale + 1e-3 and float(err.mean()) <= 3e-3 * scale + 1e-4, \
             f"{name}: max err {float(err.max()):.3e} mean {float(err.mean()):.3e} (ref max {scale:.3e})"
+    # the scalar table-driven kernel on the same inputs (fp32 throughout) brackets the oracle from the other side
+    dq2, dk2, dv2 = ops.xna_backward(q5, k5, v5, g5, ksz, path="generic")
+    for got, other, name in ((dk, dk2, "dk"), (dv, dv2, "dv")):
+        scale = float(other.abs().max())
+        assert float((got - other).abs().max()) <= 2e-2 * scale + 1e-3, name
+
+
+@pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
+    (4, 256, 768, 4, (16, 16), (32, 32), 9),     # the reference's OWN training step (train.py:113-133, config/base.yaml): ratio 2, Dv = 192
+    (1, 256, 384, 4, (12, 10), (168, 140), 9),   # patch-14 backbone (ratio 14: no 16-pixel row tiles for the cell kernel), Dv = 96
+    (2, 256, 128, 4, (9, 11), (27, 44), 7),      # ratio (3, 4), Dv = 32 through the fragment path, ragged key tiles
+    (1, 256, 1024, 4, (15, 15), (60, 60), 15),   # 15 x 15 window as tall as the grid, ratio 4, Dv = 256
+    (1, 128, 6, 2, (10, 20), (20, 40), 5),       # ratio 2 with three value channels per head (gather form)
+    (1, 256, 512, 4, (8, 8), (64, 64), 3),       # ratio 8, Dv = 128
+])
+def test_xna_backward_rows_integer_ratios(dev, B, Cq, C, heads, lr, out_sz, ksz):
+    """Integer ratios the cell kernel does not take (cells narrower than a 16-pixel row tile, 15 x 15 windows): the row-streaming
+    matrix-core backward with the key-stationary pass walking every query column chunk of the keys' inverse neighbourhood."""
+    _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz)
 
 
 def test_xna_autograd_function(dev):
