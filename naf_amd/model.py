@@ -651,8 +651,10 @@ class NAF(nn.Module):
         and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
         differentiate them (the fused inference stem has no backward).  In ``.train()`` mode the RoPE coordinates get the
-        reference's random rescale (rope.py:107-124, NAF's rope_rescale); in ``.eval()`` mode they are deterministic.  Needs the shapes
-        ``ops.xna_backward_supported`` accepts (integer ratio, Wo/w a multiple of 16, window <= 13 with K/V windows inside the LDS).
+        reference's random rescale (rope.py:107-124, NAF's rope_rescale); in ``.eval()`` mode they are deterministic.  Every geometry
+        has a backward kernel (``ops.xna_backward_select``): the MFMA cell kernel (integer ratio, Wo/w a multiple of 16, window <= 13
+        with K/V windows inside the LDS), the row-streaming matrix-core kernel (every other integer ratio: the reference's own training
+        geometry 16^2 -> 32^2, patch-14 backbones, the denoising call), the table-driven scalar kernel for the rest.
         ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
         mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32.  ``amp="hip"`` is the same
         precision class on this library's own stem: ``_HipStem`` (fused forward kernels, bf16 activations kept per layer, HIP
