@@ -680,7 +680,8 @@ class ForwardPlan:
         a.events[0] = events[0].cuda_event if events else None
         a.events[1] = events[1].cuda_event if events else None
         for i in range(8):     # naf_forward_args.phase_events: hipEvent_t handles at the phase boundaries of the one call
-            a.phase_events[i] = phase_events[i].cuda_event if (phase_events and i < len(phase_events)) else None
+            e = phase_events[i] if (phase_events and i < len(phase_events)) else None    # None entries are skipped by the library
+            a.phase_events[i] = e.cuda_event if e is not None else None
         logits = None
         if return_logits:
             logits = torch.empty((self.shape_out[0], a.heads, self.shape_out[1], self.shape_out[2], a.ksize * a.ksize),
