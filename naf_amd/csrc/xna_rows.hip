@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void xna_rows_kernel(const XnaRowsParams p) {
 namespace {
 bool aligned_to(const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; }
 
+}  // namespace
+
 // widest run of low-res columns the 16 queries of an aligned tile touch (canonical table, evaluated on the host)
-int tile_span(int L_out, int L_in, int k) {
+int naf_tile_span(int L_out, int L_in, int k) {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int>, int> cache;   // O(L_out * k) host work: once per geometry
     const std::tuple<int, int, int> key(L_out, L_in, k);
@@ -200,6 +202,7 @@ int tile_span(int L_out, int L_in, int k) {
     return worst;
 }
 
+namespace {
 template <int NDQ>
 int launch_ndq(const XnaRowsParams& p, int out_dtype, int grid, hipStream_t s) {
     if (out_dtype == NAF_BF16) hipLaunchKernelGGL((xna_rows_kernel<NDQ, bf16_t>), dim3(grid), dim3(256), 0, s, p);
@@ -220,7 +223,7 @@ int naf_xna_rows_eligible(const naf_xna_args* a) {
     if (!aligned_to(a->q, 16) || !aligned_to(a->k_lr, 16)) return 0;
     for (int i = 0; i < 4; ++i)
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8) return 0;
-    return tile_span(a->Wo, a->w, a->kx) <= 32 ? 1 : 0;
+    return naf_tile_span(a->Wo, a->w, a->kx) <= 32 ? 1 : 0;
 }
 
 int naf_launch_xna_rows(const naf_xna_args* a, float scale, hipStream_t s) {

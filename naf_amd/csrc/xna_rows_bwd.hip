@@ -1,24 +1,28 @@
-// Cross-scale neighbourhood attention BACKWARD on the matrix cores for every INTEGER ratio the cell kernel (xna_bwd_kernel.h)
-// does not serve: what autograd runs through legacy_attention (attentions.py:16-29) in
+// Cross-scale neighbourhood attention BACKWARD on the matrix cores for everything the cell kernel (xna_bwd_kernel.h) does not
+// serve with a square window: what autograd runs through legacy_attention (attentions.py:16-29) in
 //   * the reference's denoising loop (denoising.py:213,301 -- NAF(dim = 96 ... 512) on a 3-channel image: ratio 1, ONE head of
-//     dim up to 512, three value channels, window 15), and
+//     dim up to 512, three value channels, window 15),
 //   * the reference's own training step (train.py:113-133 with config/base.yaml: 512^2 images, ViT-B/16, down_factor 0.5,
 //     batch 4, window 9: 768 x 16^2 features -> the 32^2 high-res feature grid, ratio 2, four heads of 64 with 192 value
-//     channels each), and patch-14 backbones (ratio 14).
+//     channels each), patch-14 backbones (ratio 14), and
+//   * `down_factor: random` training (utils/training.py:38-45: the low-res image is a random 0.25 ... 0.6 of the high-res one,
+//     e.g. 13^2 -> 32^2) and the notebook's geometries: NON-integer ratios, where taps repeat (multiplicities).
 // Until round 3 these shapes fell to xna_generic_bwd_kernel (one wave per query, scalar FMAs, k^2 x (Dq + Dv) atomics per query:
 // 1.58 ms = 42 % of the GPU time of the reference's training step here).
 //
 // At an integer ratio every query attends to k x k CONSECUTIVE low-res cells whose first row / column (idx_y[y][0], idx_x[x][0])
-// is non-decreasing in y / x (tests/test_oracle.py::test_lowres_form_equals_dilated_form), so the kernels use the
-// tables only through their first tap.  Two launches of ONE kernel template, both without atomics:
-//   * QUERIES stationary (KEYS = false): a wave owns 16 consecutive queries of an output row and streams the k low-res rows of
+// is non-decreasing in y / x (tests/test_oracle.py::test_lowres_form_equals_dilated_form): ranges come from a
+// bisection on the first taps and every weight is 0 or 1.  Otherwise (`mult`) a query's taps along an axis are a non-decreasing
+// run with repeats, the weight of a (query, key) pair is (row taps on the key's row) x (column taps on its column) exactly as in
+// xna_rows_kernel / xna_union_kernel, and the ranges come from a strided scan of the tables.
+// Two launches of ONE kernel template, both without atomics:
+//   * QUERIES stationary (KEYS = false): a wave owns 16 consecutive queries of an output row and streams the low-res rows of
 //     their windows (at most 32 low-res columns).  Pass 1 = the forward's online softmax (running max / sum) plus the running sum
 //     of e * dP, which gives delta = sum_j P_j dP_j without the forward's output; the per-query (max, 1 / sum, delta) go to the
 //     workspace.  Pass 2 recomputes S and dP row by row, dS = scale P (dP - delta), and accumulates dQ[q][d] += dS[q][slot] K[slot][d].
 //   * KEYS stationary (KEYS = true): a wave owns 16 consecutive low-res keys of a row and streams the query rows whose windows
-//     contain that row (a contiguous range: the window start is monotone), 32 query columns at a time; P and dS are rebuilt from
-//     the stored statistics; dK[key][d] += dS^T Q and dV[key][c] += P^T dO accumulate in registers over ALL queries of the key
-//     and are written once.
+//     contain that row, 32 query columns at a time; P and dS are rebuilt from the stored statistics;
+//     dK[key][d] += dS^T Q and dV[key][c] += P^T dO accumulate in registers over ALL queries of the key and are written once.
 // In both, the S-type products (S over the head dim, dP over the value channels) have the stationary tile as the B operand
 // (fragments in registers, 16 B per lane per 32 dims) and the streamed row as the A operand straight from L2, so their results
 // have a lane per stationary element holding 8 streamed slots -- which IS the A-operand layout of the second products
@@ -40,6 +44,7 @@ struct XnaRowsBwdParams {
     const int32_t* idx_y;  // [Ho][ks]
     const int32_t* idx_x;  // [Wo][ks]
     int32_t B, heads, Ho, Wo, h, w, Dv, ks;
+    int32_t mult;          // 1: non-integer ratio -- taps repeat (multiplicities) and their first row / column need not be monotone
     int32_t ntx[2];        // 16-element tiles per row: [0] queries, [1] keys
     int64_t ntiles[2];
     float scale, scale_log2e;
@@ -67,10 +72,29 @@ __device__ __forceinline__ int last_starting_by(const int32_t* tab, int L, int k
     }
     return lo - 1;
 }
+// [lo, hi] of the indices i in [0, L) whose taps tab[i*ks] .. tab[i*ks + ks-1] (non-decreasing) overlap [t0, t1]; lo > hi when none.
+// Any order of the first taps (non-integer ratios): a strided scan by the whole wave, O(L / 64) loads per lane.
+__device__ __forceinline__ void overlapping_range(const int32_t* tab, int L, int ks, int t0, int t1, int lane, int& lo, int& hi) {
+    int l = L, h = -1;
+    for (int i = lane; i < L; i += 64) {
+        const int a = tab[(int64_t)i * ks], z = tab[(int64_t)i * ks + ks - 1];
+        if (a <= t1 && z >= t0) {
+            l = min(l, i);
+            h = max(h, i);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l = min(l, __shfl_xor(l, o));
+        h = max(h, __shfl_xor(h, o));
+    }
+    lo = l;
+    hi = h;
+}
 constexpr int rb_regs_heavy(int ndq, int ndv) { return ndq >= 12 || ndv >= 6; }
 }  // namespace
 
-template <int NDQ, int NDV, bool KEYS>
+template <int NDQ, int NDV, bool KEYS, bool MULT>
 __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_rows_bwd_kernel(const XnaRowsBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rb[];
     constexpr int ROWLEN = NDQ * 32 + 8;   // elements; +16 B per row keeps the transposing reads off one bank group
@@ -146,14 +170,21 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
 
         // streamed rows, and the streamed columns in chunks of 32 slots
         int r0, r1, xlo, xhi;
+        // queries stationary: lane l < KS holds row tap l of the tile's query row (row multiplicities come from ballots)
+        const int iyl = (MULT && !KEYS && lane < KS) ? p.idx_y[(int64_t)row * KS + lane] : INT_MAX;
         if constexpr (KEYS) {
-            r0 = first_reaching(p.idx_y, p.Ho, KS, row);
-            r1 = last_starting_by(p.idx_y, p.Ho, KS, row);
-            xlo = first_reaching(p.idx_x, p.Wo, KS, tx * 16);
-            xhi = last_starting_by(p.idx_x, p.Wo, KS, min(tx * 16 + 15, p.w - 1));
+            if constexpr (MULT) {
+                overlapping_range(p.idx_y, p.Ho, KS, row, row, lane, r0, r1);
+                overlapping_range(p.idx_x, p.Wo, KS, tx * 16, min(tx * 16 + 15, p.w - 1), lane, xlo, xhi);
+            } else {
+                r0 = first_reaching(p.idx_y, p.Ho, KS, row);
+                r1 = last_starting_by(p.idx_y, p.Ho, KS, row);
+                xlo = first_reaching(p.idx_x, p.Wo, KS, tx * 16);
+                xhi = last_starting_by(p.idx_x, p.Wo, KS, min(tx * 16 + 15, p.w - 1));
+            }
         } else {
             r0 = p.idx_y[(int64_t)row * KS];
-            r1 = r0 + KS - 1;
+            r1 = p.idx_y[(int64_t)row * KS + KS - 1];
             int xmin = p.idx_x[(int64_t)c_lane * KS];
             xmin = min(xmin, __shfl_xor(xmin, 1));
             xmin = min(xmin, __shfl_xor(xmin, 2));
@@ -165,26 +196,54 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
         r1 = __builtin_amdgcn_readfirstlane(min(r1, Ht - 1));
         xlo = __builtin_amdgcn_readfirstlane(xlo);
         xhi = __builtin_amdgcn_readfirstlane(xhi);
-        const int own_start = KEYS ? 0 : p.idx_x[(int64_t)c_lane * KS];
-
-        // this lane's 8 slots of the chunk at xa: slot (hh, i) is streamed column xa + hh*16 + grp*4 + i; wx = 1 when the
-        // (query, key) pair are neighbours
+        // this lane's 8 slots of the chunk at xa: slot (hh, i) is streamed column xa + hh*16 + grp*4 + i; wx = how many column taps
+        // of the query land on the key (0: not neighbours; 1 at integer ratios; repeats when the ratio is not an integer)
         float wx[2][4];
         auto chunk_mask = [&](int xa) __attribute__((always_inline)) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int xs = xa + hh * 16 + grp * 4 + i;
-                    bool ok = xs < Wt && c_true < Ws;
-                    if constexpr (KEYS) {
-                        const int st = p.idx_x[(int64_t)min(xs, Wt - 1) * KS];   // window start of the streamed QUERY column
-                        ok = ok && st <= c_true && c_true < st + KS;
-                    } else {
-                        ok = ok && own_start <= xs && xs < own_start + KS;
+                for (int i = 0; i < 4; ++i) wx[hh][i] = 0.f;
+            if constexpr (!MULT) {   // integer ratio: KS consecutive columns from the first tap, each once
+                const int own0 = KEYS ? 0 : p.idx_x[(int64_t)c_lane * KS];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int xs = xa + hh * 16 + grp * 4 + i;
+                        const int st = KEYS ? p.idx_x[(int64_t)min(xs, Wt - 1) * KS] : own0;     // window start of the QUERY column
+                        const int kc = KEYS ? c_true : xs;                                        // the key column
+                        wx[hh][i] = (st <= kc && kc < st + KS) ? 1.f : 0.f;
                     }
-                    wx[hh][i] = ok ? 1.f : 0.f;
-                }
+            } else
+            for (int tp = 0; tp < KS; ++tp) {
+                int own = 0;
+                if constexpr (!KEYS) own = p.idx_x[(int64_t)c_lane * KS + tp];            // a column tap of this lane's query
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int xs = xa + hh * 16 + grp * 4 + i;
+                        if constexpr (KEYS) wx[hh][i] += (p.idx_x[(int64_t)min(xs, Wt - 1) * KS + tp] == c_true) ? 1.f : 0.f;   // a tap of the streamed query
+                        else wx[hh][i] += (own == xs) ? 1.f : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(xa + hh * 16 + grp * 4 + i < Wt && c_true < Ws)) wx[hh][i] = 0.f;
+        };
+        // how many row taps of the query on hi-res row y (keys stationary: streamed) or of the tile's own row land on low-res row ry
+        auto row_weight = [&](int ry) __attribute__((always_inline)) {
+            if constexpr (!MULT) {
+                return 1;          // integer ratio: every row of the range carries exactly one tap
+            } else if constexpr (KEYS) {
+                const int tap = lane < KS ? p.idx_y[(int64_t)ry * KS + lane] : INT_MAX;
+                return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tap == row));
+            } else {
+                return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(iyl == ry));
+            }
         };
 
         // S and dP of one streamed row: s[hh][i], dp[hh][i] for slot (hh, i) and this lane's stationary element
@@ -225,6 +284,9 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
             chunk_mask(xlo);
             float m = -INFINITY, l = 0.f, dsum = 0.f;
             for (int ry = r0; ry <= r1; ++ry) {
+                const int wyi = row_weight(ry);
+                if (wyi == 0) continue;
+                const float wy = (float)wyi;
                 f32x4_t s[2], dp[2];
                 row_products(xlo, ry, false, s, dp);
                 float mrow = -INFINITY;
@@ -246,7 +308,7 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float e = wx[hh][i] > 0.f ? __builtin_amdgcn_exp2f(fmaf(s[hh][i], p.scale_log2e, -mcn)) : 0.f;
+                        const float e = wx[hh][i] > 0.f ? wy * wx[hh][i] * __builtin_amdgcn_exp2f(fmaf(s[hh][i], p.scale_log2e, -mcn)) : 0.f;
                         psum += e;
                         dps = fmaf(e, dp[hh][i], dps);
                     }
@@ -273,6 +335,9 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
         for (int xa = xlo; xa <= xhi; xa += 32) {
             if constexpr (KEYS) chunk_mask(xa);
             for (int ry = r0; ry <= r1; ++ry) {
+                const int wyi = row_weight(ry);
+                if (wyi == 0) continue;
+                const float wy = (float)wyi;
                 f32x4_t s[2], dp[2];
                 row_products(xa, ry, true, s, dp);
                 bf16x8_t dsa, pa;
@@ -286,7 +351,7 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
                             const f32x4_t st = p.stats[(((int64_t)b * p.heads + head) * p.Ho + ry) * p.Wo + xs];
                             qmc = st[0]; qinv = st[1]; qdel = st[2];
                         }
-                        const float pr = wx[hh][i] > 0.f ? __builtin_amdgcn_exp2f(fmaf(s[hh][i], p.scale_log2e, -qmc)) * qinv : 0.f;
+                        const float pr = wx[hh][i] > 0.f ? wy * wx[hh][i] * __builtin_amdgcn_exp2f(fmaf(s[hh][i], p.scale_log2e, -qmc)) * qinv : 0.f;
                         pa[hh * 4 + i] = (bf16_t)pr;
                         dsa[hh * 4 + i] = (bf16_t)(p.scale * pr * (dp[hh][i] - qdel));
                     }
@@ -339,24 +404,33 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
 namespace {
 bool rb_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-template <int NDQ, int NDV>
-int launch_rows_bwd(const XnaRowsBwdParams& p, hipStream_t s) {
+template <int NDQ, int NDV, bool MULT>
+int launch_rows_bwd_m(const XnaRowsBwdParams& p, hipStream_t s) {
     const size_t ldsq = (size_t)4 * 32 * (NDQ * 32 + 8) * sizeof(bf16_t);
     const size_t ldsk = ldsq + (NDV > 0 ? (size_t)4 * 32 * (NDV * 32 + 8) * sizeof(bf16_t) : 0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk) != hipSuccess) {
-        naf_set_error("naf_xna_bwd: cannot reserve %zu bytes of LDS", ldsk);
-        return NAF_ERR_LAUNCH;
+    static bool configured = false;   // per instantiation; the attribute is idempotent, so a race only repeats it
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, false, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, true, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk) != hipSuccess) {
+            naf_set_error("naf_xna_bwd: cannot reserve %zu bytes of LDS", ldsk);
+            return NAF_ERR_LAUNCH;
+        }
+        configured = true;
     }
     const int64_t cap = (int64_t)naf_cu_count() * 8;
     int64_t gq = (p.ntiles[0] + 3) / 4, gk = (p.ntiles[1] + 3) / 4;
     gq = gq > cap ? cap : gq;
     gk = gk > cap ? cap : gk;
-    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, false>), dim3((uint32_t)gq), dim3(256), ldsq, s, p);   // statistics + dQ
+    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, false, MULT>), dim3((uint32_t)gq), dim3(256), ldsq, s, p);   // statistics + dQ
     const int rc = naf_check_launch("xna_rows_bwd_kernel<queries>");
     if (rc != NAF_OK) return rc;
-    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, true>), dim3((uint32_t)gk), dim3(256), ldsk, s, p);    // dK, dV
+    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, true, MULT>), dim3((uint32_t)gk), dim3(256), ldsk, s, p);    // dK, dV
     return naf_check_launch("xna_rows_bwd_kernel<keys>");
+}
+
+template <int NDQ, int NDV>
+int launch_rows_bwd(const XnaRowsBwdParams& p, hipStream_t s) {
+    return p.mult ? launch_rows_bwd_m<NDQ, NDV, true>(p, s) : launch_rows_bwd_m<NDQ, NDV, false>(p, s);
 }
 
 bool rb_ndq_ok(int ndq) { return ndq == 2 || ndq == 3 || ndq == 4 || ndq == 6 || ndq == 8 || ndq == 12 || ndq == 16; }
@@ -380,8 +454,10 @@ size_t naf_xna_rows_bwd_workspace(const naf_xna_bwd_args* a) {
 // 1 when the row-streaming matrix-core backward serves the shapes (tables and workspace are checked at launch)
 int naf_xna_rows_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->ky != a->kx || (a->ky & 1) == 0 || a->ky > 15) return 0;
-    if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;   // integer ratio: k x k consecutive low-res cells per query
-    if (a->ky > a->h || a->kx > a->w) return 0;
+    if (a->Ho < a->h || a->Wo < a->w) return 0;
+    const bool integer_ratio = a->Ho % a->h == 0 && a->Wo % a->w == 0;
+    // integer ratio: k x k consecutive low-res cells per query; otherwise taps repeat and 16 consecutive queries must still fit 32 columns
+    if (integer_ratio ? (a->ky > a->h || a->kx > a->w) : (naf_tile_span(a->Wo, a->w, a->kx) > 32)) return 0;
     if (a->Dq % 32 != 0 || !rb_ndq_ok(a->Dq / 32)) return 0;
     if (rb_value_form(a) < 0) return 0;
     if (!rb_aligned(a->q) || !rb_aligned(a->k_lr)) return 0;
@@ -393,7 +469,7 @@ int naf_xna_rows_bwd_eligible(const naf_xna_bwd_args* a) {
 
 int naf_launch_xna_rows_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     if (!naf_xna_rows_bwd_eligible(a)) {
-        naf_set_error("naf_xna_bwd: the row-streaming MFMA backward needs an integer ratio, a square odd kernel <= 15 (<= h, w), "
+        naf_set_error("naf_xna_bwd: the row-streaming MFMA backward needs a square odd kernel <= 15 (<= h, w at integer ratios; 16 queries within 32 low-res columns otherwise), "
                       "Dq in {64,96,128,192,256,384,512} with Dv <= 32, or Dq = 64 with Dv in {32,64,96,128,192,256}, and 16-byte aligned "
                       "tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)", a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;
@@ -415,6 +491,7 @@ int naf_launch_xna_rows_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t 
     p.stats = static_cast<f32x4_t*>(a->workspace);
     p.idx_y = a->idx_y; p.idx_x = a->idx_x;
     p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w; p.Dv = a->Dv; p.ks = a->ky;
+    p.mult = (a->Ho % a->h == 0 && a->Wo % a->w == 0) ? 0 : 1;
     p.ntx[0] = (a->Wo + 15) / 16;
     p.ntx[1] = (a->w + 15) / 16;
     p.ntiles[0] = (int64_t)a->B * a->heads * a->Ho * p.ntx[0];

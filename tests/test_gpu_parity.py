@@ -748,7 +748,7 @@ def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
 
 
 @pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
-    (1, 256, 24, 4, (5, 7), (23, 30), 3),       # non-integer ratio (F4 shapes): irregular neighbourhoods, duplicates
+    (1, 160, 24, 4, (5, 7), (23, 30), 3),       # non-integer ratio (F4 shapes), heads of 40 dims: irregular neighbourhoods, duplicates
     (1, 80, 3, 1, (12, 10), (12, 10), 5),       # ratio 1, one head of 80 (no matrix-core instantiation), C = 3
     (2, 64, 16, 2, (4, 4), (16, 16), (3, 1)),   # rectangular window, Dq = 32, d = 4 (MFMA backward does not serve it)
 ])
@@ -818,6 +818,23 @@ def _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz):
     (1, 256, 512, 4, (8, 8), (64, 64), 3),       # ratio 8, Dv = 128
 ])
 def test_xna_backward_rows_integer_ratios(dev, B, Cq, C, heads, lr, out_sz, ksz):
+    _rows_backward_integer_doc(dev, B, Cq, C, heads, lr, out_sz, ksz)
+
+
+@pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
+    (1, 256, 24, 4, (5, 7), (23, 30), 3),        # F4 shapes: irregular neighbourhoods, repeated taps, six value channels per head
+    (4, 256, 768, 4, (13, 13), (32, 32), 9),     # `down_factor: random` training (utils/training.py:38-45): 512^2 * 0.4 -> 208^2 -> 13^2 features
+    (1, 256, 384, 4, (28, 28), (64, 64), 9),     # the notebook's geometry (F9): ratio 16/7
+    (1, 96, 3, 1, (20, 24), (30, 31), 7),        # one wide head, three value channels, ratio 1.5 / 1.29
+    (2, 128, 64, 2, (9, 10), (31, 17), 5),       # ratio 3.4 / 1.7, Dv = 32
+])
+def test_xna_backward_rows_noninteger_ratios(dev, B, Cq, C, heads, lr, out_sz, ksz):
+    """Non-integer ratios: taps repeat, so a (query, key) pair carries the product of its row and column multiplicities and the
+    keys' inverse neighbourhoods are found by scanning the tables."""
+    _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz)
+
+
+def _rows_backward_integer_doc(dev, B, Cq, C, heads, lr, out_sz, ksz):
     """Integer ratios the cell kernel does not take (cells narrower than a 16-pixel row tile, 15 x 15 windows): the row-streaming
     matrix-core backward with the key-stationary pass walking every query column chunk of the keys' inverse neighbourhood."""
     _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz)
