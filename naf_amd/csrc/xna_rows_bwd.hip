@@ -408,14 +408,16 @@ template <int NDQ, int NDV, bool MULT>
 int launch_rows_bwd_m(const XnaRowsBwdParams& p, hipStream_t s) {
     const size_t ldsq = (size_t)4 * 32 * (NDQ * 32 + 8) * sizeof(bf16_t);
     const size_t ldsk = ldsq + (NDV > 0 ? (size_t)4 * 32 * (NDV * 32 + 8) * sizeof(bf16_t) : 0);
-    static bool configured = false;   // per instantiation; the attribute is idempotent, so a race only repeats it
-    if (!configured) {
+    static bool configured_on[64] = {};   // per instantiation and device; the attribute is idempotent, so a race only repeats it
+    int devid = -1;
+    const bool cacheable = hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64;
+    if (!cacheable || !configured_on[devid]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, false, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, true, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk) != hipSuccess) {
             naf_set_error("naf_xna_bwd: cannot reserve %zu bytes of LDS", ldsk);
             return NAF_ERR_LAUNCH;
         }
-        configured = true;
+        if (cacheable) configured_on[devid] = true;
     }
     const int64_t cap = (int64_t)naf_cu_count() * 8;
     int64_t gq = (p.ntiles[0] + 3) / 4, gk = (p.ntiles[1] + 3) / 4;
