@@ -374,8 +374,8 @@ typedef struct naf_xna_bwd_args {
     int64_t workspace_bytes;
 } naf_xna_bwd_args;
 /* NAF_XNA_MFMA, NAF_XNA_ROWS or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run; negative naf_status on invalid arguments.
- * NAF_XNA_ROWS (round 3) is the matrix-core backward of every INTEGER ratio the cell kernel does not take (square window <= 15
- * that fits the low-res grid): the denoising call (denoising.py:213,301: ratio 1, one head of Dq = 64 ... 512 as in naf_xna_fwd's
+ * NAF_XNA_ROWS (round 3) is the matrix-core backward of the square windows <= 15 the cell kernel does not take, at any integer
+ * ratio and at non-integer ratios whose 16-query tiles stay within 32 low-res columns (tap multiplicities as in the forward): the denoising call (denoising.py:213,301: ratio 1, one head of Dq = 64 ... 512 as in naf_xna_fwd's
  * NAF_XNA_ROWS, Dv <= 32) and heads of 64 with Dv in {32, 64, 96, 128, 192, 256} at any integer ratio -- the reference's own
  * training step (train.py:113-133: 16^2 -> 32^2, ratio 2), patch-14 backbones (ratio 14), 15 x 15 windows.  It needs idx_y /
  * idx_x like the table-driven kernel AND `workspace` (per-query softmax statistics, 16 bytes per query); without a workspace
