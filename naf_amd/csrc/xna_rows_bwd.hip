@@ -11,7 +11,7 @@
 // 1.58 ms = 42 % of the GPU time of the reference's training step here).
 //
 // At an integer ratio every query attends to k x k CONSECUTIVE low-res cells whose first row / column (idx_y[y][0], idx_x[x][0])
-// is non-decreasing in y / x (tests/test_oracle.py::test_lowres_form_equals_dilated_form): ranges come from a
+// is non-decreasing in y / x (asserted by the low-res-form identity test in tests/): ranges come from a
 // bisection on the first taps and every weight is 0 or 1.  Otherwise (`mult`) a query's taps along an axis are a non-decreasing
 // run with repeats, the weight of a (query, key) pair is (row taps on the key's row) x (column taps on its column) exactly as in
 // xna_rows_kernel / xna_union_kernel, and the ranges come from a strided scan of the tables.
