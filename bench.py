@@ -421,15 +421,15 @@ def main():
         m = lambda k: timer.mean_ms(k)
         r4 = lambda v: round(v, 4) if v else None
         phases = {k: r4(m(k)) for k in ("stem", "stem_conv0", "stem_conv1", "stem_conv3", "rope_pool", "attention", "xna_mfma")}
-        if m("branch0_layers"):
-            # single-call mode: naf_forward records events at its phase boundaries (naf_forward_args.phase_events).  Branch 0 is
-            # the 1x1 branch (`encoder`), branch 1 the 3x3 branch (`sem_encoder`); a branch's block layers are nlayer launches of
-            # one kernel, so the per-launch figures are the phase / nlayer.  rope_pool includes the 9 us value packing.
+        if m("stem_layer_3x3"):
+            # single-call mode: naf_forward records events at its phase boundaries (naf_forward_args.phase_events, version >= 105).
+            # The two branches' layers alternate (first convolutions, then block layer 0 of both branches, layer 1 of both, ...),
+            # so the call brackets ONE launch of each layer kernel (stage 1): stem_conv1 / stem_conv3 are measured per-launch
+            # times, not phase / nlayer; the remainder of the stem is the other stages.  rope_pool includes the 9 us value packing.
             nl = 2 * len(list(model.image_encoder.encoder)[1:])
-            phases.update({"stem_conv0_1x1_stats": r4(m("branch0_conv0")), "stem_conv0_3x3": r4(m("branch1_conv0")),
-                           "stem_layers_1x1": r4(m("branch0_layers")), "stem_layers_3x3": r4(m("branch1_layers")),
-                           "stem_conv1": r4(m("branch0_layers") / nl), "stem_conv3": r4(m("branch1_layers") / nl),
-                           "layers_per_branch": nl, "source": f"hipEvents recorded inside the one naf_forward call, on {timer.count('stem')} of the {args.steps} timed steps"})
+            phases.update({"stem_first_convs": r4(m("stem_first_convs")), "stem_conv1": r4(m("stem_layer_1x1")), "stem_conv3": r4(m("stem_layer_3x3")),
+                           "layers_per_branch": nl, "stem_order": "layers of the two branches alternate (1x1, 3x3, 1x1, ...)",
+                           "source": f"hipEvents recorded inside the one naf_forward call, on {timer.count('stem')} of the {args.steps} timed steps"})
         if roof and m("rope_pool"):
             # a separate RoPE / key-pooling pass is overhead against the achieved fraction, not algorithmic traffic
             t_pre = (xna_ms + m("rope_pool")) * 1e-3

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 104 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 105 /* major*10000 + minor*100 + patch */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -441,10 +441,14 @@ typedef struct naf_forward_args {
     int64_t image_stride[4];
     int64_t feat_stride[4];
     /* optional hipEvent_t handles recorded on the stream at the phase boundaries of the forward (NULL entries skipped), so that a
-     * caller can time the phases of the ONE call: [0] start, [1] after branch 0's first convolution, [2] after branch 0's block
-     * layers, [3] after branch 1's first convolution, [4] after branch 1's block layers and the guidance pooling (= end of the
-     * conv stem), [5] after RoPE / key pooling, value packing and index tables (= start of the attention kernel), [6] after the
-     * attention kernel, [7] reserved.  Appended in 0.1.3 (naf_version() >= 103): callers that zero-initialise the struct need no change. */
+     * caller can time the parts of the ONE call.  Appended in 0.1.3 (naf_version() >= 103): callers that zero-initialise the struct
+     * need no change.  Since 0.1.5 (>= 105) the two branches' layers alternate -- first convolutions, block layer 0 of both
+     * branches, layer 1 of both, ...; within a stage the branch with 1x1 block layers goes first -- and the entries are:
+     * [0] start, [1] after both first convolutions, [2] before block-layer stage 1 (stage 0 when there is one layer), [3] after
+     * that stage's first launch (the 1x1 layer), [7] after its second launch (the 3x3 layer), [4] end of the conv stem (guidance
+     * pooled to the output size where needed), [5] after RoPE / key pooling, value packing and index tables (= start of the
+     * attention kernel), [6] after the attention kernel.  [3]-[2] and [7]-[3] time ONE launch of each layer kernel inside the
+     * call.  (103-104: [1] / [2] after branch 0's first convolution / block layers, [3] after branch 1's first convolution.) */
     void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);

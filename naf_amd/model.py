@@ -779,13 +779,14 @@ class NAF(nn.Module):
                     every = int(getattr(timer, "phases", 1) or 0)       # 0 / False: none; n: every n-th call (an event record
                     timer._calls = getattr(timer, "_calls", -1) + 1       # between two kernels costs ~5 us of device time)
                     if every > 0 and timer._calls % every == 0:
-                        # the phases of the ONE call (naf_forward_args.phase_events): both stem branches, first convolution and
-                        # block layers apart, the RoPE / key-pooling pre-pass, the attention
-                        pe = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+                        # the phases of the ONE call (naf_forward_args.phase_events, version >= 105: the branches' layers alternate):
+                        # the whole stem, both first convolutions, ONE launch of each block-layer kernel (stage 1), the RoPE /
+                        # key-pooling pre-pass, the attention
+                        pe = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
                         for e in pe:
                             e.record()
-                        for name, i, j in (("stem", 0, 4), ("branch0_conv0", 0, 1), ("branch0_layers", 1, 2), ("branch1_conv0", 2, 3),
-                                           ("branch1_layers", 3, 4), ("rope_pool", 4, 5), ("attention", 5, 6)):
+                        for name, i, j in (("stem", 0, 4), ("stem_first_convs", 0, 1), ("stem_layer_1x1", 2, 3), ("stem_layer_3x3", 3, 7),
+                                           ("rope_pool", 4, 5), ("attention", 5, 6)):
                             timer.pairs.setdefault(name, []).append((pe[i], pe[j]))
                 return plan.run(image, features, ev, return_logits=bool(return_weights), phase_events=pe)
         fuse_for = None

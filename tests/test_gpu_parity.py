@@ -1253,22 +1253,56 @@ def test_single_call_forward_phase_events(dev):
     plan = m._forward_plan(img, ft, (256, 256))
     assert plan is not None
     base = plan.run(img, ft).clone()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
     for e in ev:
         e.record()
     torch.cuda.synchronize()
     out = plan.run(img, ft, phase_events=ev)
     torch.cuda.synchronize()
     assert torch.equal(out, base)
-    gaps = [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
+    # stream order of the entries (version >= 105: the branches' layers alternate): [0] start, [1] first convolutions, [2] before
+    # block-layer stage 1, [3] after its 1x1 layer, [7] after its 3x3 layer, [4] stem end, [5] attention start, [6] attention end
+    order = [0, 1, 2, 3, 7, 4, 5, 6]
+    gaps = [ev[order[i]].elapsed_time(ev[order[i + 1]]) for i in range(7)]
     assert all(g >= 0.0 for g in gaps), gaps
     total = ev[0].elapsed_time(ev[6])
     assert total > 0.0 and abs(sum(gaps) - total) <= 1e-3 + 0.05 * total
-    assert gaps[3] > gaps[2] and gaps[5] > 0.0          # the 3x3 branch's layers outweigh its first convolution; attention ran
+    assert gaps[2] > 0.0 and gaps[3] > 0.0 and gaps[6] > 0.0     # one launch of each layer kernel was bracketed; attention ran
+    assert gaps[3] > gaps[2]                                       # the 3x3 layer outweighs the 1x1 layer
     sparse = [None, None, ev[2], None, ev[4]]           # only some boundaries asked for
     assert torch.equal(plan.run(img, ft, phase_events=sparse), base)
     torch.cuda.synchronize()
     assert ev[2].elapsed_time(ev[4]) > 0.0
+
+
+def test_single_call_forward_alternating_order_equals_sequential(dev):
+    """The stem's launch order (the two branches' layers alternate, three rotating activation buffers) does not change a bit of the
+    result: the same forward through a library instance with NAF_STEM_ORDER=0 (one branch after the other) in a child process."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from naf_amd import NAF\n"
+        "torch.manual_seed(5)\n"
+        "m = NAF(kernel_size=5).cuda().eval()\n"
+        "img = torch.rand(2, 3, 96, 80).cuda(); ft = torch.randn(2, 64, 6, 5).cuda()\n"
+        "with torch.no_grad(): o = m(img, ft, (96, 80))\n"
+        "torch.save(o.float().cpu(), sys.argv[1])\n")
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for order in ("0", None):
+            env = dict(os.environ, NAF_HIP_KNOBS="1")
+            env.pop("NAF_STEM_ORDER", None)
+            if order is not None:
+                env["NAF_STEM_ORDER"] = order
+            f = os.path.join(td, f"o{order}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("hw,lr,C,ksz,path", [
