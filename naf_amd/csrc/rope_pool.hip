@@ -315,7 +315,11 @@ __global__ __launch_bounds__(256) void rope_pool_keys_kernel(const RopePoolParam
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float o1, o2;
+#ifdef NAF_ROPE_ABL_NOROT   // measurement build: no rotation arithmetic (wrong keys), what the vector work costs inside the forward
+                    o1 = (float)va[u][i] + c0[i & 3] * 0.f; o2 = (float)vb[u][i] + s0[i & 3] * 0.f;
+#else
                     naf_rope_rotate((float)va[u][i], (float)vb[u][i], i < 4 ? c0[i & 3] : c1v[i & 3], i < 4 ? s0[i & 3] : s1v[i & 3], o1, o2);
+#endif
                     acc1[i] += ok ? o1 : 0.f;
                     acc2[i] += ok ? o2 : 0.f;
                 }
