@@ -447,20 +447,40 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 // at 1024^2: one segment of matrix work and epilogue per 32 pixels just to add up its outputs) by one read of the
 // 12 MB image.  The 9 moments are accumulated in the caller's (zeroed) stats slots, which the second kernel then
 // overwrites with the 16 group sums.
+// Round 3: four pixels per 16-byte (8-byte for bf16) load where the rows allow it (the scalar walk was latency-bound).  Folding the
+// second kernel into the last workgroup to finish (counter + fences) was measured and is slower: 29 us against 13.5 + 4.6.
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict__ img, int64_t ibs, int is1, int is2, int is3, int H, int W,
-                                                            double* __restrict__ stats) {
+                                                            double* __restrict__ stats, int vec4) {
     const int b = blockIdx.y;
     const T* ib = img + (int64_t)b * ibs;
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // S1[0..2], S2: 00 01 02 11 12 22
     const int64_t npx = (int64_t)H * W;
-#pragma unroll 4
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-        const int o = y * is2 + x * is3;
-        const double c0 = (double)(float)ib[o], c1 = (double)(float)ib[o + is1], c2 = (double)(float)ib[o + 2 * is1];
+    auto add = [&](float f0, float f1, float f2) __attribute__((always_inline)) {
+        const double c0 = (double)f0, c1 = (double)f1, c2 = (double)f2;
         m[0] += c0; m[1] += c1; m[2] += c2;
         m[3] += c0 * c0; m[4] += c0 * c1; m[5] += c0 * c2; m[6] += c1 * c1; m[7] += c1 * c2; m[8] += c2 * c2;
+    };
+    if (vec4) {   // uniform: x contiguous, W % 4 == 0, every row start aligned to four pixels
+        typedef T vec4_t __attribute__((ext_vector_type(4)));
+        const int64_t nq = npx >> 2;
+#pragma unroll 2
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+            const int64_t i = q << 2;
+            const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+            const int o = y * is2 + x;
+            const vec4_t v0 = *reinterpret_cast<const vec4_t*>(ib + o), v1 = *reinterpret_cast<const vec4_t*>(ib + o + is1),
+                         v2 = *reinterpret_cast<const vec4_t*>(ib + o + 2 * is1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) add((float)v0[e], (float)v1[e], (float)v2[e]);
+        }
+    } else {
+#pragma unroll 4
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
+            const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+            const int o = y * is2 + x * is3;
+            add((float)ib[o], (float)ib[o + is1], (float)ib[o + 2 * is1]);
+        }
     }
     __shared__ double red[4][9];
 #pragma unroll
@@ -513,16 +533,20 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     }
     if (a->y == nullptr && a->ksize == 1) {   // statistics of the 1x1 layer: from the image's moments, no matrix work
         const int64_t npx = (int64_t)a->H * a->W;
-        int nb = (int)((npx + 256 * 16 - 1) / (256 * 16));   // few workgroups: 9 fp64 atomics each land on the same 9 addresses
-        const int cap = naf_cu_count();
+        int nb = (int)((npx + 256 * 4 - 1) / (256 * 4));     // one 4-pixel load per lane and channel; 9 fp64 atomics per workgroup land on the same 9 addresses
+        const int cap = naf_cu_count();   // measured (gpurun r11h): 32 / 64 / 128 / 256 / 1024 workgroups -> 25.2 / 16.3 / 12.0 / 11.7 / 21.6 us
         nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
         const dim3 g((uint32_t)nb, (uint32_t)a->B), blk(256);
+        const int64_t* is = a->image_stride;
+        const size_t esz = a->image_dtype == NAF_BF16 ? 2 : 4;
+        const int vec4 = (is[3] == 1 && a->W % 4 == 0 && is[0] % 4 == 0 && is[1] % 4 == 0 && is[2] % 4 == 0 &&
+                          reinterpret_cast<uintptr_t>(a->image) % (4 * esz) == 0) ? 1 : 0;
         if (a->image_dtype == NAF_BF16)
             hipLaunchKernelGGL(conv0_moments_kernel<bf16_t>, g, blk, 0, s, static_cast<const bf16_t*>(a->image), a->image_stride[0],
-                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out);
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4);
         else
             hipLaunchKernelGGL(conv0_moments_kernel<float>, g, blk, 0, s, static_cast<const float*>(a->image), a->image_stride[0],
-                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out);
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4);
         hipLaunchKernelGGL(conv0_moment_sums_kernel, dim3((uint32_t)a->B), dim3(128), 0, s, a->stats_out, a->weight, a->bias, (double)npx);
         return naf_check_launch("conv0_moments_kernel");
     }
