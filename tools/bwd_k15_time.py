@@ -1,0 +1,25 @@
+"""15 x 15 windows at integer ratios (BASELINE configs[2]'s largest window): the cell backward does not take them (accumulators beyond
+the register file); round 3 routes them to the row-streaming matrix-core backward instead of the scalar table-driven kernel."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from naf_amd import ops
+dev = torch.device("cuda:0")
+def timed(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for lr, out, C, ks in ((32, 512, 1024, 15), (32, 512, 1024, 13), (32, 448, 384, 9), (16, 32, 768, 9)):
+    heads = 4
+    q = torch.randn(1, out, out, heads, 64, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    k = torch.randn(1, lr, lr, heads, 64, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    v = torch.randn(1, lr, lr, heads, C // heads, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    g = torch.randn(1, out, out, heads, C // heads, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    sel = ops.xna_backward_select(q, k, v, ks)
+    t = timed(lambda: ops.xna_backward(q, k, v, g, ks))
+    line = "%3d^2 -> %4d^2  C %4d  k %2d: backward path %-7s %9.3f ms" % (lr, out, C, ks, sel, t)
+    if sel == "rows" and out <= 512:
+        line += "   (scalar table-driven kernel: %9.3f ms)" % timed(lambda: ops.xna_backward(q, k, v, g, ks, path="generic"), n=1)
+    print(line)
