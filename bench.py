@@ -453,9 +453,11 @@ def main():
                                 + (", hipGraph replay" if args.graph else ""),
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
             "roofline": roof,
-            "phases_ms": phases,
-            "launches_per_step": {k: timer.count(k) // max(1, args.steps) for k in ("stem_conv0", "stem_conv1", "stem_conv3")},
+            "phases_ms": {k: v for k, v in phases.items() if v is not None},
         }
+        lps = {k: timer.count(k) // max(1, args.steps) for k in ("stem_conv0", "stem_conv1", "stem_conv3")}
+        if any(lps.values()):    # only the composed (multi-call) modes time every launch on its own
+            line["launches_per_step"] = lps
         if world > 1:
             line["ranks"] = ranks_info
             line["weak_leg"] = weak
