@@ -840,6 +840,46 @@ def _rows_backward_integer_doc(dev, B, Cq, C, heads, lr, out_sz, ksz):
     _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz)
 
 
+def test_rows_backward_fuzz_against_table_driven_kernel(dev):
+    """Seeded random geometries (ratios 1 .. 9 per axis, integer and not, every window size, ragged widths, both value forms): the
+    row-streaming matrix-core backward against the independent scalar table-driven kernel (fp32 throughout) on the same bf16 inputs."""
+    from naf_amd import ops
+    rng = np.random.RandomState(4321)
+    done = nonint = wide = 0
+    for _ in range(600):
+        ksz = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        h, w = int(rng.randint(ksz, 30)), int(rng.randint(ksz, 30))
+        if rng.rand() < 0.5:
+            Ho, Wo = h * int(rng.randint(1, 5)), w * int(rng.randint(1, 5))
+        else:
+            Ho, Wo = max(h, int(h * rng.uniform(1.0, 9.0) ** rng.uniform(0.0, 1.0))), max(w, int(w * rng.uniform(1.0, 9.0) ** rng.uniform(0.0, 1.0)))
+        if Ho * Wo > 90 * 90 or ksz * (Ho // h) > Ho or ksz * (Wo // w) > Wo:
+            continue
+        heads = int(rng.choice([1, 2]))
+        if rng.rand() < 0.5:
+            Dq, Dv = 64, int(rng.choice([32, 64, 96, 128, 192, 256]))
+        else:
+            Dq, Dv = int(rng.choice([64, 96, 128, 192, 256, 384, 512])), int(rng.randint(1, 33))
+        q = (torch.randn(1, heads, Ho, Wo, Dq, device=dev) * (64.0 / Dq) ** 0.25).to(torch.bfloat16)
+        k = (torch.randn(1, heads, h, w, Dq, device=dev) * (64.0 / Dq) ** 0.25).to(torch.bfloat16)
+        v = torch.randn(1, h, w, heads, Dv, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        g = torch.randn(1, Ho, Wo, heads, Dv, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        if ops.xna_backward_select(q, k, v, ksz) != "rows":
+            continue
+        a = ops.xna_backward(q, k, v, g, ksz)
+        b = ops.xna_backward(q, k, v, g, ksz, path="generic")
+        for x, y, name in zip(a, b, ("dq", "dk", "dv")):
+            scale = float(y.float().abs().max())
+            err = float((x.float() - y.float()).abs().max())
+            assert bool(torch.isfinite(x.float()).all()) and err <= 2.5e-2 * scale + 1e-3, (name, h, w, Ho, Wo, ksz, Dq, Dv, heads, err, scale)
+        done += 1
+        nonint += int(Ho % h != 0 or Wo % w != 0)
+        wide += int(Dq > 64)
+        if done >= 60:
+            break
+    assert done >= 40 and nonint >= 10 and wide >= 10, (done, nonint, wide)
+
+
 def test_xna_autograd_function(dev):
     """ops.XnaFunction: torch autograd drives naf_xna_fwd / naf_xna_bwd."""
     from naf_amd import ops
