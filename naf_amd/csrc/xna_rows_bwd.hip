@@ -30,6 +30,8 @@
 // fragments just loaded are also written to the wave's LDS segment [32 slots][D], and ds_read_b64_tr_b16 returns them
 // transposed (as xna_bwd_kernel.h does for the cell shapes).  No barrier: every wave works on its own segment.
 // NDV = Dv / 32 value k-steps; NDV = 0 is the few-channel form (Dv <= 32, any value: 2-byte gathers, one k-step).
+#include <type_traits>
+
 #include "naf_common.h"
 
 struct XnaRowsBwdParams {
@@ -44,6 +46,8 @@ struct XnaRowsBwdParams {
     const int32_t* idx_y;  // [Ho][ks]
     const int32_t* idx_x;  // [Wo][ks]
     int32_t B, heads, Ho, Wo, h, w, Dv, ks;
+    int32_t nsplit;        // keys stationary: the streamed query rows of a key tile are shared by this many waves (partial sums meet by atomics)
+    int32_t narrow;        // integer ratio and 16 consecutive queries within 16 low-res columns: the queries-stationary pass runs its 16-slot form
     int32_t mult;          // 1: non-integer ratio -- taps repeat (multiplicities) and their first row / column need not be monotone
     int32_t ntx[2];        // 16-element tiles per row: [0] queries, [1] keys
     int64_t ntiles[2];
@@ -94,7 +98,7 @@ __device__ __forceinline__ void overlapping_range(const int32_t* tab, int L, int
 constexpr int rb_regs_heavy(int ndq, int ndv) { return ndq >= 12 || ndv >= 6; }
 }  // namespace
 
-template <int NDQ, int NDV, bool KEYS, bool MULT>
+template <int NDQ, int NDV, bool KEYS, bool MULT, int NH>
 __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_rows_bwd_kernel(const XnaRowsBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rb[];
     constexpr int ROWLEN = NDQ * 32 + 8;   // elements; +16 B per row keeps the transposing reads off one bank group
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
     const int Ws = KEYS ? p.w : p.Wo, Hs = KEYS ? p.h : p.Ho;    // stationary grid
     const int Wt = KEYS ? p.Wo : p.w, Ht = KEYS ? p.Ho : p.h;    // streamed grid
     const int ntx = p.ntx[KEYS ? 1 : 0];
-    const int64_t ntiles = p.ntiles[KEYS ? 1 : 0];
+    const int nsplit = KEYS ? p.nsplit : 1;
+    const int64_t ntiles = p.ntiles[KEYS ? 1 : 0] * nsplit;
 
     // B operand of a second product for the 16-wide tile nt of a staged row block: lane (d = nt*16 + col), slots
     // (j>>2)*16 + grp*4 + (j&3) -- the order the S-type results hold their slots in
@@ -125,8 +130,18 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
         return o;
     };
 
+    // NH = 1 (queries stationary at ratios where 16 consecutive queries see at most 16 low-res columns: the host checks the canonical
+    // table): the upper 16 slots of a chunk never carry a neighbour -- no loads, no products, 16-slot second products.
+    // NH = 2: a chunk whose upper 16 slots carry no neighbour for any lane still skips them at run time (chunk ends, image borders);
+    // their stale copies in the LDS segment then meet zero weights in the second products, so the segment must never hold anything
+    // but finite numbers: cleared once here, afterwards it only ever holds copies of the inputs.
+    if constexpr (NH == 2)
+        for (int i = lane; i < SEGW / 8; i += 64)
+            reinterpret_cast<bf16x8_t*>(seg)[i] = bf16x8_t{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
         int64_t r = t;
+        const int seg_i = (int)(r % nsplit);   // which share of the streamed rows (keys stationary)
+        r /= nsplit;
         const int tx = (int)(r % ntx);
         r /= ntx;
         const int row = (int)(r % Hs);       // the stationary tile's row (query row y, or low-res key row)
@@ -194,11 +209,17 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
         }
         r0 = __builtin_amdgcn_readfirstlane(r0);
         r1 = __builtin_amdgcn_readfirstlane(min(r1, Ht - 1));
+        if (KEYS && nsplit > 1) {   // this wave's share of the rows
+            const int per = (r1 - r0 + nsplit) / nsplit;
+            r0 += seg_i * per;
+            r1 = min(r1, r0 + per - 1);
+        }
         xlo = __builtin_amdgcn_readfirstlane(xlo);
         xhi = __builtin_amdgcn_readfirstlane(xhi);
         // this lane's 8 slots of the chunk at xa: slot (hh, i) is streamed column xa + hh*16 + grp*4 + i; wx = how many column taps
         // of the query land on the key (0: not neighbours; 1 at integer ratios; repeats when the ratio is not an integer)
         float wx[2][4];
+        bool need_hi = true;     // uniform: some lane has a neighbour among slots 16 .. 31 of the chunk
         auto chunk_mask = [&](int xa) __attribute__((always_inline)) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
@@ -233,6 +254,7 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (!(xa + hh * 16 + grp * 4 + i < Wt && c_true < Ws)) wx[hh][i] = 0.f;
+            need_hi = __builtin_amdgcn_ballot_w64((wx[1][0] + wx[1][1] + wx[1][2] + wx[1][3]) > 0.f) != 0ull;
         };
         // how many row taps of the query on hi-res row y (keys stationary: streamed) or of the tile's own row land on low-res row ry
         auto row_weight = [&](int ry) __attribute__((always_inline)) {
@@ -248,11 +270,14 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
 
         // S and dP of one streamed row: s[hh][i], dp[hh][i] for slot (hh, i) and this lane's stationary element
         auto row_products = [&](int xa, int ry, bool stage, f32x4_t (&s)[2], f32x4_t (&dp)[2]) __attribute__((always_inline)) {
+            s[1] = dp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < NH; ++hh) {
+                s[hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                dp[hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (hh == 1 && !need_hi) continue;
                 const int xs = min(xa + hh * 16 + col, Wt - 1);
                 const bf16_t* t0 = tbase + (int64_t)ry * tst[2] + (int64_t)xs * tst[3] + grp * 8;
-                s[hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NDQ; ++ks) {
                     const bf16x8_t tf = *reinterpret_cast<const bf16x8_t*>(t0 + ks * 32);
@@ -261,7 +286,6 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
                 }
                 // dP: A = the streamed row's V (queries stationary) or dO (keys stationary), lane (slot col, channels kv*32 + grp*8 + j)
                 const bf16_t* u0 = tvbase + (int64_t)ry * tvst[2] + (int64_t)xs * tvst[3];
-                dp[hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 if constexpr (NDV > 0) {
 #pragma unroll
                     for (int kv = 0; kv < NDV; ++kv) {
@@ -356,7 +380,17 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
                         dsa[hh * 4 + i] = (bf16_t)(p.scale * pr * (dp[hh][i] - qdel));
                     }
 #pragma unroll
-                for (int nt = 0; nt < 2 * NDQ; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, tr_pair(seg, ROWLEN, nt), acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < 2 * NDQ; ++nt) {
+                    if constexpr (NH == 2) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, tr_pair(seg, ROWLEN, nt), acc[nt], 0, 0, 0);
+                    } else {   // 16 slots: the 16-key MFMA on the lower halves only (the segment's upper half is never written)
+                        const bf16_t* ta = seg + (grp * 4 + (col >> 2)) * ROWLEN + (col & 3) * 4 + nt * 16;
+                        const bf16x4_t kb4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)ta);
+                        bf16x4_t ds4;
+                        ds4[0] = dsa[0]; ds4[1] = dsa[1]; ds4[2] = dsa[2]; ds4[3] = dsa[3];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ds4, kb4, acc[nt], 0, 0, 0);
+                    }
+                }
                 if constexpr (KEYS) {
                     // dV[key][c] += P^T dO: B = dO, lane (channel nt*16 + col, slots in the A operand's order)
                     if constexpr (NDV > 0) {
@@ -387,11 +421,17 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
             if constexpr (KEYS) {
                 float* dkp = p.dk + ((((int64_t)b * p.h + row) * p.w + ce) * p.heads + head) * (int64_t)(NDQ * 32);
 #pragma unroll
-                for (int nt = 0; nt < 2 * NDQ; ++nt) dkp[nt * 16 + col] += acc[nt][i];
+                for (int nt = 0; nt < 2 * NDQ; ++nt) {
+                    if (nsplit > 1) atomicAdd(dkp + nt * 16 + col, acc[nt][i]);
+                    else dkp[nt * 16 + col] += acc[nt][i];
+                }
                 float* dvp = p.dv + ((((int64_t)b * p.h + row) * p.w + ce) * p.heads + head) * (int64_t)p.Dv;
 #pragma unroll
                 for (int nt = 0; nt < NVT; ++nt)
-                    if (nt * 16 + col < p.Dv) dvp[nt * 16 + col] += accv[nt][i];
+                    if (nt * 16 + col < p.Dv) {
+                        if (nsplit > 1) atomicAdd(dvp + nt * 16 + col, accv[nt][i]);
+                        else dvp[nt * 16 + col] += accv[nt][i];
+                    }
             } else {
                 bf16_t* dqp = p.dq + b * p.dqs[0] + head * p.dqs[1] + (int64_t)row * p.dqs[2] + (int64_t)ce * p.dqs[3];
 #pragma unroll
@@ -404,35 +444,36 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
 namespace {
 bool rb_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-template <int NDQ, int NDV, bool MULT>
-int launch_rows_bwd_m(const XnaRowsBwdParams& p, hipStream_t s) {
+template <int NDQ, int NDV, bool MULT, int NH>
+int launch_rows_bwd_mh(const XnaRowsBwdParams& p, hipStream_t s) {
     const size_t ldsq = (size_t)4 * 32 * (NDQ * 32 + 8) * sizeof(bf16_t);
     const size_t ldsk = ldsq + (NDV > 0 ? (size_t)4 * 32 * (NDV * 32 + 8) * sizeof(bf16_t) : 0);
     static bool configured_on[64] = {};   // per instantiation and device; the attribute is idempotent, so a race only repeats it
     int devid = -1;
     const bool cacheable = hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64;
     if (!cacheable || !configured_on[devid]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, false, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, true, MULT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, false, MULT, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(xna_rows_bwd_kernel<NDQ, NDV, true, MULT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsk) != hipSuccess) {
             naf_set_error("naf_xna_bwd: cannot reserve %zu bytes of LDS", ldsk);
             return NAF_ERR_LAUNCH;
         }
         if (cacheable) configured_on[devid] = true;
     }
     const int64_t cap = (int64_t)naf_cu_count() * 8;
-    int64_t gq = (p.ntiles[0] + 3) / 4, gk = (p.ntiles[1] + 3) / 4;
+    int64_t gq = (p.ntiles[0] + 3) / 4, gk = (p.ntiles[1] * p.nsplit + 3) / 4;
     gq = gq > cap ? cap : gq;
     gk = gk > cap ? cap : gk;
-    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, false, MULT>), dim3((uint32_t)gq), dim3(256), ldsq, s, p);   // statistics + dQ
+    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, false, MULT, NH>), dim3((uint32_t)gq), dim3(256), ldsq, s, p);   // statistics + dQ
     const int rc = naf_check_launch("xna_rows_bwd_kernel<queries>");
     if (rc != NAF_OK) return rc;
-    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, true, MULT>), dim3((uint32_t)gk), dim3(256), ldsk, s, p);    // dK, dV
+    hipLaunchKernelGGL((xna_rows_bwd_kernel<NDQ, NDV, true, MULT, 2>), dim3((uint32_t)gk), dim3(256), ldsk, s, p);    // dK, dV
     return naf_check_launch("xna_rows_bwd_kernel<keys>");
 }
 
 template <int NDQ, int NDV>
 int launch_rows_bwd(const XnaRowsBwdParams& p, hipStream_t s) {
-    return p.mult ? launch_rows_bwd_m<NDQ, NDV, true>(p, s) : launch_rows_bwd_m<NDQ, NDV, false>(p, s);
+    if (p.mult) return launch_rows_bwd_mh<NDQ, NDV, true, 2>(p, s);
+    return p.narrow ? launch_rows_bwd_mh<NDQ, NDV, false, 1>(p, s) : launch_rows_bwd_mh<NDQ, NDV, false, 2>(p, s);
 }
 
 bool rb_ndq_ok(int ndq) { return ndq == 2 || ndq == 3 || ndq == 4 || ndq == 6 || ndq == 8 || ndq == 12 || ndq == 16; }
@@ -494,6 +535,17 @@ int naf_launch_xna_rows_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t 
     p.idx_y = a->idx_y; p.idx_x = a->idx_x;
     p.B = a->B; p.heads = a->heads; p.Ho = a->Ho; p.Wo = a->Wo; p.h = a->h; p.w = a->w; p.Dv = a->Dv; p.ks = a->ky;
     p.mult = (a->Ho % a->h == 0 && a->Wo % a->w == 0) ? 0 : 1;
+    p.narrow = (!p.mult && naf_tile_span(a->Wo, a->w, a->kx) <= 16) ? 1 : 0;
+    {   // few key tiles with long inverse neighbourhoods (ratios of 4 and more on small feature grids): a tile's ~ratio * k query rows are
+        // shared by several waves until the launch has ~8 waves per CU; a share keeps at least 4 rows
+        static const int ns_knob = [] { const char* e = naf_knob("NAF_ROWS_BWD_SPLIT"); return e ? atoi(e) : 0; }();   // A/B knob
+        const int64_t ktiles = (int64_t)a->B * a->heads * a->h * ((a->w + 15) / 16);
+        const int64_t want = ((int64_t)naf_cu_count() * 8 + ktiles - 1) / ktiles;
+        const int64_t rows = (int64_t)(a->Ho / a->h + 1) * a->ky;
+        int64_t ns = want < rows / 4 ? want : rows / 4;
+        if (ns_knob > 0) ns = ns_knob;
+        p.nsplit = (int32_t)(ns < 1 ? 1 : (ns > 64 ? 64 : ns));
+    }
     p.ntx[0] = (a->Wo + 15) / 16;
     p.ntx[1] = (a->w + 15) / 16;
     p.ntiles[0] = (int64_t)a->B * a->heads * a->Ho * p.ntx[0];
