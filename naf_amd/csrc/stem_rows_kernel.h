@@ -58,7 +58,13 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n32 = lane & 31, half = lane >> 5;
+    // Workgroup -> tile: consecutive workgroups land on different XCDs (blockIdx % 8), each with its own L2.  Strips that are
+    // neighbours in x re-read 8 of each other's 40 pixel columns, so one XCD takes a run of consecutive tiles (a whole row band at
+    // G1) instead of every eighth strip (round 3: 350 MB of L2 misses per launch for 268 MB of input).  -DNAF_ROWS_NO_XCD_RUNS: dispatch order.
     int bid = blockIdx.x;
+#ifndef NAF_ROWS_NO_XCD_RUNS
+    if ((gridDim.x & 7u) == 0u) bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+#endif
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int seg = bid % p.segs_y;
