@@ -221,7 +221,7 @@ def main():
     # NAF_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
     # collectives go through gloo) -- for testing this script only, never for reported numbers
     backend = os.environ.get("NAF_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # a launcher that shows each rank ONE device still works (index 0 everywhere)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -334,8 +334,10 @@ def main():
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, ident)
         if backend == "nccl":
-            ids = [(r["uuid"], r["pci"]) for r in ranks_info]
-            if any(i != (None, None) for i in ids) and len(set(ids)) != world:
+            # identity = what the driver reports (UUID, PCI bus id) plus the device index the rank selected: a driver that hands
+            # out a placeholder UUID to every device must not fail a correctly launched job
+            ids = [(r["uuid"], r["pci"], r["device_index"]) for r in ranks_info]
+            if len(set(ids)) != world:
                 raise SystemExit(f"bench.py: {world} ranks on {len(set(ids))} distinct GPUs: {ids}")
         # Weak-scaling leg beside the strong one: every rank runs `micro_batch` images (one micro-batch, the same per-GPU work
         # at every N) between barriers; afterwards rank 0 runs the same alone.  Raw times only.
