@@ -15,7 +15,7 @@
 // bisection on the first taps and every weight is 0 or 1.  Otherwise (`mult`) a query's taps along an axis are a non-decreasing
 // run with repeats, the weight of a (query, key) pair is (row taps on the key's row) x (column taps on its column) exactly as in
 // xna_rows_kernel / xna_union_kernel, and the ranges come from a strided scan of the tables.
-// Two launches of ONE kernel template, both without atomics:
+// Two launches of ONE kernel template (no atomics unless a key tile's rows are shared between waves, see `nsplit`):
 //   * QUERIES stationary (KEYS = false): a wave owns 16 consecutive queries of an output row and streams the low-res rows of
 //     their windows (at most 32 low-res columns).  Pass 1 = the forward's online softmax (running max / sum) plus the running sum
 //     of e * dP, which gives delta = sum_j P_j dP_j without the forward's output; the per-query (max, 1 / sum, delta) go to the
@@ -23,6 +23,10 @@
 //   * KEYS stationary (KEYS = true): a wave owns 16 consecutive low-res keys of a row and streams the query rows whose windows
 //     contain that row, 32 query columns at a time; P and dS are rebuilt from the stored statistics;
 //     dK[key][d] += dS^T Q and dV[key][c] += P^T dO accumulate in registers over ALL queries of the key and are written once.
+//     When the launch would have fewer than ~8 waves per CU (few key tiles with long inverse neighbourhoods: ratios >= 4 on small
+//     grids), a tile's streamed rows are shared by `nsplit` waves whose partial sums meet by fp32 atomics.
+// Chunks are 32 streamed slots wide; a chunk whose upper 16 slots carry no neighbour skips them (NH = 1: statically for the
+// queries-stationary pass when the canonical table proves it, otherwise a uniform run-time test).
 // In both, the S-type products (S over the head dim, dP over the value channels) have the stationary tile as the B operand
 // (fragments in registers, 16 B per lane per 32 dims) and the streamed row as the A operand straight from L2, so their results
 // have a lane per stationary element holding 8 streamed slots -- which IS the A-operand layout of the second products
