@@ -379,7 +379,8 @@ typedef struct naf_xna_bwd_args {
  * NAF_XNA_ROWS, Dv <= 32) and heads of 64 with Dv in {32, 64, 96, 128, 192, 256} at any integer ratio -- the reference's own
  * training step (train.py:113-133: 16^2 -> 32^2, ratio 2), patch-14 backbones (ratio 14), 15 x 15 windows.  It needs idx_y /
  * idx_x like the table-driven kernel AND `workspace` (per-query softmax statistics, 16 bytes per query); without a workspace
- * the call runs the table-driven kernel instead.  It writes dk_lr / dv_lr without atomics (read-add-write of zeroed buffers). */
+ * the call runs the table-driven kernel instead.  It adds into the zeroed dk_lr / dv_lr like the other kernels (one read-add-write per key, or fp32
+ * atomics where a key tile's rows are shared between waves). */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
