@@ -669,11 +669,18 @@ class ForwardPlan:
     def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False, phase_events=None):
         a = self.args
         dev = image.device
-        # the workspace belongs to the plan (one allocation per geometry, not per call); like the reference's RoPE cache
-        # (rope.py:159-163) this makes a module non-reentrant across streams / threads
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.device != dev:
-            ws = self._ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+        # the workspace belongs to the plan (one allocation per geometry, not per call) -- one per (device, stream) the plan has
+        # been run on (round 3: forwards of one module on two streams no longer share scratch; the four most recent are kept).
+        # Host-side state (the argument struct) is still per plan: calls from several THREADS need a module each.
+        skey = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+        pool = self.__dict__.setdefault("_ws_by_stream", {})
+        ws = pool.pop(skey, None)
+        if ws is None:
+            ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+            while len(pool) >= 4:
+                pool.pop(next(iter(pool)))     # least recently used (dicts keep insertion order)
+        pool[skey] = ws
+        self._ws = ws                           # the one the last call used (GraphedForward keeps it alive)
         out = torch.empty(self.shape_out, dtype=self.out_dtype, device=dev)
         a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), out.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes

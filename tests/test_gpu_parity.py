@@ -1315,6 +1315,26 @@ def test_single_call_forward_phase_events(dev):
     assert ev[2].elapsed_time(ev[4]) > 0.0
 
 
+def test_forward_on_two_streams_does_not_share_scratch(dev):
+    """a ForwardPlan used to own ONE workspace, so forwards of one module enqueued on two streams raced on the
+    stem's activation buffers.  Every (device, stream) now gets its own: two different inputs enqueued back to back on two streams give
+    exactly what they give one after the other."""
+    p = O.make_params(seed=45)
+    m = _load_model(dev, p, kernel_size=7)
+    img_a, img_b = O.hash_normal((1, 3, 512, 512), 981).to(dev), O.hash_normal((1, 3, 512, 512), 982).to(dev)
+    ft = O.hash_normal((1, 128, 32, 32), 983).to(dev).to(torch.bfloat16)
+    ref_a, ref_b = m(img_a, ft, (512, 512)).clone(), m(img_b, ft, (512, 512)).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            out_a = m(img_a, ft, (512, 512))
+        with torch.cuda.stream(s2):
+            out_b = m(img_b, ft, (512, 512))
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
+
+
 def test_single_call_forward_alternating_order_equals_sequential(dev):
     """The stem's launch order (the two branches' layers alternate, three rotating activation buffers) does not change a bit of the
     result: the same forward through a library instance with NAF_STEM_ORDER=0 (one branch after the other) in a child process."""
