@@ -182,8 +182,8 @@ def measure_traffic_live(workload, per_gpu_batch, timeout_s=90):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 on one GPU = ~0.5 s of device time, so that "
-                    "a utilisation sampler sees the timed region; 10 on several GPUs, where a step is the whole 64-image batch)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 on one GPU = ~2 s of device time, so that "
+                    "a utilisation sampler sees the timed region; 30 on several GPUs, where a step is the whole 64-image batch)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--phase-every", type=int, default=8, help="record the per-phase events on every n-th timed step")
     ap.add_argument("--no-phase-events", action="store_true", help="do not record the per-phase events inside naf_forward "
@@ -211,7 +211,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.steps is None:
-        args.steps = 200 if world == 1 else 10
+        args.steps = 1000 if world == 1 else 30
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
