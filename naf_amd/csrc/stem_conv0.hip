@@ -365,15 +365,28 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[q][j * 4 + i] = bj[i];
                 }
+            // the two weight fragments of step i + 1 are requested before the two MFMAs of step i (two register sets pinned by
+            // sched_barriers; left alone hipcc reads every fragment right in front of its MFMA -- the 1x1 layer's lesson, round 3)
+            {
+                constexpr int NSTEP = (6 - T0) * 2;
+                bf16x8_t af[2][2];
+                auto frag = [&](int i, int slot) __attribute__((always_inline)) {
+                    const int ts = T0 * 2 + i;   // = t * 2 + s
 #pragma unroll
-            for (int t = T0; t < 6; ++t)
+                    for (int q = 0; q < 2; ++q) af[slot][q] = *reinterpret_cast<const bf16x8_t*>(wa + (ts * C0 + 32 * (2 * mp + q)) * 16);
+                };
+                frag(0, 0);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int i = 0; i < NSTEP; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i + 1 < NSTEP) frag(i + 1, (i + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int t = T0 + (i >> 1), s = i & 1;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(wa + ((t * 2 + s) * C0 + 32 * (2 * mp + q)) * 16);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[split_xpart(t)][s], acc[q], 0, 0, 0);
-                    }
+                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][q], xb[split_xpart(t)][s], acc[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
