@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     using F = std::false_type;
     const bool edge = (sx + TW > p.W) || ((sy_end - sy) % 4 != 0);
     long long tm0 = 0;
-    if constexpr ((ABL & 128) != 0) tm0 = (long long)__builtin_readcyclecounter();
+    long long rt0 = 0;
+    if constexpr ((ABL & 128) != 0) { tm0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
     if (!edge) {
         // Whole strip, rows a multiple of four: the last body stops after its first double-step (input rows R, R + 1 for R rows:
         // the last real output row R is complete then) and the epilogue of that row runs below without the two drain row-steps
@@ -375,6 +376,10 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     if constexpr ((ABL & 128) != 0) {   // probe: shader cycles per double-step of this wave (stats_out + 64 .. are scratch there)
         const long long tm1 = (long long)__builtin_readcyclecounter();
         if (lane == 0 && blockIdx.x < 64) p.stats_out[64 + blockIdx.x * 4 + wave] = (double)(tm1 - tm0) / (edge ? 2.0 * nbody : 2.0 * nbody - 1.0);
+        if (lane == 0 && wave == 0 && blockIdx.x < 1024) {   // whole loop, per workgroup (XCD = blockIdx % 8): shader cycles and 100 MHz wall ticks
+            p.stats_out[1024 + blockIdx.x] = (double)(tm1 - tm0);
+            p.stats_out[2048 + blockIdx.x] = (double)((long long)__builtin_amdgcn_s_memrealtime() - rt0);
+        }
     }
     if (!edge) {
         // tail of a whole segment (R = sy_end - sy rows, R % 4 == 0): output row R (relative) = image row sy_end - 1 sits complete in

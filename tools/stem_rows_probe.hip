@@ -73,6 +73,23 @@ int main(int argc, char** argv) {
     RUN(0, "full") RUN(64, "full, no slot pins") RUN(1, "no commit (GN+SiLU, ring writes)") RUN(2, "no epilogue") RUN(8, "no row stores") RUN(16, "no global loads")
     RUN(24, "no global loads, no row stores") RUN(27, "LDS reads + MFMA + barrier") RUN(31, "MFMA + barrier only") RUN(27 + 64, "LDS reads + MFMA + barrier, no pins")
     RUN(256, "full, loads issued but never consumed") RUN(25, "epilogue + LDS reads + MFMA") RUN(26, "commit + LDS reads + MFMA") RUN(0, "full")
+    {   // the last variant run is "full": loop cycles per workgroup, by XCD (blockIdx % 8) -- how uneven the eight dies are
+        std::vector<double> h(1024); CK(hipMemcpy(h.data(), stats + 16 + 1024, 1024 * 8, hipMemcpyDeviceToHost));
+        double mn[8], mx[8], av[8]; int cnt[8];
+        for (int x = 0; x < 8; ++x) { mn[x] = 1e30; mx[x] = 0; av[x] = 0; cnt[x] = 0; }
+        for (int i = 0; i < nb && i < 1024; ++i) { const int x = i & 7; mn[x] = h[i] < mn[x] ? h[i] : mn[x]; mx[x] = h[i] > mx[x] ? h[i] : mx[x]; av[x] += h[i]; ++cnt[x]; }
+        double gmin = 1e30, gmax = 0;
+        for (int x = 0; x < 8; ++x) { av[x] /= cnt[x] ? cnt[x] : 1; gmin = av[x] < gmin ? av[x] : gmin; gmax = av[x] > gmax ? av[x] : gmax; }
+        printf("loop cycles per workgroup by XCD (mean, min-max), thousands:");
+        for (int x = 0; x < 8; ++x) printf("  %d: %.1f (%.1f-%.1f)", x, av[x] / 1e3, mn[x] / 1e3, mx[x] / 1e3);
+        printf("\n  slowest / fastest XCD mean: %.3f\n", gmax / gmin);
+        std::vector<double> r(1024); CK(hipMemcpy(r.data(), stats + 16 + 2048, 1024 * 8, hipMemcpyDeviceToHost));
+        double ra[8] = {0}; int rc[8] = {0};
+        for (int i = 0; i < nb && i < 1024; ++i) { ra[i & 7] += r[i]; ++rc[i & 7]; }
+        printf("  wall time per workgroup by XCD (us, 100 MHz ticks / 100) and implied clock (GHz):");
+        for (int x = 0; x < 8; ++x) printf("  %d: %.1f us %.2f", x, ra[x] / rc[x] / 100.0, av[x] / (ra[x] / rc[x] * 10.0));
+        printf("\n");
+    }
     for (int i = 0; i < na; ++i)
         printf("row-streaming %-40s %.4f ms  %7.1f TFLOP/s  %7.0f cycles per double-step (144 MFMAs = 4608)  => %.2f GHz\n", abl[i].name, abl[i].ms,
                flops / abl[i].ms / 1e9, abl[i].cyc, abl[i].cyc * 2.0 * ((p.seg_h + 6) / 4) / (abl[i].ms * 1e6));
