@@ -13,7 +13,8 @@ void naf_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprint
 int naf_check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return 1; } return 0; }
 int naf_cu_count() { return 256; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
-int main() {
+int main(int argc, char** argv) {
+    const bool img_mode = argc > 1 && argv[1][0] == 'i';   // `img`: the first layer of the 1x1 branch (input recomputed from the image)
     const int H = 1024, W = 1024;
     void *x, *y, *w; float *b, *ga, *be; double *si, *so;
     const size_t act = (size_t)H * W * 128 * 2;
@@ -32,13 +33,27 @@ int main() {
     a.ksize = 1; a.B = 1; a.H = H; a.W = W; a.eps = 1e-5f; a.channels = 128;
     const int64_t st[3] = {(int64_t)H * W * 128, (int64_t)W * 128, 128};
     for (int i = 0; i < 3; ++i) { a.x_stride[i] = st[i]; a.y_stride[i] = st[i]; }
+    naf_stem_conv0_args f{};
+    float *image, *w0, *b0;
+    CK(hipMalloc(&image, (size_t)3 * H * W * 4)); CK(hipMalloc(&w0, 128 * 3 * 4)); CK(hipMalloc(&b0, 512));
+    {
+        std::vector<float> hi((size_t)3 * H * W);
+        for (size_t i = 0; i < hi.size(); ++i) hi[i] = (float)((i * 2654435761u) >> 8) / 16777216.0f - 0.5f;
+        CK(hipMemcpy(image, hi.data(), hi.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w0, hi.data(), 128 * 3 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b0, hi.data(), 512, hipMemcpyHostToDevice));
+    }
+    if (img_mode) {
+        f.image = image; f.weight = w0; f.bias = b0; f.image_dtype = NAF_F32; f.ksize = 1; f.B = 1; f.H = H; f.W = W; f.channels = 128;
+        const int64_t is[4] = {(int64_t)3 * H * W, (int64_t)H * W, W, 1};
+        for (int i = 0; i < 4; ++i) f.image_stride[i] = is[i];
+        a.x = nullptr; a.first = &f;
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) naf_launch_stem_conv1x1(&a, 0);
     CK(hipEventRecord(e0));
     for (int i = 0; i < 20; ++i) naf_launch_stem_conv1x1(&a, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("stem_conv1x1_kernel 1024x1024: %.4f ms per launch\n", ms / 20);
+    printf("stem_conv1x1_kernel%s 1024x1024: %.4f ms per launch\n", img_mode ? " (first layer: input recomputed from the image)" : "", ms / 20);
 #ifdef NAF_C1_TIMING
     std::vector<unsigned long long> t(512 * NW1 * 8);
     CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_c1_tim), t.size() * 8));
