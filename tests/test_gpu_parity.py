@@ -1315,6 +1315,48 @@ def test_single_call_forward_phase_events(dev):
     assert ev[2].elapsed_time(ev[4]) > 0.0
 
 
+@pytest.mark.parametrize("B,heads,lr,out_sz,Dq,Dv,ksz,kernel", [
+    (2, 4, (16, 16), (32, 32), 64, 192, 9, "rows"),       # train.py's own step geometry: row-streaming kernel, tables + workspace
+    (1, 4, (6, 5), (96, 80), 64, 32, 5, "mfma"),          # cell kernel: nothing but the tensors
+    (1, 2, (7, 9), (7, 9), 80, 3, 3, "generic"),          # no matrix-core instantiation: table-driven scalar kernel, tables only
+])
+def test_c_host_backward_program_matches_python(dev, tmp_path, B, heads, lr, out_sz, Dq, Dv, ksz, kernel):
+    """examples/c_host_bwd.c -- a plain C program (gcc, HIP runtime API, include/naf_hip.h) -- runs naf_xna_bwd on the same inputs as
+    the Python host: it asks naf_xna_bwd_supported which kernel serves the shapes and brings the index tables / the statistics
+    workspace that kernel wants.  dq matches bit for bit; dk / dv too unless partial sums meet by atomics (row sharing)."""
+    import shutil, subprocess
+    from naf_amd import _lib, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers on this box")
+    exe = str(tmp_path / "c_host_bwd")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include", f"{root}/examples/c_host_bwd.c", "-o", exe,
+                    f"-L{libdir}", "-lnaf_hip", "-L/opt/rocm/lib", "-lamdhip64"], check=True, capture_output=True)
+    mk = lambda shape, seed: O.hash_normal(shape, seed).to(torch.bfloat16)
+    q = mk((B, *out_sz, heads, Dq), 1501); k = mk((B, *lr, heads, Dq), 1502)
+    v = mk((B, *lr, heads, Dv), 1503); g = mk((B, *out_sz, heads, Dv), 1504)
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (g, "dout")):
+        (tmp_path / f"{name}.bin").write_bytes(t.contiguous().view(torch.int16).numpy().astype("<i2").tobytes())
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe] + [str(tmp_path / f"{n}.bin") for n in ("q", "k", "v", "dout", "dq", "dk", "dv")] +
+                       [str(x) for x in (B, heads, *out_sz, *lr, Dq, Dv, ksz)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"kernel {kernel}" in r.stdout, r.stdout
+    to5 = lambda t: t.to(dev).permute(0, 3, 1, 2, 4)
+    dq, dk, dv = ops.xna_backward(to5(q), to5(k), to5(v), to5(g), ksz)
+    assert ops.xna_backward_select(to5(q), to5(k), to5(v), ksz) == kernel
+    got_dq = torch.from_numpy(np.frombuffer((tmp_path / "dq.bin").read_bytes(), dtype="<i2").copy()).view(torch.bfloat16).view(B, *out_sz, heads, Dq)
+    got_dk = torch.from_numpy(np.frombuffer((tmp_path / "dk.bin").read_bytes(), dtype="<f4").copy()).view(B, *lr, heads, Dq)
+    got_dv = torch.from_numpy(np.frombuffer((tmp_path / "dv.bin").read_bytes(), dtype="<f4").copy()).view(B, *lr, heads, Dv)
+    assert torch.equal(got_dq, dq.permute(0, 2, 3, 1, 4).cpu().contiguous())
+    for got, ref, name in ((got_dk, dk, "dk"), (got_dv, dv, "dv")):
+        ref = ref.permute(0, 2, 3, 1, 4).cpu().contiguous()
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-5 * scale + 1e-7, name      # fp32 atomics: the order of the partial sums is free
+
+
 def test_forward_on_two_streams_does_not_share_scratch(dev):
     """a ForwardPlan used to own ONE workspace, so forwards of one module enqueued on two streams raced on the
     stem's activation buffers.  Every (device, stream) now gets its own: two different inputs enqueued back to back on two streams give
