@@ -59,7 +59,7 @@ def test_training_struct_layouts_match_header(built_lib):
     from naf_amd import _lib
     pairs = [("naf_stem_act_args", _lib.StemActArgs, "a_stride"), ("naf_stem_act_bwd_args", _lib.StemActBwdArgs, "dx_stride"),
              ("naf_stem_wgrad_args", _lib.StemWgradArgs, "x_stride"), ("naf_stem_conv0_wgrad_args", _lib.StemConv0WgradArgs, "image_stride"),
-             ("naf_rope_pool_bwd_args", _lib.RopePoolBwdArgs, "dx_stride")]
+             ("naf_rope_pool_bwd_args", _lib.RopePoolBwdArgs, "dx_stride"), ("naf_xna_bwd_args", _lib.XnaBwdArgs, "workspace_bytes")]
     body = "".join(f'printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {last}));' for c, _, last in pairs)
     src = '#include "naf_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){' + body + 'return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
