@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 105 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -133,6 +133,30 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream);
  * output, w_packed = the flipped, transposed weights [k*k][128 ic][128 oc] (= weight.flip(2,3).permute(2,3,1,0)).  For the
  * 3x3 layers (reflect padding) run it over the output gradient embedded in a 2-pixel ZERO border ((H+4) x (W+4)): rows /
  * columns 1 .. H+2 of the result are the gradient on the padded domain, whose border naf_stem_act_bwd(fold) folds back. */
+
+/* naf_stem_conv_keys_fwd (0.2.0): naf_stem_conv_fwd for the LAST block layer of a branch, which ALSO writes that branch's
+ * slice of the pooled keys -- KeyEncoder's adaptive_avg_pool2d of the RoPE'd guidance (naf.py:63-69 after rope.py:139-153) --
+ * so that no pass re-reads the guidance.  It uses that the rotation is AXIAL (rope.py:139-143: inside a 64-wide head, dims
+ * [0,16) u [32,48) turn by the ROW angle only, [16,32) u [48,64) by the COLUMN angle only) and that pooling is linear:
+ * the mean of the rotated pixels of a cell = the rotation, by row r's angle, of the cell's un-rotated sum over its columns in row r
+ * (row-angle dims), resp. by column c's angle of the sum over its rows in column c (column-angle dims).  The kernel takes those
+ * sums of the bf16 outputs it has just produced (on the matrix pipe, from the tile that is in the LDS for the row stores),
+ * rotates the 16 + 16 sums per channel pair in fp32 and writes bf16 keys: the same guidance values the queries are read from.
+ *   a        as for naf_stem_conv_fwd: 128 channels, stats_out == NULL, first == NULL, GroupNorm / SiLU mode
+ *   kp->k_lr device bf16, the branch's 128 key channels: [B, h, w, >= 128] by k_stride = {b, y, x} (pointer at the slice's
+ *            first channel); tab_y / tab_x the tables of naf_rope_tables for (H, W) with 16 periods (heads of 64 channels)
+ *   16 x 16 pixel cells only: H == 16 h, W == 16 w, W a multiple of 32 for ksize 3.
+ * naf_stem_conv_keys_supported: 1 when this call would be served, 0 when the caller has to run naf_stem_conv_fwd and
+ * naf_rope_pool_fwd instead, negative naf_status on invalid arguments. */
+typedef struct naf_key_pool_args {
+    void* k_lr;
+    const float* tab_y; /* [H][2][16] */
+    const float* tab_x; /* [W][2][16] */
+    int32_t h, w;
+    int64_t k_stride[3];
+} naf_key_pool_args;
+int naf_stem_conv_keys_supported(const naf_stem_conv_args* a, const naf_key_pool_args* kp);
+int naf_stem_conv_keys_fwd(const naf_stem_conv_args* a, const naf_key_pool_args* kp, naf_stream_t stream);
 
 /* ---- training companions of the conv stem --------------------------------------------------------------
  * naf_stem_act_fwd : a = SiLU(GroupNorm(8, C)(x)) in bf16 (convolutions.py:52-55 / :58-59, the tensor naf_stem_conv_fwd never

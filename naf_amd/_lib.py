@@ -61,6 +61,13 @@ class StemConvArgs(C.Structure):
     ]
 
 
+class KeyPoolArgs(C.Structure):
+    _fields_ = [
+        ("k_lr", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32),
+        ("k_stride", I64x3),
+    ]
+
+
 class RopePoolBwdArgs(C.Structure):
     _fields_ = [
         ("dq", C.c_void_p), ("dk_lr", C.c_void_p), ("dx", C.c_void_p), ("tab_y", C.c_void_p), ("tab_x", C.c_void_p),
@@ -144,6 +151,8 @@ SIGNATURES = {
     "naf_axis_index_table_device": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_stem_conv0_fwd": (C.c_int, [C.POINTER(StemConv0Args), C.c_void_p]),
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),
+    "naf_stem_conv_keys_supported": (C.c_int, [C.POINTER(StemConvArgs), C.POINTER(KeyPoolArgs)]),
+    "naf_stem_conv_keys_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.POINTER(KeyPoolArgs), C.c_void_p]),
     "naf_rope_pool_bwd": (C.c_int, [C.POINTER(RopePoolBwdArgs), C.c_void_p]),
     "naf_stem_wgrad": (C.c_int, [C.POINTER(StemWgradArgs), C.c_void_p]),
     "naf_stem_conv0_wgrad": (C.c_int, [C.POINTER(StemConv0WgradArgs), C.c_void_p]),

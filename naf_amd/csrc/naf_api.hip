@@ -153,6 +153,37 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream));
 }
 
+static int stem_conv_keys_validate(const naf_stem_conv_args* a, const naf_key_pool_args* kp) {
+    NAF_REQUIRE(a != nullptr && kp != nullptr, "naf_stem_conv_keys_fwd: args is NULL");
+    NAF_REQUIRE(a->x && a->y && a->w_packed && a->bias && a->gn_weight && a->gn_bias && a->stats_in, "naf_stem_conv_keys_fwd: NULL pointer");
+    NAF_REQUIRE(kp->k_lr && kp->tab_y && kp->tab_x, "naf_stem_conv_keys_fwd: NULL key / table pointer");
+    NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_conv_keys_fwd: kernel size %d (1 or 3)", a->ksize);
+    NAF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && kp->h > 0 && kp->w > 0, "naf_stem_conv_keys_fwd: non-positive size");
+    NAF_REQUIRE(al16(a->x) && al16(a->y) && al16(a->w_packed), "naf_stem_conv_keys_fwd: tensors must be 16-byte aligned");
+    for (int i = 0; i < 3; ++i)
+        NAF_REQUIRE(a->x_stride[i] % 8 == 0 && a->y_stride[i] % 8 == 0, "naf_stem_conv_keys_fwd: strides must be multiples of 8 elements");
+    return NAF_OK;
+}
+
+int naf_stem_conv_keys_supported(const naf_stem_conv_args* a, const naf_key_pool_args* kp) {
+    const int rc = stem_conv_keys_validate(a, kp);
+    if (rc != NAF_OK) return -rc;
+    if (a->ksize == 1) return naf_stem_conv1x1_keys_ok(a, kp);
+    return naf_stem_conv_keys_ok(a, kp);
+}
+
+int naf_stem_conv_keys_fwd(const naf_stem_conv_args* a, const naf_key_pool_args* kp, naf_stream_t stream) {
+    const int sup = naf_stem_conv_keys_supported(a, kp);
+    if (sup < 0) return -sup;
+    if (sup == 0) {
+        naf_set_error("naf_stem_conv_keys_fwd: needs the 128-channel forward layer on 16 x 16 pixel cells (H = 16 h, W = 16 w, dense rows, "
+                      "stats_out == NULL, first == NULL; 3x3: W a multiple of 32); run naf_stem_conv_fwd + naf_rope_pool_fwd instead");
+        return NAF_ERR_UNSUPPORTED;
+    }
+    if (a->ksize == 1) return naf_launch_stem_conv1x1(a, static_cast<hipStream_t>(stream), kp);
+    return naf_launch_stem_conv(a, static_cast<hipStream_t>(stream), kp);
+}
+
 int naf_rope_pool_bwd(const naf_rope_pool_bwd_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a != nullptr, "naf_rope_pool_bwd: args is NULL");
     NAF_REQUIRE(a->dq && a->dk_lr && a->dx && a->tab_y && a->tab_x, "naf_rope_pool_bwd: NULL pointer");

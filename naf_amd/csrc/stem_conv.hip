@@ -8,7 +8,16 @@
 // profiles/r03_stem_rows_probe.txt).
 #include "stem_rows_kernel.h"
 
-int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s) {
+int naf_stem_conv_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp) {
+    (void)a; (void)kp;
+    return 0;   // TODO(3x3)
+}
+
+int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp) {
+    if (kp != nullptr) {
+        naf_set_error("naf_stem_conv_keys_fwd: 3x3 kernel not available");
+        return NAF_ERR_UNSUPPORTED;
+    }
     StemConvParams p;
     p.x = static_cast<const bf16_t*>(a->x);
     p.y = static_cast<bf16_t*>(a->y);

@@ -37,6 +37,14 @@ struct StemConv1Params {
     const float* b0;   // [128]
     int64_t ibs;       // image batch stride
     int32_t is[4];     // {unused, c, y, x} element strides (< 2^31, validated by the launcher)
+    // POOL variant (naf_stem_conv_keys_fwd): the branch's slice of the pooled keys, 16 x 16 pixel cells
+    bf16_t* kout;      // [B, h, w, >= 128] by kst = {b, y, x}
+    const float* tab_y;  // [H][2][16]
+    const float* tab_x;  // [W][2][16]
+    int64_t kst[3];
+    int32_t cw;              // cells per cell row (W / 16)
+    int32_t ncell;           // cells per image
+    int32_t cells_per_block; // a workgroup owns this many consecutive cells (its waves interleave inside that range)
 };
 
 namespace {
@@ -63,9 +71,19 @@ __device__ unsigned long long g_c1_tim[4096 * 8];
 // constant lane offset per access, a branch-free loop body (which also keeps hipcc's vmcnt waits exact).
 // PLAIN (stats_in == NULL in the C ABI): no GroupNorm, no SiLU -- y = conv1x1(x) (+ bias if given); with the transposed
 // weights this is the layer's data gradient.
-template <bool IMG, typename T, bool DENSE, bool PLAIN = false>
+// POOL (naf_stem_conv_keys_fwd; the branch's last layer, DENSE only): a group is 2 rows x 16 columns of one 16 x 16 pixel cell,
+// a wave walks the 8 groups of a cell and then moves to its next cell.  After a group's result tile is in the LDS, eight small
+// MFMAs (v_mfma_f32_16x16x32_bf16, B = the tile read back TRANSPOSED with ds_read_b64_tr_b16: contraction over the group's 32
+// pixels, A = a 0/1 indicator) add it to the cell's un-rotated sums: for the column-angle channels of a head (dims [16,32) and
+// [48,64), rope.py:139-143) the sum over rows per column (A[m][px] = col(px) == m), for the row-angle channels ([0,16) and
+// [32,48)) the sum over columns per row (A[m][px] = row(px) == m): 8 tiles x 16 x 16 sums = 32 registers.  After the cell's
+// eighth group the sums are rotated by their column's / row's angle (fp32, the tables of naf_rope_tables), added up, scaled by
+// 1/256 and written as bf16 keys: KeyEncoder's adaptive_avg_pool2d of the rotated guidance (naf.py:63-69) without a second
+// pass over the guidance.  No GroupNorm sums (the last layer has no successor).
+template <bool IMG, typename T, bool DENSE, bool PLAIN = false, bool POOL = false>
 __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_kernel(const StemConv1Params p) {
     static_assert(!(IMG && PLAIN), "the recomputed-conv0 input exists for the forward layer only");
+    static_assert(!POOL || (DENSE && !IMG && !PLAIN), "key pooling: dense forward layer reading its input from memory");
 #ifdef NAF_C1_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -82,8 +100,8 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     // Work -> memory map.  Round 1: group g = blockIdx.x * NW1 + wave, then += gridDim.x * NW1 (a persistent grid-stride walk).
     // Persistent grid-stride loops stream at 4.2-4.9 TB/s on these boxes, block-contiguous ranges handed out in dispatch order at
     // 5.3-6.2 (profiles/r02_hbm_ceiling.txt): a workgroup now owns `groups_per_block` consecutive groups.
-    const int gbase = blockIdx.x * p.groups_per_block;
-    const int ngroups = min(p.groups_per_image, gbase + p.groups_per_block);
+    const int gbase = POOL ? blockIdx.x * p.cells_per_block : blockIdx.x * p.groups_per_block;   // POOL: cells, not groups
+    const int ngroups = POOL ? min(p.ncell, gbase + p.cells_per_block) : min(p.groups_per_image, gbase + p.groups_per_block);
     const int gstride = NW1;
     const int npx = p.H * p.W;
     bf16_t* otw = ot + wave * 32 * OROW1;
@@ -98,7 +116,23 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     // plus one constant 32-bit lane offset, no bounds checks.  Otherwise per-lane (y, x) arithmetic.
     const uint32_t lane_x = (uint32_t)(psub * (int)p.xs[2] + chk * 8) * 2u, lane_y = (uint32_t)(psub * (int)p.ys[2] + chk * 8) * 2u;
     const int nfull = npx >> 5;   // groups 0 .. nfull-1 are complete
-    auto load_group = [&](int g, u32x4_t (&raw)[8]) __attribute__((always_inline)) {
+    // POOL: group `gi` of cell `cell` = image rows 16 cy + 2 gi, + 1, columns 16 cx .. + 15; tile pixel 4 it + psub = (row it >> 2,
+    // column 4 (it & 3) + psub): one uniform base per group, the same constant lane offset, a uniform offset per `it`
+    auto pool_group_off = [&](int cell, int gi, const int64_t (&st)[3]) __attribute__((always_inline)) {
+        const int cc = cell < ngroups ? cell : ngroups - 1;   // the prefetch past the wave's last cell: clamped, never consumed
+        const int cy = cc / p.cw, cx = cc - cy * p.cw;
+        return (int64_t)(cy * 16 + 2 * gi) * st[1] + (int64_t)cx * 16 * st[2];
+    };
+    auto load_group = [&](int g, u32x4_t (&raw)[8], int gi = 0) __attribute__((always_inline)) {
+        if constexpr (POOL) {
+            const char* xg = reinterpret_cast<const char*>(p.x + b * p.xs[0] + pool_group_off(g, gi, p.xs));
+            uint32_t lx = lane_x;
+            asm volatile("" : "+v"(lx));
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                raw[it] = *reinterpret_cast<const u32x4_t*>(xg + (uint32_t)(lx + (uint32_t)(((it >> 2) * (int)p.xs[1] + (it & 3) * 4 * (int)p.xs[2]) * 2)));
+            return;
+        }
         const int gc = g < ngroups ? g : ngroups - 1;
         if (DENSE || (xdense && gc < nfull)) {
             const char* xg = reinterpret_cast<const char*>(p.x + b * p.xs[0] + (int64_t)gc * 32 * p.xs[2]);
@@ -203,6 +237,21 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
 
     float sv[2] = {0.f, 0.f};
     int g = gbase + wave;
+    // POOL state: group inside the cell, the cell's sums (tile j = channels [16 j, 16 j + 16): even j row-angle, odd j column-angle
+    // channels), the indicator operands and the cell's table values
+    int gi = 0;
+    f32x4_t pacc[8];
+    float ptab[16];
+    bf16x8_t pax;
+    const int pG = lane >> 4, pli = lane & 15;
+    if constexpr (POOL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ptab[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pax[i] = (bf16_t)((8 * (pG & 1) + i == pli) ? 1.0f : 0.0f);   // k = 8 G + i is column (8 G + i) % 16
+    }
     if constexpr (IMG) load_taps(g, sv);
     // First group landed BEFORE the loop is entered: otherwise the loop header inherits "8 loads in flight, nothing
     // younger" from this path, and the per-register waits at the top of every iteration (vmcnt(7..0)) also wait for the
@@ -210,7 +259,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     if constexpr (IMG) asm volatile("; conv1x1 first group landed" ::"v"(sv[0]), "v"(sv[1]));
     else asm volatile("; conv1x1 first group landed" ::"v"(raw[0]), "v"(raw[1]), "v"(raw[2]), "v"(raw[3]), "v"(raw[4]), "v"(raw[5]), "v"(raw[6]), "v"(raw[7]));
     C1_T(0);
-    for (; g < ngroups; g += gstride) {
+    for (; g < ngroups; g += (POOL ? 0 : gstride)) {
         const int n0 = g * 32;
 #ifdef NAF_C1_TIMING
         if constexpr (!IMG) {   // the group's eight loads have landed (the previous group's eight stores may still be in flight)
@@ -301,6 +350,23 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         __builtin_amdgcn_sched_barrier(0);
         // (a second register set with the group AFTER next in flight was measured in round 3: +-0, gpurun r9s)
         if constexpr (IMG) load_taps(g + gstride, sv);
+        else if constexpr (POOL) {
+            load_group(gi == 7 ? g + gstride : g, raw, (gi + 1) & 7);
+            if (gi == 7) {
+                // the cell's table values, requested a whole MFMA / epilogue / store phase ahead of the rotation: lane (t = lane & 15,
+                // G = lane >> 4) rotates positions 4 G + i; [0,4) cos y, [4,8) sin y, [8,12) cos x, [12,16) sin x
+                const int cy = g / p.cw, cx = g - cy * p.cw;
+                const float* ty = p.tab_y + (int64_t)(cy * 16 + 4 * pG) * 32 + pli;
+                const float* tx = p.tab_x + (int64_t)(cx * 16 + 4 * pG) * 32 + pli;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ptab[i] = ty[i * 32];
+                    ptab[4 + i] = ty[i * 32 + 16];
+                    ptab[8 + i] = tx[i * 32];
+                    ptab[12 + i] = tx[i * 32 + 16];
+                }
+            }
+        }
         else if constexpr (!(NAF_C1_ABL & 16)) load_group(g + gstride, raw);
         __builtin_amdgcn_sched_barrier(0);
         // B fragments back out of the tile (pixel stride 272 B: conflict-free ds_read_b128), 4 oc-tiles each.  The five fragment
@@ -345,7 +411,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
                     bf16x4_t o;
                     o[0] = (bf16_t)v0[0]; o[1] = (bf16_t)v0[1]; o[2] = (bf16_t)v1[0]; o[3] = (bf16_t)v1[1];
                     const f32x2_t w0 = FULL ? v0 : v0 * vmask, w1 = FULL ? v1 : v1 * vmask;
-                    if constexpr (!(NAF_C1_ABL & 4)) {
+                    if constexpr (!(NAF_C1_ABL & 4) && !POOL) {
                         s1p[m * 2 + (j >> 1)] += w0 + w1;
                         s2p[m * 2 + (j >> 1)] += w0 * w0 + w1 * w1;
                     }
@@ -354,6 +420,17 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             C1_T(4);
             // whole-row stores: lane -> (pixel, 16-byte chunk), 4 px x 256 B per instruction
             bf16_t* yb = p.y + b * p.ys[0];
+            if constexpr (POOL) {
+                char* yg = reinterpret_cast<char*>(yb + pool_group_off(g, gi, p.ys));
+                uint32_t ly = lane_y;
+                asm volatile("" : "+v"(ly));
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(otw + (it * 4 + psub) * OROW1 + chk * 8);
+                    *reinterpret_cast<u32x4_t*>(yg + (uint32_t)(ly + (uint32_t)(((it >> 2) * (int)p.ys[1] + (it & 3) * 4 * (int)p.ys[2]) * 2))) = v;
+                }
+                return;
+            }
             if (FULL && (DENSE || ydense)) {
                 char* yg = reinterpret_cast<char*>(yb + (int64_t)g * 32 * p.ys[2]);
                 uint32_t ly = lane_y;
@@ -392,6 +469,58 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             if (full) epilogue(std::true_type{});
             else epilogue(std::false_type{});
         }
+        if constexpr (POOL) {
+            // the group's 32 px x 128 ch bf16 tile -> the cell's sums.  B fragment of tile j: lane (n = lane & 15, G = lane >> 4)
+            // gets pixels 8 G .. 8 G + 7 of channel 16 j + n (two transposing reads of 4 pixels x 16 channels per 16-lane group)
+            bf16x8_t pay;
+            {
+                const bf16_t one = (bf16_t)(((2 * gi + (pG >> 1)) == pli) ? 1.0f : 0.0f);   // pixel k = 8 G + i lies in the group's row G >> 1
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pay[i] = one;
+            }
+            const bf16_t* tb = otw + (8 * pG + (pli >> 2)) * OROW1 + (pli & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(tb + 16 * j));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(tb + 4 * OROW1 + 16 * j));
+                const bf16x8_t bt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                pacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((j & 1) ? pax : pay, bt, pacc[j], 0, 0, 0);
+            }
+            if (gi == 7) {
+                // pacc[j][i] = sum for channel 16 j + t (t = lane & 15) at row / column 4 G + i of the cell.  Rotation as
+                // naf_rope_rotate (rope.py:15-34): pairs (t, t + 32) of a head = tiles (4 hh, 4 hh + 2) by the row angle and
+                // (4 hh + 1, 4 hh + 3) by the column angle; then the sum over the 16 positions (4 in the lane, 4 lane groups).
+                const int cy = g / p.cw, cx = g - cy * p.cw;
+                bf16_t* kc = p.kout + b * p.kst[0] + (int64_t)cy * p.kst[1] + (int64_t)cx * p.kst[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float o[4] = {0.f, 0.f, 0.f, 0.f};   // channels 64 hh + 16 q + t
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float r1, r2;
+                        naf_rope_rotate(pacc[4 * hh][i], pacc[4 * hh + 2][i], ptab[i], ptab[4 + i], r1, r2);
+                        o[0] += r1;
+                        o[2] += r2;
+                        naf_rope_rotate(pacc[4 * hh + 1][i], pacc[4 * hh + 3][i], ptab[8 + i], ptab[12 + i], r1, r2);
+                        o[1] += r1;
+                        o[3] += r2;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] += __shfl_xor(o[q], 16);
+                        o[q] += __shfl_xor(o[q], 32);
+                    }
+                    const float v = pG == 0 ? o[0] : pG == 1 ? o[1] : pG == 2 ? o[2] : o[3];
+                    kc[64 * hh + lane] = (bf16_t)(v * (1.0f / 256.0f));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                gi = 0;
+                g += gstride;
+            } else {
+                ++gi;
+            }
+        }
     }
 
     // the (unused) prefetch past the last group lands here, not at some later merge point
@@ -428,7 +557,14 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
     }
 }
 
-int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
+// 1 when naf_stem_conv_keys_fwd's 1x1 kernel serves the layer: 16 x 16 pixel cells, dense rows, a forward layer that reads its input
+int naf_stem_conv1x1_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp) {
+    return a->ksize == 1 && a->first == nullptr && a->stats_in != nullptr && a->stats_out == nullptr && (a->channels == 0 || a->channels == 128) &&
+           a->H == 16 * kp->h && a->W == 16 * kp->w && a->x_stride[1] == (int64_t)a->W * a->x_stride[2] &&
+           a->y_stride[1] == (int64_t)a->W * a->y_stride[2] && a->x_stride[1] * 2 < 0x7fffffffLL && a->y_stride[1] * 2 < 0x7fffffffLL;
+}
+
+int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp) {
     StemConv1Params p;
     p.x = static_cast<const bf16_t*>(a->x);
     p.y = static_cast<bf16_t*>(a->y);
@@ -458,6 +594,21 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
     }
     p.img = nullptr; p.w0 = nullptr; p.b0 = nullptr; p.ibs = 0;
     for (int i = 0; i < 4; ++i) p.is[i] = 0;
+    p.kout = nullptr; p.tab_y = p.tab_x = nullptr; p.cw = p.ncell = p.cells_per_block = 0;
+    for (int i = 0; i < 3; ++i) p.kst[i] = 0;
+    if (kp != nullptr) {
+        if (!naf_stem_conv1x1_keys_ok(a, kp)) {
+            naf_set_error("naf_stem_conv_keys_fwd: the 1x1 kernel needs 16 x 16 pixel cells, dense rows, stats_out == NULL and first == NULL");
+            return NAF_ERR_UNSUPPORTED;
+        }
+        p.kout = static_cast<bf16_t*>(kp->k_lr); p.tab_y = kp->tab_y; p.tab_x = kp->tab_x;
+        for (int i = 0; i < 3; ++i) p.kst[i] = kp->k_stride[i];
+        p.cw = kp->w; p.ncell = kp->h * kp->w;
+        // every resident wave gets the same number of whole cells (8 groups each)
+        const int64_t cpw = ((int64_t)p.ncell * a->B + slots - 1) / slots;
+        p.cells_per_block = (int32_t)(cpw * NW1);
+        nbx = (p.ncell + p.cells_per_block - 1) / p.cells_per_block;
+    }
     int variant = 0;   // 0: x from memory, 1: f32 image, 2: bf16 image
     if (a->first != nullptr) {
         const naf_stem_conv0_args* f = a->first;
@@ -472,6 +623,15 @@ int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s) {
         variant = f->image_dtype == NAF_BF16 ? 2 : 1;
     }
     const dim3 grid((uint32_t)nbx, (uint32_t)a->B), blk(NW1 * 64);
+    if (kp != nullptr) {
+        auto kern = stem_conv1x1_kernel<false, float, true, false, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            naf_set_error("naf_stem_conv_keys_fwd: cannot reserve %zu bytes of LDS", (size_t)lds);
+            return NAF_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, grid, blk, lds, s, p);
+        return naf_check_launch("stem_conv1x1_kernel<keys>");
+    }
 #define NAF_LAUNCH_1X1(KERN)                                                                                              \
     do {                                                                                                                  \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \

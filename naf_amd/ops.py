@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import XnaArgs, XnaBwdArgs, RopePoolArgs, StemConv0Args, StemConvArgs, ForwardArgs, I64x3, I64x4
+from ._lib import XnaArgs, XnaBwdArgs, RopePoolArgs, StemConv0Args, StemConvArgs, KeyPoolArgs, ForwardArgs, I64x3, I64x4
 
 _DT = {torch.bfloat16: _lib.NAF_BF16, torch.float32: _lib.NAF_F32}
 
@@ -118,11 +118,14 @@ def stem_conv0(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, y:
 
 def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor, eps: float,
               w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor],
-              first=None) -> None:
+              first=None, keys=None) -> None:
     """GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, k in {1,3}, reflect) + bias on bf16 [B,H,W,128] views.
     w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats f64 [B,8,2] (stats_out pre-zeroed or None).
     ``first=(image, conv0_weight, conv0_bias)`` (1x1 layers only, ``x=None``): the input is bf16(conv0(image))
-    recomputed on the fly; ``stats_in`` then come from ``stem_conv0(..., y=None, ...)``."""
+    recomputed on the fly; ``stats_in`` then come from ``stem_conv0(..., y=None, ...)``.
+    ``keys=(k_slice, tab_y, tab_x)`` (a branch's LAST layer, ``stats_out=None``): ``naf_stem_conv_keys_fwd`` -- the layer also
+    writes its 128 channels of the pooled, RoPE'd keys into the bf16 ``[B, h, w, 128]`` view ``k_slice`` (16 x 16 pixel cells);
+    raises when the library does not serve the geometry (``stem_conv_keys_supported``)."""
     lib = _lib.load()
     f0 = None
     if first is not None:
@@ -150,9 +153,29 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
     a.B, a.H, a.W, a.eps = B, H, W, float(eps)
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
     a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2)))
+    if keys is not None:
+        kp = _fill_key_pool(keys, x)
+        with torch.cuda.device(x.device), _Timed("stem_conv%d_keys" % a.ksize):
+            rc = lib.naf_stem_conv_keys_fwd(C.byref(a), C.byref(kp), _stream(x))
+        _lib.check(rc, "naf_stem_conv_keys_fwd")
+        return
     with torch.cuda.device(x.device), _Timed("stem_conv%d" % a.ksize):
         rc = lib.naf_stem_conv_fwd(C.byref(a), _stream(x))
     _lib.check(rc, "naf_stem_conv_fwd")
+
+
+def _fill_key_pool(keys, x) -> KeyPoolArgs:
+    k_slice, tab_y, tab_x = keys
+    _gpu(k_slice, "k_slice")
+    if k_slice.dtype != torch.bfloat16 or k_slice.dim() != 4 or k_slice.shape[0] != x.shape[0] or k_slice.shape[3] != 128 or k_slice.stride(3) != 1:
+        raise ValueError("stem_conv: keys must be a bf16 [B, h, w, 128] view with channels contiguous")
+    if tab_y.dtype != torch.float32 or tab_x.dtype != torch.float32 or tab_y.shape[-1] != 16 or tab_x.shape[-1] != 16:
+        raise ValueError("stem_conv: keys need the fp32 RoPE tables of 16 periods (heads of 64 channels)")
+    kp = KeyPoolArgs()
+    kp.k_lr, kp.tab_y, kp.tab_x = k_slice.data_ptr(), tab_y.data_ptr(), tab_x.data_ptr()
+    kp.h, kp.w = int(k_slice.shape[1]), int(k_slice.shape[2])
+    kp.k_stride = I64x3(int(k_slice.stride(0)), int(k_slice.stride(1)), int(k_slice.stride(2)))
+    return kp
 
 
 def stem_conv_plain(x: torch.Tensor, w_packed: torch.Tensor, y: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
