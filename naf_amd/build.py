@@ -41,7 +41,7 @@ def _sources():
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(INCLUDE, "naf_hip.h"))
     hdrs.append(os.path.abspath(__file__))
     return max(os.path.getmtime(h) for h in hdrs)

@@ -542,6 +542,26 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
         return naf_stem_conv0_fwd(&c0, stream);
     };
+    // Key pooling rides on the branches' LAST layers (naf_stem_conv_keys_fwd: axial RoPE split, no pass over the guidance) when
+    // every query is rotated on load, the guidance is not pooled, the cells are 16 x 16 pixels and the RoPE heads are 64 wide;
+    // otherwise naf_rope_pool_fwd below.  NAF_KEYS_FUSE=0 (with NAF_HIP_KNOBS=1): always the separate pass (A/B).
+    static const bool no_keys_fuse = [] { const char* e = naf_knob("NAF_KEYS_FUSE"); return e && atoi(e) == 0; }();
+    const int hrope_ = a->heads_rope > 0 ? a->heads_rope : a->heads;
+    naf_key_pool_args kps[2];
+    bool keys_fused = !no_keys_fuse && L.fused && !L.pooled && hrope_ == 4 && SH == 16 * a->h && SW == 16 * a->w;
+    for (int br = 0; br < 2 && keys_fused; ++br) {
+        kps[br] = naf_key_pool_args{};
+        kps[br].k_lr = ws + L.keys + (size_t)br * 128 * 2;
+        kps[br].tab_y = a->tab_y; kps[br].tab_x = a->tab_x; kps[br].h = a->h; kps[br].w = a->w;
+        kps[br].k_stride[0] = (int64_t)a->h * a->w * 256; kps[br].k_stride[1] = (int64_t)a->w * 256; kps[br].k_stride[2] = 256;
+        naf_stem_conv_args c{};   // geometry only: what the last layer's call will look like
+        c.x = reinterpret_cast<const void*>(0x100); c.y = reinterpret_cast<void*>(0x100); c.w_packed = reinterpret_cast<const void*>(0x100);
+        c.bias = c.gn_weight = c.gn_bias = reinterpret_cast<const float*>(0x100); c.stats_in = reinterpret_cast<const double*>(0x100);
+        c.ksize = a->branch[br].ksize; c.B = a->B; c.H = SH; c.W = SW;
+        for (int i = 0; i < 3; ++i) { c.x_stride[i] = dense[i]; c.y_stride[i] = cat_st[i]; }
+        const bool recomputed = a->nlayer == 1 && a->branch[br].conv0_ksize == 1 && a->branch[br].ksize == 1;   // the only layer reads the image
+        if (recomputed || naf_stem_conv_keys_supported(&c, &kps[br]) != 1) keys_fused = false;
+    }
     // block layer l of branch br: x (NULL: recompute the first convolution) -> y (the last layer writes the branch's slice of the
     // concatenated guidance instead)
     auto run_layer = [&](int br, int l, const void* x, void* y) -> int {
@@ -558,6 +578,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         c.stats_out = last ? nullptr : st + (size_t)(l + 1) * stat_stride;
         c.ksize = b.ksize; c.B = a->B; c.H = SH; c.W = SW; c.eps = a->gn_eps;
         for (int i = 0; i < 3; ++i) { c.x_stride[i] = dense[i]; c.y_stride[i] = last ? cat_st[i] : dense[i]; }
+        if (last && keys_fused) return naf_stem_conv_keys_fwd(&c, &kps[br], stream);
         return naf_stem_conv_fwd(&c, stream);
     };
     // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
@@ -625,7 +646,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     const int64_t kst[4] = {(int64_t)a->h * a->w * 256, 256 / hrope, (int64_t)a->w * 256, 256};
     const int64_t qst[4] = {(int64_t)L.Ho * L.Wo * 256, 256 / hrope, (int64_t)L.Wo * 256, 256};
     for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = L.fused ? 0 : qst[i]; rp.k_stride[i] = kst[i]; }
-    int rc = naf_rope_pool_fwd(&rp, stream);
+    int rc = keys_fused ? NAF_OK : naf_rope_pool_fwd(&rp, stream);
     if (rc != NAF_OK) return rc;
     rc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, stream);
     if (rc != NAF_OK) return rc;

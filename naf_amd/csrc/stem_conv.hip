@@ -8,14 +8,15 @@
 // profiles/r03_stem_rows_probe.txt).
 #include "stem_rows_kernel.h"
 
+// 1 when naf_stem_conv_keys_fwd's 3x3 kernel serves the layer: 16 x 16 pixel cells, whole 32-pixel strips (two cells), the forward layer
 int naf_stem_conv_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp) {
-    (void)a; (void)kp;
-    return 0;   // TODO(3x3)
+    return a->ksize == 3 && a->first == nullptr && a->stats_in != nullptr && a->stats_out == nullptr && (a->channels == 0 || a->channels == 128) &&
+           a->H == 16 * kp->h && a->W == 16 * kp->w && a->W % stem_rows::TW == 0;
 }
 
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp) {
-    if (kp != nullptr) {
-        naf_set_error("naf_stem_conv_keys_fwd: 3x3 kernel not available");
+    if (kp != nullptr && !naf_stem_conv_keys_ok(a, kp)) {
+        naf_set_error("naf_stem_conv_keys_fwd: the 3x3 kernel needs 16 x 16 pixel cells, W a multiple of 32, stats_out == NULL and first == NULL");
         return NAF_ERR_UNSUPPORTED;
     }
     StemConvParams p;
@@ -39,12 +40,28 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_k
     if (segs < 1) segs = 1;
     int seg_h = (int)((a->H + segs - 1) / segs);
     seg_h = ((seg_h + 3) / 4) * 4;
+    if (kp != nullptr) {
+        // key pooling: segments of whole bands of cells (16 rows), at most POOL_ROWS tall (their row tables sit in the LDS)
+        seg_h = ((seg_h + 15) / 16) * 16;
+        if (seg_h > stem_rows::POOL_ROWS) seg_h = stem_rows::POOL_ROWS;
+        p.kout = static_cast<bf16_t*>(kp->k_lr); p.tab_y = kp->tab_y; p.tab_x = kp->tab_x;
+        for (int i = 0; i < 3; ++i) p.kst[i] = kp->k_stride[i];
+    }
     p.seg_h = seg_h;
     p.segs_y = (a->H + seg_h - 1) / seg_h;
     const int64_t nb = strips * p.segs_y;
     if (nb <= 0 || nb > 0x7fffffffLL) {
         naf_set_error("naf_stem_conv_fwd: grid out of range");
         return NAF_ERR_INVALID;
+    }
+    if (kp != nullptr) {
+        const void* fk = reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0, false, true>);
+        if (hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES_POOL) != hipSuccess) {
+            naf_set_error("naf_stem_conv_keys_fwd: cannot reserve %zu bytes of LDS", stem_rows::LDS_BYTES_POOL);
+            return NAF_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL((stem_rows::stem_conv_rows_kernel<0, false, true>), dim3((uint32_t)nb), dim3(256), stem_rows::LDS_BYTES_POOL, s, p);
+        return naf_check_launch("stem_conv_rows_kernel<keys>");
     }
     const bool plain = a->stats_in == nullptr;   // no GroupNorm / SiLU in front of the convolution (data-gradient pass)
     const void* fn = plain ? reinterpret_cast<const void*>(stem_rows::stem_conv_rows_kernel<0, true>)

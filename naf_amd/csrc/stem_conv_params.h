@@ -14,4 +14,9 @@ struct StemConvParams {
     int32_t B, H, W, tiles_x, segs_y, seg_h;
     float eps;
     int64_t xs[3], ys[3];  // element strides {b, y, x}
+    // POOL instantiation only (naf_stem_conv_keys_fwd): the branch's 128 channels of the pooled keys, 16 x 16 pixel cells
+    bf16_t* kout = nullptr;         // [B, H/16, W/16, >= 128] by kst = {b, y, x}
+    const float* tab_y = nullptr;   // [H][2][16] cos | sin (naf_rope_tables)
+    const float* tab_x = nullptr;   // [W][2][16]
+    int64_t kst[3] = {0, 0, 0};
 };

@@ -36,8 +36,23 @@ constexpr int NLD = 5;          // 16-byte load pieces per thread per batch of t
 constexpr int NST = 4;          // 16-byte store pieces per thread per output tile of two rows
 constexpr int NB = 3;           // B-fragment register buffers (a fragment is requested 4 fragments = 12 MFMAs ahead)
 constexpr size_t LDS_BYTES = (size_t)(RING * ROWE + 2 * 2 * TW * PXE) * 2 + 3 * C * sizeof(float);
+// POOL: + the strip's column tables [32][32], the segment's row tables [<= POOL_ROWS][32] (fp32 cos | sin) and the two
+// indicator operands [2][64 lanes][8] bf16
+// and the cells' sums [4 waves][4 tiles][4][64 lanes] fp32 (the kernel has no 16 registers left for them)
+constexpr int POOL_ROWS = 128;  // tallest segment of a POOL launch
+constexpr size_t LDS_BYTES_POOL = LDS_BYTES + (size_t)(TW * 32 + POOL_ROWS * 32 + 4 * 4 * 4 * 64) * sizeof(float) + 2 * 64 * 4 * 2;
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), every lane gets it (cf. naf_rows_max)
+__device__ __forceinline__ float rows_sum(float v) {
+    const uint32_t b = __float_as_uint(v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    const float s16 = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const uint32_t c = __float_as_uint(s16);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
 
 __device__ __forceinline__ int reflect(int i, int n) {
     if (i < 0) i = -i;
@@ -49,12 +64,33 @@ __device__ __forceinline__ int reflect(int i, int n) {
 // LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins, 128 cycle counter
 // PLAIN: no GroupNorm, no SiLU -- y = conv(x) (+ bias if given): the data gradient of a layer is this kernel on the output
 // gradient with the flipped, transposed weights (stats_in == NULL in the C ABI); the ring commit is then a copy.
-template <int ABL = 0, bool PLAIN = false>
+// POOL (naf_stem_conv_keys_fwd; the branch's LAST layer; whole strips, segments a multiple of 16 rows starting on a multiple of
+// 16, at most POOL_ROWS tall): the layer also writes its 128 channels of the pooled, RoPE'd keys -- KeyEncoder's
+// adaptive_avg_pool2d of the rotated guidance (naf.py:63-69 after rope.py:139-153) for 16 x 16 pixel cells.  The rotation is
+// axial: inside a 64-wide head dims [0,16) u [32,48) turn by the ROW angle, [16,32) u [48,64) by the COLUMN angle, and pooling is
+// linear, so a cell's key = the rotation, by row r's angle, of its un-rotated sum over the 16 columns of row r (row-angle dims),
+// resp. by column c's angle of its sum over the 16 rows of column c.  A strip is two cells wide.  During double-step d the tile
+// of double-step d - 1 (two output rows x 32 pixels x 128 channels, bf16, complete since the barrier) waits in the LDS for its row
+// stores; wave w = (head hh = w >> 1, type = w & 1: 0 row-angle, 1 column-angle channels) reads, per tile row and cell, its two
+// 16-channel tiles (dims 16 type + [0,16) and + 32) back TRANSPOSED (ds_read_b64_tr_b16: the B operand of
+// v_mfma_f32_16x16x16_bf16, contraction over the cell row's 16 pixels) and multiplies by a 0/1 indicator A[m][pixel] =
+// (column == m) resp. (row & 15 == m): eight small MFMAs per double-step add to the sums [position m][channel], which live in
+// the LDS between them (16 bytes per lane and tile, read before and written back after its MFMA: the kernel has no registers
+// left for them).  Every eighth double-step (d = 2 mod 8) the tile's first row
+// ends a band of cells: between the two rows' contributions the band is rotated (fp32, tables staged in the LDS), summed over
+// its 16 positions, scaled by 1/256, stored as bf16 keys, and its sums are cleared; the last band is finished in the tail.  The
+// sums are over the bf16 values the queries are read from.  No GroupNorm sums (the last layer has no successor).
+template <int ABL = 0, bool PLAIN = false, bool POOL = false>
 __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvParams p) {
+    static_assert(!(POOL && PLAIN), "key pooling rides on the forward layer");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);                     // [RING][PXR][PXE]
     bf16_t* otile = ring + RING * ROWE;                                 // [2][2*TW][PXE]
     float* cvec = reinterpret_cast<float*>(otile + 2 * 2 * TW * PXE);   // [3][128]: bias, GN scale, GN shift
+    float* ptx = cvec + 3 * C;                                          // POOL: [TW][32] column tables of the strip
+    float* pty = ptx + TW * 32;                                         // POOL: [POOL_ROWS][32] row tables of the segment
+    float* psum = pty + POOL_ROWS * 32;                                 // POOL: [4 waves][4 tiles][4][64 lanes] the cells' sums
+    bf16_t* pind = reinterpret_cast<bf16_t*>(psum + 4 * 4 * 4 * 64);    // POOL: [2 types][64 lanes][4] indicator operands
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n32 = lane & 31, half = lane >> 5;
@@ -95,6 +131,24 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             cvec[C + tid] = gmm * rstd;
             cvec[2 * C + tid] = p.beta[tid] - (float)mean * gmm * rstd;
         }
+    }
+    if constexpr (POOL) {
+        // tables of the strip's 32 columns and of the segment's rows (16 bytes per thread and trip), the indicator operands:
+        // lane (m = lane & 15, G = lane >> 4) holds A[m][k = 4 G + i], pixel k = column k of the cell row.  Type 1 (column sums):
+        // column == m; type 0 (row sums): all ones, masked per row by the row's position in its band.  The sums start at zero.
+        *reinterpret_cast<f32x4_t*>(ptx + tid * 4) = *reinterpret_cast<const f32x4_t*>(p.tab_x + (int64_t)sx * 32 + tid * 4);
+        for (int i = tid; i < (sy_end - sy) * 8; i += 256)
+            *reinterpret_cast<f32x4_t*>(pty + i * 4) = *reinterpret_cast<const f32x4_t*>(p.tab_y + (int64_t)sy * 32 + i * 4);
+        if (tid < 128) {
+            const int ty_ = tid >> 6, l_ = tid & 63, m_ = l_ & 15, G_ = l_ >> 4;
+            bf16x4_t v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (bf16_t)((ty_ == 0 || 4 * G_ + i == m_) ? 1.0f : 0.0f);
+            *reinterpret_cast<bf16x4_t*>(pind + tid * 4) = v;
+        }
+        for (int i = tid; i < 4 * 4 * 4 * 64; i += 256) psum[i] = 0.f;
+        // the first double-step's pooling reads the (not yet written) tile of double-step -1: finite values, overwritten at d = 2
+        for (int i = tid; i < 2 * 2 * TW * PXE / 8; i += 256) *reinterpret_cast<u32x4_t*>(otile + i * 8) = u32x4_t{0u, 0u, 0u, 0u};
     }
     __syncthreads();
 
@@ -224,6 +278,96 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #pragma unroll
     for (int f = 0; f < NB; ++f) load_frag(0, f, bb[f]);
 
+    // ---- POOL: state and micro-ops (placed by tools/gen_stem_rows.py like the other side work; none of it exists otherwise) ----
+    const int pwave = __builtin_amdgcn_readfirstlane(wave);   // uniform: everything derived from it stays scalar
+    const int ptype = pwave & 1, phh = pwave >> 1;            // this wave's channels: dims 16 ptype + [0,16) and + 32 of head phh of the branch
+    f32x4_t pd = {0.f, 0.f, 0.f, 0.f};             // sums of one tile [position 4 G + i][channel lane & 15] on their way through an MFMA
+    u32x2_t pa = {0u, 0u};                         // indicator operand of the tile row
+    bf16x4_t pb = {};                              // tile fragment
+    uint32_t pt = 0;
+    float pc = 0.f, ps = 0.f, plo = 0.f, phi = 0.f, po1 = 0.f, po2 = 0.f;
+    const int pmask = ptype ? 0 : 15;
+    // Lane-dependent LDS addresses are re-derived from the lane id where they are used (one shift-add each; G = lane >> 4, m = n =
+    // lane & 15): the kernel has no registers to keep them in, and an asm-opaque copy of the lane id keeps hipcc from hoisting them
+    // out of the loop.  Only the fragment offset (a multiply-add chain) is kept: pixel lane >> 2 of the cell row's 16, 4 channels at
+    // (lane & 3) * 4.
+    auto plane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    const int pb_off = (lane >> 2) * PXE + (lane & 3) * 4 + 64 * phh + 16 * ptype;
+    // LDS byte address base + (lane << sh), formed by ONE instruction that hipcc can neither hoist nor split into a copy and a shift
+    auto plds = [&](uint32_t base, int sh) __attribute__((always_inline)) {
+        uint32_t a_;
+        if (sh == 4) asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a_) : "v"(lane), "s"(base));
+        else asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a_) : "v"(lane), "s"(base));
+        return a_;
+    };
+    const uint32_t psum_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((NAF_LDS float*)psum) + (uint32_t)pwave * (4 * 4 * 64 * 4));
+    const uint32_t pind_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((NAF_LDS bf16_t*)pind) + (uint32_t)ptype * (64 * 8));
+    // sums of tile q = 2 cell + (dims + 32), positions 4 G + 0..3: 16 bytes per lane at psum[wave][q][lane]
+    auto psw_of = [&]() __attribute__((always_inline)) { return (NAF_LDS float*)(uintptr_t)plds(psum_w, 4); };
+    // indicator of image row r (a cell row of 16 pixels): the stored pattern where the lane's m is the row's position in its band
+    // (row-sum waves; column-sum waves: everywhere), zero for the rows above the segment that the first tiles hold
+    auto pool_a0 = [&](int r) __attribute__((always_inline)) {
+        pa = *((const NAF_LDS u32x2_t*)(uintptr_t)plds(pind_w, 3));
+        pt = (uint32_t)((r - (lane & 15)) & pmask) | (r < sy ? 1u : 0u);
+        asm volatile("" : "+v"(pt));
+    };
+    auto pool_a1 = [&]() __attribute__((always_inline)) {
+        const bool on = pt == 0u;
+        pa[0] = on ? pa[0] : 0u;
+        pa[1] = on ? pa[1] : 0u;
+        asm volatile("" : "+v"(pa));
+    };
+    // tile q's sums so far (the MFMA adds to them: an LDS float atomic per value is far slower than this read-modify-write of the
+    // wave's own 16 bytes per lane) and the fragment of tile q, row g of `tile`: lane (n = lane & 15, G) gets pixels 4 G .. 4 G + 3
+    // of the cell row, channel n
+    auto pool_rd = [&](const bf16_t* tile, int g, int q) __attribute__((always_inline)) {
+        pd = *((volatile NAF_LDS f32x4_t*)(psw_of() + q * 256));
+        pb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(tile + pb_off + (g * TW + (q >> 1) * 16) * PXE + (q & 1) * 32));
+    };
+    auto pool_mm = [&]() __attribute__((always_inline)) {
+        asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(pd) : "v"(pa), "v"(pb));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ... and back -- at least one MFMA slot behind pool_mm: the asm MFMA's result is invisible to the hazard recogniser
+    auto pool_st = [&](int q, int h) __attribute__((always_inline)) {   // h = 0, 1 (ds_write_b64: free beside an MFMA)
+        *((volatile NAF_LDS f32x2_t*)(psw_of() + q * 256 + 2 * h)) = f32x2_t{pd[2 * h], pd[2 * h + 1]};
+    };
+    // the band whose last row is image row rl is complete: cell c's sums -> keys.  f0: sums (then cleared) and table values of the lane's position
+    // 4 G + i (row tables for the row-sum waves, the cell's column tables otherwise), f1: rotation (rope.py:15-34) and the sum over
+    // the lane's positions, f2: over the four lane groups, f3: lanes 0..31 store dims 16 ptype + lane & 15 (po1) and + 32 (po2)
+    auto pool_f0 = [&](int rl, int c, int i) __attribute__((always_inline)) {
+        const int l = plane();
+        const float* tb = (ptype ? ptx + 16 * c * 32 : pty + (rl - 15 - sy) * 32) + (4 * (l >> 4) + i) * 32 + (l & 15);
+        NAF_LDS float* sw = psw_of();
+        pc = tb[0];
+        ps = tb[16];
+        plo = *((volatile NAF_LDS float*)(sw + (2 * c) * 256 + i));
+        phi = *((volatile NAF_LDS float*)(sw + (2 * c + 1) * 256 + i));
+        *((volatile NAF_LDS float*)(sw + (2 * c) * 256 + i)) = 0.f;      // the next band starts from zero
+        *((volatile NAF_LDS float*)(sw + (2 * c + 1) * 256 + i)) = 0.f;
+    };
+    auto pool_f1 = [&](int i) __attribute__((always_inline)) {
+        if (i == 0) { po1 = 0.f; po2 = 0.f; }
+        po1 = __builtin_fmaf(plo, pc, po1);
+        po1 = __builtin_fmaf(-phi, ps, po1);
+        po2 = __builtin_fmaf(phi, pc, po2);
+        po2 = __builtin_fmaf(plo, ps, po2);
+        asm volatile("" : "+v"(po1), "+v"(po2));
+    };
+    auto pool_f2 = [&](int which) __attribute__((always_inline)) {
+        if (which == 0) po1 = rows_sum(po1);
+        else po2 = rows_sum(po2);
+    };
+    auto pool_f3 = [&](int rl, int c) __attribute__((always_inline)) {
+        const int l = plane();
+        const float v = (((l >> 4) & 1) ? po2 : po1) * (1.0f / 256.0f);
+        // uniform base + a 32-bit lane offset made on the spot
+        char* kc = reinterpret_cast<char*>(p.kout + (int64_t)b * p.kst[0] + (int64_t)(rl >> 4) * p.kst[1] + (int64_t)((sx >> 4) + c) * p.kst[2] + 64 * phh + 16 * ptype);
+        uint32_t o_ = (uint32_t)(l & 15) * 2u + (uint32_t)(l >> 4) * 64u;
+        asm volatile("" : "+v"(o_));
+        if (l < 32) *reinterpret_cast<bf16_t*>(kc + o_) = (bf16_t)v;
+    };
+
     // loop-carried uniform row pointers / masks of the double-steps (see u_all)
     char *prev_row0 = ybu, *prev_row1 = ybu;
     const char *next_row0 = xbu, *next_row1 = xbu, *next_lo = xbu;
@@ -240,6 +384,11 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         auto dstep = [&](auto Dtag) __attribute__((always_inline)) {
             constexpr int D = decltype(Dtag)::value;
             const int d = 2 * it + D;
+            // POOL: the tile in the LDS holds image rows pr0 = sy - 5 + 2 d and pr0 + 1; pr0 & 15 == 15 (d = 2 mod 8: D = 0, it = 1 mod 4)
+            // ends a band of cells -- the first time (d = 2) a band above the segment
+            const int pr0 = sy - 5 + 2 * d;
+            const bool pfin = POOL && D == 0 && (it & 3) == 1 && it > 1;
+            (void)pr0; (void)pfin;
             // commit target: batch d + 2 = ring rows (4 it + 2 D + 4) % 8
             bf16_t* commit_base = ring + (D == 0 ? oth : oth + 2 * ROWE);
             const bf16_t* prev_tile = otile + ((d + 1) & 1) * (2 * TW * PXE);
@@ -307,11 +456,13 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[nm][j * 4 + r];
                 *reinterpret_cast<bf16x4_t*>(ot + (g * TW + n32) * PXE + wave * 32 + 8 * j + 4 * half) = o;
+                if constexpr (POOL) return;   // the last layer: no GroupNorm behind it, no sums
                 e_a = acc[nm][j * 4] + acc[nm][j * 4 + 1];
                 NAF_PIN1(e_a);
             };
             auto epi1 = [&](int nm, int g, int j) __attribute__((always_inline)) {
                 if (ABL & 2) return;
+                if constexpr (POOL) return;
                 e_a += acc[nm][j * 4 + 2];
                 e_a += acc[nm][j * 4 + 3];
                 e_q = acc[nm][j * 4] * acc[nm][j * 4];
@@ -320,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             };
             auto epi2 = [&](int nm, int g, int j) __attribute__((always_inline)) {
                 if (ABL & 2) return;
+                if constexpr (POOL) return;
                 e_q = __builtin_fmaf(acc[nm][j * 4 + 2], acc[nm][j * 4 + 2], e_q);
                 e_q = __builtin_fmaf(acc[nm][j * 4 + 3], acc[nm][j * 4 + 3], e_q);
                 const float m = EDGE ? mrow[g] * lane_m : mrow[g];
@@ -395,11 +547,15 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[0][j * 4 + r];
                     o[r] = (bf16_t)v;
-                    a += v;
-                    q = __builtin_fmaf(v, v, q);
+                    if constexpr (!POOL) {
+                        a += v;
+                        q = __builtin_fmaf(v, v, q);
+                    }
                 }
-                s1p[j >> 1] += a;
-                s2p[j >> 1] += q;
+                if constexpr (!POOL) {
+                    s1p[j >> 1] += a;
+                    s2p[j >> 1] += q;
+                }
                 *reinterpret_cast<bf16x4_t*>(t1 + n32 * PXE + wave * 32 + 8 * j + 4 * half) = o;
             }
         }
@@ -414,6 +570,35 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             for (int n = 0; n < 2; ++n) {     // tile 1, first row: image row sy_end - 1
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(t1 + st_lds0 + 16 * n * PXE);
                 *reinterpret_cast<u32x4_t*>(ybu + (int64_t)(sy_end - 1) * p.ys[1] * 2 + (n & 1) * st_px16 + st_goff0) = v;
+            }
+        }
+        if constexpr (POOL) {
+            // the last band's rows 13, 14 (tile 0) and 15 (tile 1's first row), then its keys
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                pool_a0(sy_end - 3 + h);
+                pool_a1();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pool_rd(h < 2 ? otile : t1, h & 1, q);
+                    asm volatile("s_nop 4");    // asm MFMAs are invisible to the hazard recogniser: VALU-written operand, MFMA result read by the LDS
+                    pool_mm();
+                    asm volatile("s_nop 15\n\ts_nop 7");
+                    pool_st(q, 0);
+                    pool_st(q, 1);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pool_f0(sy_end - 1, c, i);
+                    pool_f1(i);
+                }
+                pool_f2(0);
+                pool_f2(1);
+                pool_f3(sy_end - 1, c);
             }
         }
     } else {
@@ -431,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         }
     }
 
-    if (p.stats_out) {
+    if (!POOL && p.stats_out) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float a = s1p[g], q = s2p[g];

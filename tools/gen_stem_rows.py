@@ -123,6 +123,72 @@ def build(D):
         start = g + 1
     last_commit = start
 
+    # ---- POOL instantiation (naf_stem_conv_keys_fwd): the previous double-step's tile -> the cells' sums, see stem_rows_kernel.h ----
+    # Per tile row g: the row's indicator operand, then four chains (fragment read -> small MFMA three slots later -> its result
+    # joins the sums in the LDS two slots behind it; an asm MFMA has no hazard recogniser between it and its consumers).  In D = 0
+    # the finished band's keys sit between the two rows, under `if (pfin)` (one double-step in eight).  Everything is placed on top of
+    # the schedule above with a slightly larger budget (the 16-cycle MFMAs are not side work: they follow their slot's MFMA, and
+    # the POOL instantiation has no GroupNorm sums in its epilogue slices); `if constexpr (POOL)` removes all of it elsewhere.
+    PDIST = int(os.environ.get("NAF_ROWS_POOL_DIST", "3"))     # slots between a chain's LDS reads and its MFMA
+    pool = [[] for _ in range(NSLOT)]
+    PCAP = CAP + float(os.environ.get("NAF_ROWS_POOL_EXTRA", "5"))
+    lp = list(load)
+    for k in range(NSLOT):          # the epilogue slices' sums do not exist in this instantiation
+        for kind, code in ops[k]:
+            if code.startswith("epi1") or code.startswith("epi2"):
+                lp[k] -= 4 * V
+            elif code.startswith("epi0"):
+                lp[k] -= V
+    def pl(cost, earliest, cap=PCAP):
+        k = max(0, earliest)
+        while k < NSLOT - 1 and lp[k] + cost > cap:
+            k += 1
+        assert k < NSLOT - 1, "pool schedule does not fit"
+        lp[k] += cost
+        return k
+    lb = list(lp)           # the keys' own budget (D = 0 only): one double-step in eight may run over
+    BCAP = CAP + float(os.environ.get("NAF_ROWS_POOL_BND_EXTRA", "20"))
+    def plb(cost, earliest):
+        kk = max(0, earliest)
+        while kk < NSLOT - 1 and lb[kk] + cost > BCAP:
+            kk += 1
+        assert kk < NSLOT - 1, "pool keys do not fit"
+        lb[kk] += cost
+        return kk
+    k = 3                   # chain cursor: one accumulator register set, so the chains follow each other
+    for g in range(2):
+        ka = pl(LR + 2 * V, k)
+        pool[ka].append(("", f"pool_a0(pr0 + {g});"))
+        ka = pl(2 * V, ka + 2)
+        pool[ka].append(("", "pool_a1();"))
+        k = max(k, ka)
+        for q in range(4):
+            kr = pl(2 * LR, k)    # sums so far + tile fragment
+            pool[kr].append(("", f"pool_rd(prev_tile, {g}, {q});"))
+            km = pl(6.0, max(kr + PDIST, ka + 1))
+            pool[km].append(("", "pool_mm();"))
+            ks = pl(2 * LW, km + 2)
+            pool[ks].append(("", f"pool_st({q}, 0); pool_st({q}, 1);"))
+            k = ks
+        if g == 0 and D == 0:       # the band's keys between the two rows' chains (not beside them: the chains' registers are free then)
+            kf = k + 1
+            for c in range(2):
+                for i in range(4):
+                    kf = plb(4 * LR + 2 * LW, kf)
+                    pool[kf].append(("pfin", f"pool_f0(pr0, {c}, {i});"))
+                    kf = plb(4 * V, kf + 3)
+                    pool[kf].append(("pfin", f"pool_f1({i});"))
+                    kf += 1
+                for w in range(2):
+                    kf = plb(4 * V, kf)
+                    pool[kf].append(("pfin", f"pool_f2({w});"))
+                    kf += 1
+                kf = plb(4 * V + VS, kf)
+                pool[kf].append(("pfin", f"pool_f3(pr0, {c});"))
+                kf += 1
+            k = kf
+    pool_done = k
+
     # ---- emit ----
     out = []
     for k in range(NSLOT):
@@ -167,6 +233,11 @@ def build(D):
                 out.append(f"if constexpr (PLAIN && !(ABL & 1)) {{ {code} }}")
             else:
                 out.append(f"if constexpr (!PLAIN && !(ABL & 1)) {{ {code} }}")
+        for cond, code in pool[k]:
+            if cond:
+                out.append(f"if constexpr (POOL) {{ if ({cond}) {{ {code} }} }}")
+            else:
+                out.append(f"if constexpr (POOL) {{ {code} }}")
         out.append("NAF_SLOT_PIN;")
     return out, load, last_commit
 
