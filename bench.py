@@ -179,6 +179,26 @@ def measure_traffic_live(workload, per_gpu_batch, timeout_s=90):
     return int(vals["WRITE_SIZE"] * 1024 + 2 * vals["FETCH_SIZE"] * 1024), kname
 
 
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`.
+    Fails loudly when fewer than N devices are visible (unless NAF_BENCH_BACKEND=gloo: the dry run that shares devices)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("NAF_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"bench.py: --gpus {n} but only {have} ROCm device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,8 +233,10 @@ def main():
     if args.steps is None:
         args.steps = 1000 if world == 1 else 30
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the ranks ourselves -- the same command under torch.distributed.run, one rank
+            # per GPU, rendezvous on a free local port; the children print (rank 0: the one JSON line), we return their status
+            raise SystemExit(_self_launch(args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the NAF hot path has no CPU implementation)")
@@ -429,8 +451,11 @@ def main():
             # so the call brackets ONE launch of each layer kernel (stage 1): stem_conv1 / stem_conv3 are measured per-launch
             # times, not phase / nlayer; the remainder of the stem is the other stages.  rope_pool includes the 9 us value packing.
             nl = 2 * len(list(model.image_encoder.encoder)[1:])
+            two = not m("stem_layer_1x1")   # version >= 200: the branches run on two streams, only the 3x3 launch is bracketed
             phases.update({"stem_first_convs": r4(m("stem_first_convs")), "stem_conv1": r4(m("stem_layer_1x1")), "stem_conv3": r4(m("stem_layer_3x3")),
-                           "layers_per_branch": nl, "stem_order": "layers of the two branches alternate (1x1, 3x3, 1x1, ...)",
+                           "layers_per_branch": nl,
+                           "stem_order": ("two streams: the 1x1 branch's layers run beside the 3x3 branch's (stem_conv3 = one 3x3 launch with 1x1 launches beside it)"
+                                          if two else "layers of the two branches alternate (1x1, 3x3, 1x1, ...)"),
                            "source": f"hipEvents recorded inside the one naf_forward call, on {timer.count('stem')} of the {args.steps} timed steps"})
         if roof and m("rope_pool"):
             # a separate RoPE / key-pooling pass is overhead against the achieved fraction, not algorithmic traffic

@@ -43,6 +43,11 @@ static void* to_device(const void* host, size_t bytes) {
 
 int main(int argc, char** argv) {
     if (argc != 14) { fprintf(stderr, "usage: %s params image features out B H W h w C ksize Ho Wo\n", argv[0]); return 1; }
+    /* the argument structs carry no size field: header and library must agree in major.minor (include/naf_hip.h) */
+    if (naf_version() / 100 != NAF_HIP_VERSION / 100) {
+        fprintf(stderr, "libnaf_hip.so is version %d, this host was built against %d\n", naf_version(), NAF_HIP_VERSION);
+        return 1;
+    }
     const int B = atoi(argv[5]), H = atoi(argv[6]), W = atoi(argv[7]), h = atoi(argv[8]), w = atoi(argv[9]), C = atoi(argv[10]);
     const int ksize = atoi(argv[11]), Ho = atoi(argv[12]), Wo = atoi(argv[13]);
     size_t np_bytes, ni, nf;

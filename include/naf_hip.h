@@ -15,7 +15,9 @@
  *   - plain C types only; every pointer marked "device" is a HIP device pointer owned by the caller.
  *   - the library allocates, retains and frees NO device memory; outputs and workspaces are the
  *     caller's.  Launches are asynchronous on the caller's hipStream_t (passed as void*), on the
- *     caller's current device.  Functions are re-entrant.
+ *     caller's current device.  Functions are re-entrant.  The only HIP objects the library owns are one
+ *     non-blocking stream and two events per device, created on naf_forward's first call there (it runs the two
+ *     encoder branches side by side and joins them back into the caller's stream before it returns).
  *   - return value 0 = success; non-zero = error, text via naf_last_error() (thread-local).
  *     Nothing throws or aborts across the ABI.  Argument checks mirror the reference's failure modes
  *     (NATTEN: odd kernel, kernel*dilation <= extent; einops: channels divisible by heads).
@@ -32,6 +34,11 @@ extern "C" {
 #endif
 
 #define NAF_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
+/* Binary compatibility: the argument structs carry no size field, so a host must be BUILT against the header of the library it
+ * loads whenever the minor version differs (compare naf_version() / 100 with NAF_HIP_VERSION / 100 at start-up, as
+ * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
+ * that zero-initialise the structs stay source-compatible; since 0.2.0 new capabilities arrive as new entry points with their
+ * own structs (naf_stem_conv_keys_fwd / naf_key_pool_args) instead of growing existing ones. */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -404,7 +411,10 @@ typedef struct naf_xna_bwd_args {
  * training step (train.py:113-133: 16^2 -> 32^2, ratio 2), patch-14 backbones (ratio 14), 15 x 15 windows.  It needs idx_y /
  * idx_x like the table-driven kernel AND `workspace` (per-query softmax statistics, 16 bytes per query); without a workspace
  * the call runs the table-driven kernel instead.  It adds into the zeroed dk_lr / dv_lr like the other kernels (one read-add-write per key, or fp32
- * atomics where a key tile's rows are shared between waves). */
+ * atomics where a key tile's rows are shared between waves).
+ * Inputs must be FINITE on the NAF_XNA_ROWS kernel: it skips the upper half of a 32-slot chunk that no lane needs and lets the
+ * stale copies of earlier inputs in its LDS segment meet zero weights, so an Inf / NaN in q, k_lr, v_lr or dout can surface in
+ * gradients of pixels whose neighbourhood does not contain it (the reference and the table-driven kernel keep it local). */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
@@ -473,7 +483,12 @@ typedef struct naf_forward_args {
      * that stage's first launch (the 1x1 layer), [7] after its second launch (the 3x3 layer), [4] end of the conv stem (guidance
      * pooled to the output size where needed), [5] after RoPE / key pooling, value packing and index tables (= start of the
      * attention kernel), [6] after the attention kernel.  [3]-[2] and [7]-[3] time ONE launch of each layer kernel inside the
-     * call.  (103-104: [1] / [2] after branch 0's first convolution / block layers, [3] after branch 1's first convolution.) */
+     * call.  (103-104: [1] / [2] after branch 0's first convolution / block layers, [3] after branch 1's first convolution.)
+     * Since 0.2.0 (>= 200) the two branches' block layers run on TWO streams -- the caller's (3x3 branch) and a second one the
+     * library creates per device on first use (1x1 branch), forked by an event after the first convolutions and joined before
+     * the attention; the call stays capturable -- and [2] / [7] bracket one 3x3 launch on the caller's stream (1x1 launches run
+     * beside it), [3] is recorded behind one 1x1 launch on the second stream; [0], [1], [4], [5], [6] as before.  On 16 x 16
+     * pixel cells the key pooling rides on the last block layers (naf_stem_conv_keys_fwd), so [4] -> [5] is the value packing only. */
     void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "naf_common.h"
 
 static thread_local char g_err[512] = "";
@@ -348,6 +350,9 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
     if (naf_xna_bwd_eligible(a)) return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
     // the denoising call's shapes: matrix cores when the caller brought the tables and the statistics workspace
+    // a workspace pointer that is not 16-byte aligned cannot be one this library asked for (a host built against a 0.1.0 header
+    // leaves stack garbage in the field): refuse it instead of writing the per-query statistics through it
+    NAF_REQUIRE(a->workspace == nullptr || al16(a->workspace), "naf_xna_bwd: workspace must be 16-byte aligned");
     if (naf_xna_rows_bwd_eligible(a) && a->idx_y && a->idx_x && a->workspace && (size_t)a->workspace_bytes >= naf_xna_rows_bwd_workspace(a))
         return naf_launch_xna_rows_bwd(a, scale, static_cast<hipStream_t>(stream));
     return naf_launch_xna_generic_bwd(a, scale, static_cast<hipStream_t>(stream));
@@ -355,8 +360,35 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
 
 // ---- whole forward in one call ---------------------------------------------------------------------------
 namespace {
+// The two branches' block layers run on TWO streams (round 4) -- the caller's and one the library creates per device on first use --,
+// forked after the first convolutions and joined before the attention: the launch that follows a 3x3 layer on the other branch is
+// independent of it, so the HBM-bound 1x1 workgroups fill the CUs that a 3x3 launch's tail leaves idle (its first and last
+// workgroups finish 16-27 us apart) instead of waiting behind it.  Same kernels, bit-identical output; -2.0 % per G1 step
+// (profiles/r04_two_streams.txt).  The fork / join are events, so the call is still capturable in a hipGraph.
+// NAF_STEM_STREAMS=1 (with NAF_HIP_KNOBS=1): one stream, the branches' layers alternating (round 3).
+bool fwd_two_streams() {
+    static const bool one = [] { const char* e = naf_knob("NAF_STEM_STREAMS"); return e && atoi(e) == 1; }();
+    static const bool seq = [] { const char* e = naf_knob("NAF_STEM_ORDER"); return e && atoi(e) == 0; }();
+    return !one && !seq;
+}
+// The second stream and its two events are the only HIP objects the library owns (per device, created once, never destroyed); the
+// enqueue of a forked stem holds the device's mutex, so concurrent host threads cannot interleave their fork / join records.
+struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; std::mutex mu; };
+AuxStream* fwd_aux_stream() {
+    static AuxStream aux[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    AuxStream& x = aux[dev];
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> g(create_mu);
+    if (x.s == nullptr) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &x;
+}
 struct FwdLayout {
-    size_t stats, buf0, buf1, buf2, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t stats, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
     int Ho, Wo;   // output size
@@ -382,6 +414,7 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
+    L.buf3 = off;  if (fwd_two_streams()) off = align256(off + px * 128 * 2);   // two streams: a ping-pong pair per branch
     L.cat = off;   off = align256(off + px * 256 * 2);
     L.pooled = L.Ho != L.Hs || L.Wo != L.Ws;
     const size_t opx = (size_t)a->B * L.Ho * L.Wo;
@@ -531,6 +564,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     static const bool sequential = [] { const char* e = naf_knob("NAF_STEM_ORDER"); return e && atoi(e) == 0; }();
     naf_stem_conv0_args c0s[2];
     // first convolution of branch br into y (NULL: statistics only -- the 1x1 branch's first block layer recomputes it)
+    naf_stream_t lstream = stream;   // the stream run_conv0 / run_layer launch on (two-stream mode switches it per branch)
     auto run_conv0 = [&](int br, void* y) -> int {
         const naf_stem_branch& b = a->branch[br];
         naf_stem_conv0_args& c0 = c0s[br];
@@ -540,7 +574,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         for (int i = 0; i < 4; ++i) c0.image_stride[i] = simg_stride[i];
         c0.y = y;
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
-        return naf_stem_conv0_fwd(&c0, stream);
+        return naf_stem_conv0_fwd(&c0, lstream);
     };
     // Key pooling rides on the branches' LAST layers (naf_stem_conv_keys_fwd: axial RoPE split, no pass over the guidance) when
     // every query is rotated on load, the guidance is not pooled, the cells are 16 x 16 pixels and the RoPE heads are 64 wide;
@@ -578,12 +612,53 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         c.stats_out = last ? nullptr : st + (size_t)(l + 1) * stat_stride;
         c.ksize = b.ksize; c.B = a->B; c.H = SH; c.W = SW; c.eps = a->gn_eps;
         for (int i = 0; i < 3; ++i) { c.x_stride[i] = dense[i]; c.y_stride[i] = last ? cat_st[i] : dense[i]; }
-        if (last && keys_fused) return naf_stem_conv_keys_fwd(&c, &kps[br], stream);
-        return naf_stem_conv_fwd(&c, stream);
+        if (last && keys_fused) return naf_stem_conv_keys_fwd(&c, &kps[br], lstream);
+        return naf_stem_conv_fwd(&c, lstream);
     };
     // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
     const bool rec[2] = {a->branch[0].conv0_ksize == 1 && a->branch[0].ksize == 1, a->branch[1].conv0_ksize == 1 && a->branch[1].ksize == 1};
-    if (!sequential) {
+    if (fwd_two_streams() && !sequential) {
+        AuxStream* ax = fwd_aux_stream();
+        NAF_REQUIRE(ax != nullptr, "naf_forward: cannot create the second stream");
+        std::lock_guard<std::mutex> guard(ax->mu);
+        const int timed = a->nlayer > 1 ? 1 : 0;   // the stage whose launches phase_events bracket: [2] .. [7] the 3x3 layer's on the
+                                                   // caller's stream, [3] behind the 1x1 layer's on the second stream
+        auto mark_on = [&](int i, hipStream_t st) -> bool {
+            if (a->phase_events[i] == nullptr) return true;
+            if (hipEventRecord(static_cast<hipEvent_t>(a->phase_events[i]), st) == hipSuccess) return true;
+            naf_set_error("naf_forward: hipEventRecord(phase_events[%d]) failed", i);
+            return false;
+        };
+        const int first = (a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1;   // the HBM-bound branch goes to the second stream
+        void* pp[2][2] = {{ws + L.buf0, ws + L.buf1}, {ws + L.buf2, ws + L.buf3}};
+        void* cur[2] = {nullptr, nullptr};
+        for (int br = 0; br < 2; ++br) {
+            cur[br] = rec[br] ? nullptr : pp[br][0];
+            const int rc = run_conv0(br, cur[br]);
+            if (rc != NAF_OK) return rc;
+        }
+        if (!mark(1)) return NAF_ERR_LAUNCH;
+        if (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) {
+            naf_set_error("naf_forward: stream fork failed");
+            return NAF_ERR_LAUNCH;
+        }
+        for (int l = 0; l < a->nlayer; ++l)
+            for (int k = 0; k < 2; ++k) {
+                const int br = k == 0 ? first : 1 - first;
+                lstream = k == 0 ? static_cast<naf_stream_t>(ax->s) : stream;
+                void* y = (l == a->nlayer - 1) ? nullptr : pp[br][cur[br] == pp[br][0] ? 1 : 0];
+                if (l == timed && k == 1 && !mark_on(2, s)) return NAF_ERR_LAUNCH;
+                const int rc = run_layer(br, l, cur[br], y);
+                lstream = stream;
+                if (rc != NAF_OK) return rc;
+                cur[br] = y;
+                if (l == timed && !mark_on(k == 0 ? 3 : 7, k == 0 ? ax->s : s)) return NAF_ERR_LAUNCH;
+            }
+        if (hipEventRecord(ax->join, ax->s) != hipSuccess || hipStreamWaitEvent(s, ax->join, 0) != hipSuccess) {
+            naf_set_error("naf_forward: stream join failed");
+            return NAF_ERR_LAUNCH;
+        }
+    } else if (!sequential) {
         // within a stage the HBM-bound branch (1x1 block layers) goes first, so that the stem ends on a matrix-bound kernel
         const int first = (a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1;
         const int order[2] = {first, 1 - first};

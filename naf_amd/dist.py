@@ -81,9 +81,14 @@ def broadcast_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, devi
     world, rank = dist.get_world_size(), dist.get_rank()
     via_host = dist.get_backend() == "gloo" and torch.device(device).type != "cpu"
     final_device, device = device, ("cpu" if via_host else device)
+    # The owner's argument check is COLLECTIVE: a one-element status broadcast first, so that a bad `full` raises on every rank
+    # instead of leaving the others blocked in the data broadcast until the process-group timeout.
+    ok = rank != src or (full is not None and tuple(full.shape) == tuple(shape) and full.dtype == dtype)
+    status = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.broadcast(status, src=src)
+    if int(status.item()) != 1:
+        raise ValueError(f"broadcast_batch: rank {src} must pass the full tensor of shape {tuple(shape)} and dtype {dtype}")
     if rank == src:
-        if full is None or tuple(full.shape) != tuple(shape) or full.dtype != dtype:
-            raise ValueError(f"broadcast_batch: rank {src} must pass the full tensor of shape {tuple(shape)} and dtype {dtype}")
         buf = full.contiguous().to(device)
     else:
         buf = torch.empty(tuple(shape), dtype=dtype, device=device)

@@ -23,6 +23,8 @@ view of a channels-last buffer -- the same view the reference returns on its fus
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -531,6 +533,13 @@ class GraphedForward:
                 for _ in range(max(1, warmup)):
                     model._forward_inference(self.image, self.features, self.output_size)
             cur.wait_stream(side)
+            # the warm-up's workspace (1 GB at 1024^2) belonged to the throw-away stream: drop it before the capture allocates the
+            # graph's own, instead of leaving it in the plan's pool until four other streams evict it
+            side.synchronize()
+            warm_plan = (model.__dict__.get("_plan_cache") or (None, None))[1]
+            if warm_plan is not None and hasattr(warm_plan, "release_workspaces"):
+                pool = warm_plan.__dict__.get("_ws_by_stream", {})
+                pool.pop((image.device.index, int(side.cuda_stream)), None)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = model._forward_inference(self.image, self.features, self.output_size)
@@ -785,8 +794,19 @@ class NAF(nn.Module):
                         pe = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
                         for e in pe:
                             e.record()
-                        for name, i, j in (("stem", 0, 4), ("stem_first_convs", 0, 1), ("stem_layer_1x1", 2, 3), ("stem_layer_3x3", 3, 7),
-                                           ("rope_pool", 4, 5), ("attention", 5, 6)):
+                        # under the A/B knob NAF_STEM_ORDER=0 (one branch after the other) the library never records [7] and [1] / [2] / [3]
+                        # mean other things (include/naf_hip.h): only the boundaries both orders share are registered then
+                        knobs = os.environ.get("NAF_HIP_KNOBS") == "1"
+                        sequential = knobs and os.environ.get("NAF_STEM_ORDER") == "0"
+                        one_stream = knobs and os.environ.get("NAF_STEM_STREAMS") == "1"
+                        pairs = (("stem", 0, 4), ("rope_pool", 4, 5), ("attention", 5, 6))
+                        if sequential:
+                            pass
+                        elif one_stream:      # round 3: the branches' layers alternate on one stream
+                            pairs += (("stem_first_convs", 0, 1), ("stem_layer_1x1", 2, 3), ("stem_layer_3x3", 3, 7))
+                        else:                 # version >= 200: two streams; [2] .. [7] bracket one 3x3 launch (the 1x1 launches run beside it)
+                            pairs += (("stem_first_convs", 0, 1), ("stem_layer_3x3", 2, 7))
+                        for name, i, j in pairs:
                             timer.pairs.setdefault(name, []).append((pe[i], pe[j]))
                 return plan.run(image, features, ev, return_logits=bool(return_weights), phase_events=pe)
         fuse_for = None

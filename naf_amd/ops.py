@@ -689,19 +689,32 @@ class ForwardPlan:
         self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype,
                     (Ho, Wo))
 
+    WS_POOL_BYTES = 8 << 30
+
+    def release_workspaces(self, keep_stream: Optional[int] = None) -> None:
+        """Drop the plan's scratch buffers (all of them, or all but the one of raw stream handle ``keep_stream``).  Safe once
+        the work queued on those streams has been synchronised with; a captured graph keeps its own workspace alive itself."""
+        pool = self.__dict__.get("_ws_by_stream", {})
+        for k in [k for k in pool if keep_stream is None or k[1] != keep_stream]:
+            del pool[k]
+        if keep_stream is None:
+            self._ws = None
+
     def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False, phase_events=None):
         a = self.args
         dev = image.device
         # the workspace belongs to the plan (one allocation per geometry, not per call) -- one per (device, stream) the plan has
         # been run on (round 3: forwards of one module on two streams no longer share scratch; the four most recent are kept).
         # Host-side state (the argument struct) is still per plan: calls from several THREADS need a module each.
+        # Memory: a workspace is ~1 GB at 1024^2 and several GB at 2048^2, so the pool is bounded in BYTES too (WS_POOL_BYTES,
+        # default 8 GiB: at least the current stream's workspace always stays); ``release_workspaces()`` drops all of them.
         skey = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
         pool = self.__dict__.setdefault("_ws_by_stream", {})
         ws = pool.pop(skey, None)
         if ws is None:
-            ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
-            while len(pool) >= 4:
+            while pool and (len(pool) >= 4 or (len(pool) + 1) * self.ws_bytes > self.WS_POOL_BYTES):
                 pool.pop(next(iter(pool)))     # least recently used (dicts keep insertion order)
+            ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
         pool[skey] = ws
         self._ws = ws                           # the one the last call used (GraphedForward keeps it alive)
         out = torch.empty(self.shape_out, dtype=self.out_dtype, device=dev)

@@ -56,9 +56,12 @@ def _worker(rank, world, port, ret):
         assert img_b.untyped_storage().nbytes() == img_b.numel() * 4
         if rank == 0:
             assert img_b.data_ptr() != full_img.data_ptr()
-            for bad in (None, full_img[:-1], full_img.double()):         # missing / wrong shape / wrong dtype on the owner
-                with pytest.raises(ValueError):
-                    nd.broadcast_batch(bad, (N, 3, 4, 4), torch.float32, "cpu", src=0)
+        # missing / wrong shape / wrong dtype on the owner: the check is collective -- EVERY rank enters the call and every rank
+        # raises (a src-only raise would leave the others blocked in the broadcast until the process-group timeout)
+        for which in range(3):
+            bad = None if rank != 0 else (None, full_img[:-1], full_img.double())[which]
+            with pytest.raises(ValueError):
+                nd.broadcast_batch(bad, (N, 3, 4, 4), torch.float32, "cpu", src=0)
         empty = nd.scatter_batch(torch.zeros(0, 2) if rank == 0 else None, (0, 2), torch.float32, "cpu", src=0)
         assert empty.shape == (0, 2)
 

@@ -273,8 +273,10 @@ def test_forward_is_differentiable_when_a_gradient_is_wanted(dev):
     _assert_close(out_t.detach().float().cpu(), out.float().cpu(), 8e-2, 4e-2, "forward_train vs inference path")
 
 
-def test_bench_multi_rank_path_dry_run(dev):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process), on ONE GPU with the
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "plain"])
+def test_bench_multi_rank_path_dry_run(dev, launcher):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process) AND as the plain command
+    line `python bench.py --gpus 2` (bench.py then starts its ranks itself on a free port), on ONE GPU with the
     collectives on gloo (NAF_BENCH_BACKEND=gloo: a dry run of the code path, never a measurement): the G3 experiment --
     rank 0 owns the batch, parameters by flat broadcast, inputs by scatter, every rank runs its shard through
     ShardedNAF, rank 0 then runs the whole batch alone for speedup_vs_1 -- prints one well-formed JSON line."""
@@ -285,8 +287,13 @@ def test_bench_multi_rank_path_dry_run(dev):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NAF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "6"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "6"]
+    if launcher == "plain":
+        cmd = [sys.executable, *tail]
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), *tail]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -303,7 +310,7 @@ def test_bench_multi_rank_path_dry_run(dev):
     assert all("uuid" in r and "pci" in r for r in j["ranks"])
     assert j["weak_leg"]["images_per_gpu"] == 3 and j["weak_leg"]["ms_all_ranks_busy"] > 0 and j["weak_leg"]["ms_rank0_alone"] > 0
     ph = j["phases_ms"]
-    assert ph["stem"] > 0 and ph["rope_pool"] > 0 and ph["attention"] > 0 and ph["stem_conv3"] > 0 and ph["stem_conv1"] > 0
+    assert ph["stem"] > 0 and ph["rope_pool"] > 0 and ph["attention"] > 0 and ph["stem_conv3"] > 0
     assert 0 < j["roofline"]["frac_with_prepass"] < j["roofline"]["frac"]
 
 
