@@ -185,10 +185,26 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
         const int row = (mt * 16 + 15 < NSLOT) ? mt * 16 + col : min(mt * 16 + col, NSLOT - 1);
         return Ks + row * KROW + grp * 8;
     };
-    auto va_of = [&](int blk) __attribute__((always_inline)) {
-        const int r = blk * 16 + grp * 4 + (col >> 2);
-        const int row = (blk * 16 + 15 < NSLOT) ? r : min(r, NSLOT - 1);
-        return Vs + row * VROW + (col & 3) * 4;
+    // V^T fragment rows.  A 15x15 window's V rows span 139 KB, more than a ds_read's 16-bit offset field: left to itself hipcc
+    // materialises (and hoists) one address register per (row block, channel-tile pair) -- 80+ registers in the unrolled PV loop.
+    // Two opaque bases, 8 row blocks (<= 61 KB with the channel offset) apart, keep every fragment address "base + immediate";
+    // the blocks that hold padding slots clamp their rows per lane and get a base of their own.
+    constexpr int VFULL = NSLOT / 16;                      // row blocks without padding slots
+    const uint32_t vs_lds = (uint32_t)(uintptr_t)((NAF_LDS bf16_t*)Vs);   // LDS byte address of the V window
+    uint32_t vbase0 = vs_lds + (uint32_t)((grp * 4 + (col >> 2)) * VROW + (col & 3) * 4) * 2u;
+    uint32_t vbase1 = vbase0 + (uint32_t)(8 * 16 * VROW) * 2u;
+    asm volatile("" : "+v"(vbase0), "+v"(vbase1));
+    uint32_t vclamp[2 * KST - VFULL > 0 ? 2 * KST - VFULL : 1];
+#pragma unroll
+    for (int i = 0; i < 2 * KST - VFULL; ++i) {
+        const int r = min((VFULL + i) * 16 + grp * 4 + (col >> 2), NSLOT - 1);
+        vclamp[i] = vs_lds + (uint32_t)(r * VROW + (col & 3) * 4) * 2u;
+        asm volatile("" : "+v"(vclamp[i]));
+    }
+    // LDS pointer of row block blk's fragment rows (add ct * 16 elements for channel tile ct)
+    auto va_of = [&](int blk) __attribute__((always_inline)) -> NAF_LDS bf16_t* {
+        if (blk >= VFULL) return (NAF_LDS bf16_t*)(uintptr_t)vclamp[blk - VFULL];
+        return (NAF_LDS bf16_t*)(uintptr_t)((blk < 8 ? vbase0 : vbase1) + (uint32_t)((blk & 7) * 16 * VROW) * 2u);
     };
 
     // staged stores: 16-byte chunk i = it*64 + lane of the wave's [16 px][DVT] tile (see xna_mfma_kernel.h)
@@ -255,6 +271,7 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     s[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (mt * 16 >= NSLOT) continue;          // a tile of padding slots only (15x15: slots 240 .. 255): P = 0 below
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         if (ABL & 16) { s[mt][ks] += (float)qf[u][ks][mt & 7]; continue; }     // probe: no QK MFMAs / K reads
@@ -262,28 +279,31 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                         s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][ks], s[mt], 0, 0, 0);
                     }
                 }
+                constexpr int MTR = (NSLOT + 15) / 16;     // score tiles that hold real keys
                 float m = -INFINITY;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (mt * 16 + 15 >= NSLOT) s[mt][r] = ((mt * 16 + r + grp * 4) < NSLOT) ? s[mt][r] : -INFINITY;
                         m = fmaxf(m, s[mt][r]);
                     }
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                float sum = 0.f;
-                const float mc = m * p.scale_log2e;
+                m = naf_rows_max(m);          // over the four 16-lane rows on the VALU (a ds_bpermute is an LDS round trip behind the K / V reads)
+                // exponent arguments and the sums two at a time (v_pk_fma_f32 / v_pk_add_f32: the softmax's vector time is what the
+                // large windows are bound by; the exponentials themselves have no packed form)
+                const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, mc2 = {m * p.scale_log2e, m * p.scale_log2e};
+                f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2e, -mc));
-                        s[mt][r] = e;
-                        sum += e;
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2_t x = f32x2_t{s[mt][r], s[mt][r + 1]} * sc2 - mc2;
+                        const f32x2_t e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        s[mt][r] = e[0];
+                        s[mt][r + 1] = e[1];
+                        sum2 += e;
                     }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
+                float sum = naf_rows_sum(sum2[0] + sum2[1]);
                 const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) s[mt] *= inv;
