@@ -270,7 +270,7 @@ def test_forward_is_differentiable_when_a_gradient_is_wanted(dev):
     ftg = ft.clone().requires_grad_(True)
     assert m(img, ftg, (32, 32)).grad_fn is not None             # eval mode, but a gradient w.r.t. the features is wanted
     # both paths compute the same function (fp32 torch stem vs bf16 fused stem: loose tolerance)
-    _assert_close(out_t.detach().float().cpu(), out.float().cpu(), 8e-2, 4e-2, "forward_train vs inference path")
+    _assert_close(out_t.detach().float().cpu(), out.float().cpu(), 2e-2, 1e-2, "forward_train vs inference path")   # measured 7.3e-3
 
 
 @pytest.mark.parametrize("launcher", ["torch.distributed.run", "plain"])
@@ -410,8 +410,12 @@ def test_denoising_configuration_runs_entirely_on_hip(dev):
     noisy = O.hash_normal((1, 3, S, S), 7102)
     out = m(img.to(dev), noisy.to(dev), (S, S)).float().cpu()
     ref = O.naf_forward(p, img, noisy, (S, S), kernel_size=15, heads_attn=1, heads_rope=1)
-    _assert_close(out, ref, 1e-1, 4e-2, "denoising configuration")
-    assert float((out - ref).abs().mean()) <= 8e-3
+    # one head, a 15x15 window at ratio 1 (every query's own cell dominates its softmax), three value channels: measured maximum
+    # 5.8e-2, 16 of 6912 elements outside SURVEY 8c's 2e-2 + 1e-2 |ref|, mean 1.4e-3 (profiles/r04_tolerance_budget.txt); asserted
+    # with 1.5x head-room on the maximum and three times the outliers
+    _assert_close(out, ref, 8.7e-2, 1e-2, "denoising configuration")
+    assert float(((out - ref).abs() > 2e-2 + 1e-2 * ref.abs()).float().mean()) <= 7e-3
+    assert float((out - ref).abs().mean()) <= 3e-3
 
 
 def test_attention_G3_whole_batch_of_64_in_one_launch(dev):

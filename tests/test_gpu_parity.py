@@ -7,10 +7,11 @@ Tolerances (fp, stated here as the prompt asks):
       bf16 output  : |err| <= 1.2e-2 + 1.2e-2*|ref|  (+ one bf16 rounding of the result)
   * whole forward (bf16-activation HIP conv stem, bf16 Q/K/V) vs the fp32 reference golden vectors / the oracle:
       SURVEY.md section 8c's |err| <= 2e-2 + 1e-2*|ref| elementwise and mean |err| <= 6e-3 (outputs are O(1));
-      looser where the softmax is peaked and the output follows single keys instead of averaging them (the stem's bf16
-      error, 6.9e-3 of the guidance RMS after five layers -- profiles/r02_stem_error_budget.txt -- then shows undamped):
-      6e-2 + 3e-2*|ref| for cells of 1-2 pixels, 1e-1 + 3e-2*|ref| for the one-head k=5 denoising case F6, and for the
-      bf16-output variants one more output rounding (8e-2 + 4e-2*|ref| kept from round 1 where not re-measured).
+      looser only where the softmax is peaked and the output follows single keys instead of averaging them (the stem's bf16
+      error, 6.9e-3 of the guidance RMS after five layers -- profiles/r02_stem_error_budget.txt -- then shows undamped), each
+      with its measured budget (profiles/r04_tolerance_budget.txt, tools/tolerance_probe.py: measured maximum x 1.5 and a bound
+      on the fraction of elements outside 8c): cells of 2 pixels 3.6e-2, of 1 pixel 6e-2 (+ 1e-2*|ref|), the one-head k=5
+      denoising golden F6 4.5e-2 (profiles/r03_f6_error.txt).  Everything else, bf16 I/O and 14-pixel cells included, holds 8c.
 """
 import os
 
@@ -563,7 +564,7 @@ def test_golden_F5_full_forward_P1(dev, golden_dir):
     # bf16 features -> bf16 output, same values within one more rounding
     out_b = m(img.to(dev), ft.to(dev).to(torch.bfloat16), [224, 224])
     assert out_b.dtype == torch.bfloat16
-    assert_close(out_b.float().cpu()[:, :, oy::st, ox::st], ref, 8e-2, 4e-2, "F5 bf16 I/O")
+    assert_close(out_b.float().cpu()[:, :, oy::st, ox::st], ref, 2e-2, 1e-2, "F5 bf16 I/O")      # measured 2.7e-3 (r04_tolerance_budget.txt)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -606,9 +607,8 @@ def test_golden_F10_patch14(dev, golden_dir, feat_dtype):
     assert ops.xna_rope_fusable(q_raw, (h, w), C // 4, int(g["k"]), m.image_encoder.rope.tables(H, W))
     out = m(img, ft, (H, W)).float().cpu()
     got, ref = out[:, ::2, ::3, 1::3], torch.from_numpy(g["sample"])
-    tol = 1.0 if feat_dtype == torch.float32 else 1.35
-    assert_close(got, ref, 6e-2 * tol, 3e-2 * tol, "F10 strided sample vs reference")
-    assert _forward_stats(got, ref)[1] <= 6e-3 * tol
+    assert_close(got, ref, 2e-2, 1e-2, "F10 strided sample vs reference")     # measured 3.3e-3 (fp32 features) / 3.7e-3 (bf16)
+    assert _forward_stats(got, ref)[1] <= 6e-3
 
 
 def test_golden_F6_denoise_like(dev, golden_dir):
@@ -1449,8 +1449,16 @@ def test_single_call_forward_other_geometries(dev, hw, lr, C, ksz, path):
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), hw, kernel_size=ksz)
     # cells of 1 or 2 pixels: each query's own cell dominates its window (q.k of the cell it was pooled from), the softmax is
     # peaked and the output follows single keys instead of averaging them -- the stem's bf16 error shows undamped
-    small_cells = hw[0] // lr[0] <= 2
-    assert_close(a.float().cpu(), ref, *((6e-2, 3e-2) if small_cells else (2e-2, 1e-2)), f"single-call forward vs oracle {hw} {lr}")
+    # Measured (profiles/r04_tolerance_budget.txt): 2-pixel cells max 3.2e-2 with 2 of 491 520 elements outside 8c, 1-pixel cells
+    # 4.1e-2 with 19 of 129 600; asserted: the maximum with 1.5x head-room and three times the outliers.
+    cell = hw[0] // lr[0]
+    got = a.float().cpu()
+    if cell <= 2:
+        assert_close(got, ref, 3.6e-2 if cell == 2 else 6e-2, 1e-2, f"single-call forward vs oracle {hw} {lr}")
+        outside = ((got - ref).abs() > 2e-2 + 1e-2 * ref.abs()).float().mean()
+        assert float(outside) <= (1.3e-5 if cell == 2 else 4.5e-4), float(outside)
+    else:
+        assert_close(got, ref, 2e-2, 1e-2, f"single-call forward vs oracle {hw} {lr}")
 
 
 @pytest.mark.parametrize("L_out,L_in,k", [(64, 28, 9), (512, 37, 9), (518, 37, 15), (23, 5, 3), (30, 7, 5), (256, 256, 15),
