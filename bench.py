@@ -159,7 +159,10 @@ def measure_traffic_live(workload, per_gpu_batch, timeout_s=90):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--per-gpu-batch", str(per_gpu_batch), "--steps", "3",
                    "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"]
-            env = dict(os.environ, TMPDIR="/tmp")
+            # a plain single-GPU child, also when this process is rank 0 of a multi-GPU run (no launcher variables, same device)
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                       "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "NAF_BENCH_BACKEND")}
+            env["TMPDIR"] = "/tmp"
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 return None
@@ -418,8 +421,10 @@ def main():
         if xna_ms:
             ach = alg / (xna_ms * 1e-3) / 1e9
             traffic, kname, tsrc = None, "xna_mfma_kernel", None
-            if world == 1 and not args.no_live_traffic and not args.attention_only and not args.graph:
-                live = measure_traffic_live(args.workload, B)
+            # one GPU: this workload; several: rank 0 measures one micro-batch launch of its shard the same way (the other ranks wait
+            # at the closing barrier), so that the N > 1 line carries a measured number too, not a constant x micro-batch
+            if not args.no_live_traffic and not args.attention_only and not args.graph and backend == "nccl":
+                live = measure_traffic_live(args.workload, mb, timeout_s=90 if world == 1 else 240)
                 if live is not None:
                     traffic, kname = live
                     tsrc = "measured in this run: rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean per launch of the attention kernel"
@@ -435,7 +440,7 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": tsrc or ("committed constant: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r03_pmc_hbm_traffic.txt" if traffic else None),
+                    "traffic_source": tsrc or ("committed constant x images per launch: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/traffic.json" if traffic else None),
                     "kernel": kname,
                     "kernel_ms": round(xna_ms, 4), "launches": timer.count("xna_mfma"), "algorithmic_bytes": alg,
                     # the same kernel against the matrix pipe (large windows approach the MFMA ridge):

@@ -26,6 +26,7 @@ struct StemConv0Params {
     int32_t is[4];     // {b unused, c, y, x} element strides (validated < 2^31 by the launcher)
     int64_t ibs;       // batch stride of the image
     int64_t ys[3];     // {b, y, x}
+    int32_t groups_per_block = 0;   // split kernel: a workgroup owns this many CONSECUTIVE segments (its waves interleave inside the range)
 };
 
 namespace {
@@ -250,10 +251,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
 // Not bit-equal to an fmaf chain any more (the 1x1 layer, whose recompute relies on that, keeps the fp32 kernel): agrees with it
 // to ~1e-7 relative before the bf16 rounding of the output (tests/test_gpu_parity.py::test_stem_conv0).
 namespace {
-constexpr int NWS = 8;                                   // waves per workgroup (the 48 KB of split weights are shared by 8 waves)
-// term t = (image part, weight part), smallest products first;  parts: 0 = high, 1 = middle, 2 = low
-__device__ __forceinline__ constexpr int split_xpart(int t) { return t == 0 ? 1 : t == 1 ? 2 : t == 2 ? 0 : t == 3 ? 1 : t == 4 ? 0 : 0; }
-__device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 1 : t == 1 ? 0 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 1 : 0; }
+#ifndef NAF_CONV0_NWS
+#define NAF_CONV0_NWS 12   // 168 registers: three waves per SIMD (round 4: 0.086 -> 0.080 ms alone; 8 waves = two per SIMD before)
+#endif
+constexpr int NWS = NAF_CONV0_NWS;                                   // waves per workgroup (they share one LDS copy of the 48 KB of split weights)
+// term t = (image part, weight part);  parts: 0 = high, 1 = middle, 2 = low.  Round 4: the terms are GROUPED BY WEIGHT PART --
+// (x0 w2) | (x1 w1) (x0 w1) | (x2 w0) (x1 w0) (x0 w0) -- so that a weight fragment is read from the LDS once and feeds up to three
+// MFMAs back to back: 6 fragment reads per output-channel tile instead of 12 (the weight reads were the kernel's largest LDS
+// stream: 48 KB per 32-pixel segment), and the LDS holds 3 x 2 instead of 6 x 2 k-steps of weights.  The largest products still
+// come last; with fp32 accumulation the order inside the 2^-16 / 2^-8 classes is immaterial at the 1e-7 the split is good for.
+__device__ __forceinline__ constexpr int split_xpart(int t) { return t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 0 : t == 3 ? 2 : t == 4 ? 1 : 0; }
+__device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 0 : 0; }
 }  // namespace
 
 // T0 = first term used: 0 -> all six (fp32-exact products), 3 -> the three largest (products carried to 16 mantissa bits).
@@ -270,8 +278,8 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    bf16_t* wl = reinterpret_cast<bf16_t*>(smem0);                       // [12][128][16]
-    bf16_t* otile = wl + 12 * C0 * 16;                                    // [NWS][32][OPX]
+    bf16_t* wl = reinterpret_cast<bf16_t*>(smem0);                       // [3 parts][2 s][128][16]
+    bf16_t* otile = wl + 6 * C0 * 16;                                     // [NWS][32][OPX]
     float* biasv = reinterpret_cast<float*>(otile + NWS * 32 * OPX);      // [128]
     float* red = biasv + C0;                                              // [NWS][16]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
     const int b = blockIdx.y;
     const T* ib = reinterpret_cast<const T*>(p.img) + (int64_t)b * p.ibs;
 
-    // split weights -> LDS: element (kstep = term*2 + s, oc, k = kg*8 + j) = part wpart(term) of W[oc][tap = s*16 + k] (0 past 27)
+    // split weights -> LDS: element (part * 2 + s, oc, k = kg*8 + j) = that bf16 part of W[oc][tap = s*16 + k] (0 past 27)
     for (int i = tid; i < C0 * 32; i += NWS * 64) {
         const int oc = i >> 5, tap = i & 31;
         const float w = tap < 27 ? p.w[oc * 27 + tap] : 0.f;
@@ -289,11 +297,9 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
         const bf16_t w1 = (bf16_t)r1;
         const bf16_t w2 = (bf16_t)(r1 - (float)w1);
         const int s = tap >> 4, k = tap & 15;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int wp = split_wpart(t);
-            wl[((t * 2 + s) * C0 + oc) * 16 + k] = wp == 0 ? w0 : wp == 1 ? w1 : w2;
-        }
+        wl[((0 * 2 + s) * C0 + oc) * 16 + k] = w0;
+        wl[((1 * 2 + s) * C0 + oc) * 16 + k] = w1;
+        wl[((2 * 2 + s) * C0 + oc) * 16 + k] = w2;
     }
     if (tid < C0) biasv[tid] = p.bias[tid];
     __syncthreads();
@@ -336,15 +342,19 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
     bf16_t* yb = p.y + (int64_t)b * p.ys[0];
     bf16_t* otw = otile + wave * 32 * OPX;
     const int chk = lane & 15, psub = lane >> 4;
-    const int gstride = gridDim.x * NWS;
+    // Work -> memory map: a workgroup owns a block of consecutive segments, handed out in dispatch order (one-shot ranges stream at
+    // 5.3-6.2 TB/s on these boxes, a persistent grid-stride walk over the whole image at 4.2-4.9: profiles/r02_hbm_ceiling.txt -- the
+    // lesson the 1x1 layers took in round 2; this kernel writes 268 MB and still walked the image grid-stride until round 4)
+    const int gstride = NWS;
+    const int gend = min(p.ngroups, (int)(blockIdx.x + 1) * p.groups_per_block);
     const uint32_t st_lane = (uint32_t)(psub * (int)p.ys[2] + chk * 8) * 2u;
     const bf16_t* wa = wl + n32 * 16 + half * 8;           // + (kstep * 128 + 32 m) * 16
 
     float sv[16], nx[16];
-    int g = blockIdx.x * NWS + wave;
+    int g = blockIdx.x * p.groups_per_block + wave;
     load_taps(g, sv);
     C0_T(0);   // set-up: split weights -> LDS, first taps requested
-    for (; g < p.ngroups; g += gstride) {
+    for (; g < gend; g += gstride) {
         bf16x8_t xb[3][2];
         split_taps(sv, xb);
         C0_T(1);   // taps arrive + three-way split
@@ -365,25 +375,32 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[q][j * 4 + i] = bj[i];
                 }
-            // the two weight fragments of step i + 1 are requested before the two MFMAs of step i (two register sets pinned by
-            // sched_barriers; left alone hipcc reads every fragment right in front of its MFMA -- the 1x1 layer's lesson, round 3)
+            // one weight fragment pair (part wp, half s) per group of terms that share it; the next pair is requested before the MFMAs
+            // of the current one (two register sets pinned by sched_barriers; left alone hipcc reads every fragment right in front of its
+            // MFMA -- the 1x1 layer's lesson, round 3)
             {
-                constexpr int NSTEP = (6 - T0) * 2;
+                // (weight part, first term, terms) of the groups from term T0 on: T0 = 0: w2 {0}, w1 {1, 2}, w0 {3, 4, 5}; T0 = 3: w0 {3, 4, 5}
+                constexpr int NGRP = T0 == 0 ? 3 : 1;
+                constexpr int GW[3] = {T0 == 0 ? 2 : 0, 1, 0}, GT0[3] = {T0 == 0 ? 0 : 3, 1, 3}, GN[3] = {T0 == 0 ? 1 : 3, 2, 3};
+                constexpr int NFR = NGRP * 2;                     // fragment pairs: (group, s)
                 bf16x8_t af[2][2];
-                auto frag = [&](int i, int slot) __attribute__((always_inline)) {
-                    const int ts = T0 * 2 + i;   // = t * 2 + s
+                auto frag = [&](int f, int slot) __attribute__((always_inline)) {
+                    const int gi = f >> 1, sh = f & 1;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) af[slot][q] = *reinterpret_cast<const bf16x8_t*>(wa + (ts * C0 + 32 * (2 * mp + q)) * 16);
+                    for (int q = 0; q < 2; ++q) af[slot][q] = *reinterpret_cast<const bf16x8_t*>(wa + ((GW[gi] * 2 + sh) * C0 + 32 * (2 * mp + q)) * 16);
                 };
                 frag(0, 0);
 #pragma unroll
-                for (int i = 0; i < NSTEP; ++i) {
+                for (int f = 0; f < NFR; ++f) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (i + 1 < NSTEP) frag(i + 1, (i + 1) & 1);
+                    if (f + 1 < NFR) frag(f + 1, (f + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int t = T0 + (i >> 1), s = i & 1;
+                    const int gi = f >> 1, sh = f & 1;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i & 1][q], xb[split_xpart(t)][s], acc[q], 0, 0, 0);
+                    for (int n = 0; n < GN[gi]; ++n)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[f & 1][q], xb[split_xpart(GT0[gi] + n)][sh], acc[q], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -583,7 +600,8 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
         const int64_t gpw8 = (ng * a->B + slots8 - 1) / slots8;
         int64_t nb8 = (ng + gpw8 * NWS - 1) / (gpw8 * NWS);
         if (nb8 < 1) nb8 = 1;
-        const size_t lds = (size_t)(12 * C0 * 16 + NWS * 32 * OPX) * 2 + (size_t)(C0 + NWS * 16) * sizeof(float);
+        p.groups_per_block = (int32_t)(gpw8 * NWS);
+        const size_t lds = (size_t)(6 * C0 * 16 + NWS * 32 * OPX) * 2 + (size_t)(C0 + NWS * 16) * sizeof(float);
         const dim3 g8((uint32_t)nb8, (uint32_t)a->B), blk8(NWS * 64);
         auto launch = [&](auto kern) -> int {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -13,6 +13,26 @@ rm -rf $out; mkdir -p $out
 python bench.py > $out/bench_line.json 2> $out/bench.err
 python bench.py --no-cpu-baseline --no-live-traffic --phase-every 1 > $out/bench_line_all_phases.json 2>> $out/bench.err
 tail -1 $out/bench_line.json | cut -c1-400
+# the same step replayed from a hipGraph (launch gaps on record), and the A/B lines of this round's two changes to the forward:
+# key pooling on the last stem layers vs the separate pre-pass, two streams vs one (interleaved, one lease)
+python bench.py --graph --no-cpu-baseline --no-live-traffic > $out/bench_line_graph.json 2>> $out/bench.err
+{
+  echo "# interleaved A/B on one lease (bench.py --steps 300, G1): ms per step, Mpix/s, phases"
+  for i in 1 2; do
+    for v in "default" "NAF_KEYS_FUSE=0" "NAF_STEM_STREAMS=1" "NAF_KEYS_FUSE=0 NAF_STEM_STREAMS=1"; do
+      if [ "$v" = default ]; then e=""; else e="NAF_HIP_KNOBS=1 $v"; fi
+      env $e python bench.py --steps 300 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-40s %.4f ms  %.1f Mpix/s  stem %.4f  prepass %.4f  attention kernel %.4f  frac %.4f  frac_with_prepass %.4f' % ('$v', d['ms_per_step'], d['value'], d['phases_ms']['stem'], r['prepass_ms'], r['kernel_ms'], r['frac'], r['frac_with_prepass']))"
+    done
+  done
+} > $out/ab_keys_streams.txt
+cat $out/ab_keys_streams.txt
+{
+  echo "# bench.py --workload W --steps 100 (one lease): Mpix/s, ms per step, attention kernel ms, fraction of the 8 TB/s HBM roof, of the 2.5 PFLOP/s MFMA roof"
+  for w in G2-k7 G2-k11 G2-k15 G3 G4 REF448; do
+    python bench.py --workload $w --steps 100 --no-cpu-baseline --no-live-traffic 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-8s %8.2f Mpix/s  %.4f ms/step  attention %.4f ms  hbm %.4f  mfma %.4f  stem %.4f' % ('$w', d['value'], d['ms_per_step'], r['kernel_ms'], r['frac'], r['mfma_frac'], d['phases_ms']['stem']))"
+  done
+} > $out/other_workloads.txt
+cat $out/other_workloads.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --no-cpu-baseline --no-live-traffic > $out/trace.log 2>&1)
 grep '^{"metric"' $out/trace.log | tail -1 > $out/bench_line_under_rocprof.json
 f=$(ls $out/trace/*/*kernel_stats.csv | head -1)
