@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 if (mt * 16 + 15 >= NSLOT) sT[mt][r] = (mt * 16 + grp * 4 + r < NSLOT) ? sT[mt][r] : -INFINITY;
                 m = fmaxf(m, sT[mt][r]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        // the three cross-row reductions of a tile on the VALU (v_permlane16/32_swap): as ds_bpermute round trips they queued behind
+        // the K / V row reads of all eight waves of the CU, three dependent pairs per tile (round 4)
+        m = naf_rows_max(m);
         const float mc = m * p.scale_log2e;
         float sum = 0.f;
 #pragma unroll
@@ -253,8 +254,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 sT[mt][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = naf_rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         float delta = 0.f;
 #pragma unroll
@@ -264,8 +264,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 sT[mt][r] *= inv;                       // P^T
                 delta = fmaf(sT[mt][r], gT[mt][r], delta);
             }
-        delta += __shfl_xor(delta, 16);
-        delta += __shfl_xor(delta, 32);
+        delta = naf_rows_sum(delta);
         // dS^T = scale * P (dP - delta), packed as the B operand of dQ^T = K^T . dS^T  (k order as the forward's P)
         bf16x8_t dsf[KST];
 #pragma unroll
@@ -318,13 +317,18 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
         // ---- lane = key: P and dS in A-operand form for the contractions over queries ----
         {
             // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout
-            float mcq[4], invq[4], dlq[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mcq[r] = __shfl(mc, grp * 4 + r);
-                invq[r] = __shfl(inv, grp * 4 + r);
-                dlq[r] = __shfl(delta, grp * 4 + r);
+            // ... and travel through the wave's own dS slots of the LDS, which are free until they are written below: three 64-byte
+            // writes and three ds_read_b128 (queries 4 grp .. + 3 are consecutive) instead of twelve ds_bpermute (round 4)
+            float* stw = reinterpret_cast<float*>(Sl + (wave * MT) * 64);
+            if (grp == 0) {
+                stw[col] = mc;
+                stw[16 + col] = inv;
+                stw[32 + col] = delta;
             }
+            const f32x4_t mcq = *reinterpret_cast<const f32x4_t*>(stw + grp * 4);
+            const f32x4_t invq = *reinterpret_cast<const f32x4_t*>(stw + 16 + grp * 4);
+            const f32x4_t dlq = *reinterpret_cast<const f32x4_t*>(stw + 32 + grp * 4);
+            asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq));   // the reads complete before the slots are overwritten
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool kvalid = live && (mt * 16 + col < NSLOT);

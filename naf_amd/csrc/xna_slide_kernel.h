@@ -30,11 +30,17 @@ struct XnaSlideParams {
 // windows).  STG (bf16 output, TPWV == 1): whole-row stores through a per-wave LDS tile, as in xna_mfma_kernel.
 // ABL: ablation bits for tools/xna_probe.hip (1 no output stores, 2 no PV MFMAs / V reads, 4 no query loads, 8 no window
 // column loads, 16 no QK MFMAs / K reads).
-template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false, int ABL = 0>
+// HS (round 4; TPWV == 2, bf16 output, windows whose LDS leaves room: 11x11 with HS = 128, 13x13 with HS = 64): the two tiles' results
+// of HS consecutive channels are collected in a per-wave LDS tile [2][16 px][HS] and leave as runs of 2 * HS bytes per pixel --
+// whole 128-byte lines -- instead of one 64-byte piece per pixel and channel-tile pair (half a line per store instruction: the
+// stores were a quarter of the 11x11 kernel, profiles/r03_negative_results.txt).  Whole-row staging needs one tile per wave (STG)
+// and was slower there because every V^T fragment then feeds one MFMA instead of two.
+template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false, int ABL = 0, int HS = 0>
 __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams sp) {
     const XnaMfmaParams& p = sp.m;
     constexpr int NT = NW * 64, TPW = TPWV;
     static_assert(!STG || (TPWV == 1 && sizeof(OutT) == 2 && (DVT % 32) == 0), "staged stores: bf16, one tile per wave, even channel-tile count");
+    static_assert(HS == 0 || (!STG && TPWV == 2 && sizeof(OutT) == 2 && (HS == 64 || HS == 128) && DVT % HS == 0), "half-row staging: bf16, two tiles per wave");
     using G = XnaGeom<KS, 1>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW;
     constexpr int VROW = XnaVRow<DVT>::VROW;
@@ -386,7 +392,48 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                     }
                 }
             } else {
-            if constexpr (kWide) {
+            if constexpr (HS != 0) {
+                using HT = XnaStageTile<HS>;
+                constexpr int HCT = HS / 16, HVC = HS / 8, HIT = 16 * HVC / 64;     // channel tiles / 16-byte chunks per staged pixel, read-back trips
+                bf16_t* ow = Os + wave * 2 * 16 * HT::OROW;
+                const int ochunk = (grp & 1) * 2 + (grp >> 1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ct += 2) {
+                    f32x4_t a[TPW], bq[TPW];
+                    pv_tile(ct, a);
+                    pv_tile(ct + 1, bq);
+#pragma unroll
+                    for (int u = 0; u < TPW; ++u) {
+                        bf16x4_t ab, bb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ab[i] = (bf16_t)a[u][i];
+                            bb[i] = (bf16_t)bq[u][i];
+                        }
+                        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                        *reinterpret_cast<u32x4_t*>(ow + u * 16 * HT::OROW + HT::offset(col, (ct % HCT) * 2 + ochunk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    }
+                    if ((ct + 2) % HCT == 0) {      // HS channels of both tiles are in the LDS: they leave as 2 * HS bytes per pixel
+                        const int cbase = ct + 2 - HCT;
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) {
+                            char* otile = reinterpret_cast<char*>(opv[u]) - o_lane;     // first pixel of the tile (wave-uniform)
+#pragma unroll
+                            for (int it = 0; it < HIT; ++it) {
+                                const int i = it * 64 + lane, pp = i / HVC, ch = i - pp * HVC;
+                                const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + u * 16 * HT::OROW + HT::offset(pp, ch));
+                                if (ABL & 1) {
+                                    asm volatile("" ::"v"(wv));
+                                } else if (okv[u]) {
+                                    *reinterpret_cast<u32x4_t*>(otile + (uint32_t)(pp * (int)p.os[3] + cbase * 16 + ch * 8) * 2u) = wv;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else if constexpr (kWide) {
 #pragma unroll
                 for (int ct = 0; ct < CTP; ct += 2) {
                     f32x4_t a[TPW], bq[TPW];
@@ -413,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
                 }
             }
 #pragma unroll
-            for (int ct = CTP; ct < CT; ++ct) {
+            for (int ct = (HS != 0 ? CT : CTP); ct < CT; ++ct) {
                 f32x4_t acc[TPW];
                 pv_tile(ct, acc);
 #pragma unroll
@@ -451,11 +498,25 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
     for (int u = 0; u < TPW; ++u) asm volatile("; xna slide loop drained" ::"v"(qf[u][0]), "v"(qf[u][1]));
 }
 
+// channels staged per flush of the half-row variant: 8-wave windows (one workgroup per CU anyway) whose LDS leaves room for the
+// per-wave tiles [2][16][HS] bf16 -- 128 at 11x11, 64 at 13x13 (Dv 256); -DNAF_SLIDE_NO_HS: never (A/B builds)
+constexpr int xna_slide_hs(int ks, int dvt, int nw, int tpw, bool stg, size_t out_bytes) {
+#ifdef NAF_SLIDE_NO_HS
+    return 0;
+#else
+    if (stg || tpw != 2 || out_bytes != 2 || nw != 8) return 0;
+    const size_t base = xna_mfma_lds_for(ks, 1, dvt, false);
+    if (dvt % 128 == 0 && base + (size_t)nw * 2 * 16 * 128 * 2 <= 160 * 1024) return 128;
+    if (dvt % 64 == 0 && base + (size_t)nw * 2 * 16 * 64 * 2 <= 160 * 1024) return 64;
+    return 0;
+#endif
+}
 template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false>
 static int xna_slide_launch_one(const XnaSlideParams& sp, hipStream_t s) {
-    constexpr size_t lds = xna_mfma_lds_bytes<KS, 1, DVT, STG, NW>();
+    constexpr int HSV = xna_slide_hs(KS, DVT, NW, TPWV, STG, sizeof(OutT));
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, 1, DVT, STG, NW>() + (size_t)NW * 2 * 16 * HSV * 2;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_slide_kernel<KS, DVT, OutT, NW, ROPE, TPWV, STG>;
+    auto kern = xna_slide_kernel<KS, DVT, OutT, NW, ROPE, TPWV, STG, 0, HSV>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

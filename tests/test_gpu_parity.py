@@ -1249,6 +1249,8 @@ def test_full_forward_odd_shapes_match_oracle(dev, img_hw, lr, C, ksz):
     (2, 256, (12, 20), (192, 320), 7, torch.float32),      # fp32 output -> sliding kernel, several segments per row
     (1, 192, (11, 13), (176, 416), 11, torch.bfloat16),    # 11x11, dx = 32 (two row tiles per cell row), Dv = 48 (odd tile count)
     (1, 1024, (15, 17), (240, 272), 15, torch.bfloat16),   # 15x15, Dv = 256: 155 KB window, 8 waves
+    (1, 1024, (12, 13), (192, 208), 11, torch.bfloat16),   # 11x11, Dv = 256: stores staged 128 channels at a time (round 4)
+    (2, 1024, (13, 14), (208, 448), 13, torch.bfloat16),   # 13x13, Dv = 256: staged 64 channels at a time, dx = 32, two images
 ])
 def test_sliding_window_kernel_matches_oracle(dev, B, C, lr, out_sz, ksz, out_dtype):
     """xna_slide_kernel (plans without staged stores): ring-of-columns window, per-cell column refresh, segment borders."""
