@@ -74,3 +74,63 @@ def test_stem_conv_keys_refuses_other_geometries(dev):
     keys = torch.zeros((B, 2, 3, 128), dtype=torch.bfloat16, device=dev)
     with pytest.raises(Exception):
         ops.stem_conv(xd, st_in, gw, gb, 1e-5, wp, bias, y, None, keys=(keys, ty, tx))
+
+
+def test_stem_conv_keys_fuzz_sizes(dev):
+    """Seeded random geometries (cells of 16 x 16, strips of 32 for the 3x3 kernel, 1-3 images, 1-9 bands of cells): both kernels,
+    keys vs the oracle on the layer's own bf16 output, as in the parametrised test above."""
+    import numpy as np
+    from naf_amd import ops
+    rng = np.random.RandomState(404)
+    per = O.rope_periods(256, 4, 100.0)
+    for n in range(8):
+        ks = 1 if n % 2 == 0 else 3
+        B, h = int(rng.randint(1, 4)), int(rng.randint(1, 10))
+        w = int(rng.randint(1, 8)) * (2 if ks == 3 else 1)
+        H, W = 16 * h, 16 * w
+        xd, st_in, gw, gb, wp, bias = _layer_inputs(dev, B, H, W, ks, 1000 + n)
+        ty, tx = ops.rope_tables(per.to(dev), H, W)
+        cat = torch.zeros((B, H, W, 256), dtype=torch.bfloat16, device=dev)
+        keys = torch.zeros((B, h, w, 256), dtype=torch.bfloat16, device=dev)
+        br = n % 2
+        ops.stem_conv(xd, st_in, gw, gb, 1e-5, wp, bias, cat[..., 128 * br:128 * br + 128], None,
+                      keys=(keys[..., 128 * br:128 * br + 128], ty, tx))
+        y = cat[..., 128 * br:128 * br + 128].float().cpu().permute(0, 3, 1, 2).contiguous()
+        ref = O.key_pool(O.rope(y, per, 2), (h, w))
+        got = keys[..., 128 * br:128 * br + 128].float().cpu().permute(0, 3, 1, 2)
+        err = (got - ref).abs()
+        assert bool((err <= 1e-5 + 2 ** -8 * ref.abs()).all()), f"ks={ks} B={B} {H}x{W}: max err {float(err.max()):.3e}"
+
+
+def test_forward_with_and_without_key_fusion_agree(dev):
+    """naf_forward with the keys riding on the last stem layers (default) against the same forward with the separate pooling
+    pre-pass (NAF_KEYS_FUSE=0, a process-wide A/B knob: second process): the keys differ by fp32 summation order only, i.e. by
+    at most one bf16 rounding, and the outputs by what that moves (far inside the parity tolerance)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from oracle import naf_oracle as O\n"
+        "from naf_amd import NAF\n"
+        "p = O.make_params(seed=45)\n"
+        "m = NAF(kernel_size=7).eval(); m.load_state_dict(p, strict=True); m = m.cuda()\n"
+        "img = O.hash_normal((2, 3, 128, 160), 981).cuda(); ft = O.hash_normal((2, 128, 8, 10), 982).cuda().to(torch.bfloat16)\n"
+        "with torch.no_grad(): o = m(img, ft, (128, 160))\n"
+        "torch.save(o.float().cpu(), sys.argv[1])\n")
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for fuse in (None, "0"):
+            env = dict(os.environ, NAF_HIP_KNOBS="1")
+            env.pop("NAF_KEYS_FUSE", None)
+            if fuse is not None:
+                env["NAF_KEYS_FUSE"] = fuse
+            f = os.path.join(td, f"o{fuse}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(f))
+    err = (outs[0] - outs[1]).abs()
+    assert float(err.max()) <= 1.2e-2 and float(err.mean()) <= 2e-4, (float(err.max()), float(err.mean()))
