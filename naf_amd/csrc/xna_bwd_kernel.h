@@ -205,22 +205,59 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
 
         // S^T, dP^T (lane = query) and S, dP (lane = key) from the same fragments
         f32x4_t sT[MT], gT[MT], sS[MT], gS[MT];
+        // Only where it pays and fits: 9x9 at C = 384 0.935 -> 0.86 ms (round 4, interleaved); 7x7 windows measure the same with and without
+        // (G1 0.97-1.00 vs 0.96-0.97 ms: their four key tiles leave little to pipeline), the widest shapes spill with the second set.
+        constexpr bool kPrefetch = (KS == 9 && DV <= 128) || KS == 11 || (KS == 13 && DV <= 96);
+        if constexpr (kPrefetch) {
+            // the K / V row fragments of key tile mt + 1 are requested before the MFMAs of tile mt (two register sets pinned by
+            // sched_barriers: left alone hipcc reads every fragment right in front of its MFMAs, and this phase -- 42 % of a wave's
+            // life, profiles/r02_xna_bwd_phase.txt -- is then a chain of LDS round trips; the 1x1 stem layer's lesson, round 3)
+            bf16x8_t kfr[2][2], vfr[2][DKS];
+            auto frags = [&](int mt, int slot) __attribute__((always_inline)) {
+                const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+                const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            sT[mt] = gT[mt] = sS[mt] = gS[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+                for (int ks = 0; ks < 2; ++ks) kfr[slot][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
-                sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sT[mt], 0, 0, 0);
-                sS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sS[mt], 0, 0, 0);
+                for (int ks = 0; ks < DKS; ++ks) vfr[slot][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (mt + 1 < MT) frags(mt + 1, (mt + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                sT[mt] = gT[mt] = sS[mt] = gS[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[mt & 1][ks], qf[ks], sT[mt], 0, 0, 0);
+                    sS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kfr[mt & 1][ks], sS[mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks) {
+                    gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt & 1][ks], gf[ks], gT[mt], 0, 0, 0);
+                    gS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ks], vfr[mt & 1][ks], gS[mt], 0, 0, 0);
+                }
             }
-            const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
-            for (int ks = 0; ks < DKS; ++ks) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
-                gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], gT[mt], 0, 0, 0);
-                gS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ks], vf, gS[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                sT[mt] = gT[mt] = sS[mt] = gS[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                    sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sT[mt], 0, 0, 0);
+                    sS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sS[mt], 0, 0, 0);
+                }
+                const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks) {
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+                    gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], gT[mt], 0, 0, 0);
+                    gS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[ks], vf, gS[mt], 0, 0, 0);
+                }
             }
         }
 
