@@ -488,7 +488,8 @@ typedef struct naf_forward_args {
      * library creates per device on first use (1x1 branch), forked by an event after the first convolutions and joined before
      * the attention; the call stays capturable -- and [2] / [7] bracket one 3x3 launch on the caller's stream (1x1 launches run
      * beside it), [3] is recorded behind one 1x1 launch on the second stream; [0], [1], [4], [5], [6] as before.  On 16 x 16
-     * pixel cells the key pooling rides on the last block layers (naf_stem_conv_keys_fwd), so [4] -> [5] is the value packing only. */
+     * pixel cells the key pooling rides on the last block layers (naf_stem_conv_keys_fwd) and the value packing runs on the second stream
+     * beside the first convolutions, so nothing is left between [4] and [5]. */
     void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);

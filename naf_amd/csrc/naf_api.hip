@@ -617,6 +617,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     };
     // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
     const bool rec[2] = {a->branch[0].conv0_ksize == 1 && a->branch[0].ksize == 1, a->branch[1].conv0_ksize == 1 && a->branch[1].ksize == 1};
+    bool values_packed = false;
     if (fwd_two_streams() && !sequential) {
         AuxStream* ax = fwd_aux_stream();
         NAF_REQUIRE(ax != nullptr, "naf_forward: cannot create the second stream");
@@ -632,6 +633,17 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         const int first = (a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1;   // the HBM-bound branch goes to the second stream
         void* pp[2][2] = {{ws + L.buf0, ws + L.buf1}, {ws + L.buf2, ws + L.buf3}};
         void* cur[2] = {nullptr, nullptr};
+        // the value packing depends on nothing but the features: it runs on the second stream beside the first convolutions (an
+        // event orders it behind whatever the caller queued before this call) instead of between the stem and the attention
+        if (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) {
+            naf_set_error("naf_forward: stream fork failed");
+            return NAF_ERR_LAUNCH;
+        }
+        {
+            const int prc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, static_cast<naf_stream_t>(ax->s));
+            if (prc != NAF_OK) return prc;
+            values_packed = true;
+        }
         for (int br = 0; br < 2; ++br) {
             cur[br] = rec[br] ? nullptr : pp[br][0];
             const int rc = run_conv0(br, cur[br]);
@@ -723,7 +735,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     for (int i = 0; i < 4; ++i) { rp.x_stride[i] = xs[i]; rp.q_stride[i] = L.fused ? 0 : qst[i]; rp.k_stride[i] = kst[i]; }
     int rc = keys_fused ? NAF_OK : naf_rope_pool_fwd(&rp, stream);
     if (rc != NAF_OK) return rc;
-    rc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, stream);
+    if (!values_packed) rc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, stream);
     if (rc != NAF_OK) return rc;
     naf_xna_args x;
     fwd_xna_args(a, &L, L.fused, &x);
