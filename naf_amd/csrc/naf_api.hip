@@ -644,13 +644,21 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
             if (prc != NAF_OK) return prc;
             values_packed = true;
         }
-        for (int br = 0; br < 2; ++br) {
+        // Both first convolutions on the caller's stream, the fork behind them.  Measured against the alternative (NAF_STEM_FORK_EARLY=1,
+        // A/B knob): each branch on one stream from its first convolution on, so that the 1x1 branch's statistics kernels and first
+        // layer run beside the 3x3 first convolution -- 1.923-1.927 ms against 1.907-1.909 per step (interleaved): the two
+        // write-heavy kernels slow each other down by more than the overlap brings.
+        static const bool fork_late = [] { const char* e = naf_knob("NAF_STEM_FORK_EARLY"); return !(e && atoi(e) != 0); }();
+        for (int k = 0; k < 2; ++k) {
+            const int br = k == 0 ? first : 1 - first;
+            lstream = (k == 0 && !fork_late) ? static_cast<naf_stream_t>(ax->s) : stream;
             cur[br] = rec[br] ? nullptr : pp[br][0];
             const int rc = run_conv0(br, cur[br]);
+            lstream = stream;
             if (rc != NAF_OK) return rc;
         }
-        if (!mark(1)) return NAF_ERR_LAUNCH;
-        if (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) {
+        if (!mark(1)) return NAF_ERR_LAUNCH;      // behind the caller's stream's first convolution(s)
+        if (fork_late && (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess)) {
             naf_set_error("naf_forward: stream fork failed");
             return NAF_ERR_LAUNCH;
         }
