@@ -33,12 +33,14 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 300 /* major*10000 + minor*100 + patch */
 /* Binary compatibility: the argument structs carry no size field, so a host must be BUILT against the header of the library it
  * loads whenever the minor version differs (compare naf_version() / 100 with NAF_HIP_VERSION / 100 at start-up, as
  * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
  * that zero-initialise the structs stay source-compatible; since 0.2.0 new capabilities arrive as new entry points with their
- * own structs (naf_stem_conv_keys_fwd / naf_key_pool_args) instead of growing existing ones. */
+ * own structs (naf_stem_conv_keys_fwd / naf_key_pool_args) instead of growing existing ones.  0.3.0 changed the LAYOUT of the
+ * GroupNorm-sum buffers of the stem entry points ([B][8][2] -> [NAF_STATS_SLOTS][B][8][2], see "guidance conv stem"): a 0.2.x
+ * host of those entries must be rebuilt and allocate the larger buffers; naf_forward and the attention entries are unchanged. */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -80,8 +82,12 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  * Replaces the reference's encoder() branches (convolutions.py:6-92, built at naf.py:26-27 with
  * hidden = dim/2 = 128 channels, GroupNorm(8), SiLU, reflect padding, no residual) for the default
  * width.  Activations are channels-last bf16 [B, H, W, 128]; GroupNorm statistics travel as fp64
- * {sum, sum of squares} per (batch, group) in `stats` buffers [B][8][2] that the CALLER zeroes
- * before the producing launch (hipMemsetAsync on the same stream).
+ * {sum, sum of squares} per (batch, group) in `stats` buffers [NAF_STATS_SLOTS][B][8][2] that the CALLER
+ * zeroes before the producing launch (hipMemsetAsync on the same stream): NAF_STATS_SLOTS partial copies -- a
+ * producing workgroup adds into copy (workgroup index mod NAF_STATS_SLOTS), a consumer adds the copies up; the sums
+ * of (b, g) are the sum over the first axis.  (One copy per image is one 128-byte line; device-scope atomics to one line
+ * are served one after another, and with a single copy the 4096 atomics of a 256-workgroup launch held its end back by
+ * 17-20 us: profiles/r04_stats_atomics.txt.)  Since 0.3.0; 0.2.x had one copy.
  *
  * naf_stem_conv0_fwd : Conv2d(3 -> 128, ksize 1 or 3, reflect) + bias         (convolutions.py:68-75)
  *   image device [B, 3, H, W] f32/bf16, element strides {b, c, y, x}; weight device f32 [128][3][k][k]
@@ -102,6 +108,9 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   128 channels only;
  *   stats_in then are the sums a naf_stem_conv0_fwd(y = NULL) call produced.  Given the same stats_in the results
  *   are bit-identical to the two-call sequence. */
+#ifndef NAF_STATS_SLOTS
+#define NAF_STATS_SLOTS 16 /* copies of every GroupNorm-sum buffer (part of the ABI: a library built with another value is another ABI) */
+#endif
 typedef struct naf_stem_conv0_args {
     const void* image;
     void* y;

@@ -410,7 +410,7 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     size_t off = 0;
     L.img = off;
     if (L.shrunk) off = align256(off + px * 3 * sizeof(float));
-    L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * a->B * 16 * sizeof(double));
+    L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * NAF_STATS_SLOTS * a->B * 16 * sizeof(double));
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
@@ -528,7 +528,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(a->workspace);
     double* stats = reinterpret_cast<double*>(ws + L.stats);
-    const size_t stat_stride = (size_t)a->B * 16;   // doubles per (branch, stage)
+    const size_t stat_stride = (size_t)NAF_STATS_SLOTS * a->B * 16;   // doubles per (branch, stage): [NAF_STATS_SLOTS][B][8][2]
     if (hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
         naf_set_error("naf_forward: hipMemsetAsync failed");
         return NAF_ERR_LAUNCH;

@@ -129,6 +129,22 @@ __device__ __forceinline__ float naf_rows_sum(float v) {
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
+// GroupNorm sums travel as fp64 {sum, sum of squares} in NAF_STATS_SLOTS copies [slot][B][8][2] (include/naf_hip.h): a producer's
+// workgroup adds into copy (workgroup index mod NAF_STATS_SLOTS), a consumer adds the copies up.  One copy of an image is one
+// 128-byte line, and device-scope atomics to one line are served one after another (~4.6 ns each, tools/stem_rows_fixed_probe.hip:
+// 256 workgroups x 16 atomics into ONE line held the end of every stem launch back by 17-20 us).
+__device__ __forceinline__ double* naf_gn_slot(double* stats, int B, int b, uint32_t wg) {
+    return stats + ((size_t)(wg % (uint32_t)NAF_STATS_SLOTS) * (size_t)B + (size_t)b) * 16;
+}
+__device__ __forceinline__ void naf_gn_sums(const double* stats, int B, int b, int g, double& s1, double& s2) {
+    typedef double f64x2_t __attribute__((ext_vector_type(2)));
+    f64x2_t acc = {0.0, 0.0};
+#pragma unroll
+    for (int sl = 0; sl < NAF_STATS_SLOTS; ++sl) acc += *reinterpret_cast<const f64x2_t*>(stats + ((size_t)sl * (size_t)B + (size_t)b) * 16 + g * 2);
+    s1 = acc[0];
+    s2 = acc[1];
+}
+
 // A/B tuning knobs (NAF_XNA_ORDER, NAF_XNA_STAGE, NAF_UNION_PLAN, ...) are measurement tools: they are honoured only when the
 // process also sets NAF_HIP_KNOBS=1, so that a stray environment variable cannot change kernel selection in production.
 inline const char* naf_knob(const char* name) {

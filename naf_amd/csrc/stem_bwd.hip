@@ -44,7 +44,8 @@ __device__ __forceinline__ void gn_vectors(const StemActParams& p, int b, float*
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         const int g = c / (p.C / GROUPS);
         const double n = (double)p.H * (double)p.W * (double)(p.C / GROUPS);
-        const double s1 = p.stats_in[(b * GROUPS + g) * 2 + 0], s2 = p.stats_in[(b * GROUPS + g) * 2 + 1];
+        double s1, s2;
+        naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
         var = var > 0.0 ? var : 0.0;

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             cvec[c] = p.bias ? p.bias[c] : 0.f;
         } else {
             const double n = (double)p.H * (double)p.W * 16.0;
-            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            double s1, s2;
+            naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
             const double mean = s1 / n;
             double var = s2 / n - mean * mean;
             var = var > 0.0 ? var : 0.0;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
         for (int i = 0; i < 8; ++i) g_c1_tim[(blockIdx.x * NW1 + wave) * 8 + i] = tacc[i];
 #endif
     if (p.stats_out) {
-        // wave sums -> one set of fp64 atomics per WORKGROUP (atomics on 16 addresses serialise in L2)
+        // wave sums -> one set of fp64 atomics per WORKGROUP, into the workgroup's copy of the sums (naf_gn_slot: atomics on one line serialise)
         __syncthreads();                      // every wave is done with its LDS tile
         float* red = reinterpret_cast<float*>(ot);   // [NW1 waves][16]
 #pragma unroll
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(NW1 * 64, (NW1 <= 4 ? 2 : 1)) void stem_conv1x1_ker
             float a = 0.f;
 #pragma unroll
             for (int wv = 0; wv < NW1; ++wv) a += red[wv * 16 + tid];
-            atomicAdd(&p.stats_out[(b * 8 + (tid & 7)) * 2 + (tid >> 3)], (double)a);
+            atomicAdd(&naf_gn_slot(p.stats_out, p.B, b, blockIdx.x)[(tid & 7) * 2 + (tid >> 3)], (double)a);
         }
     }
 }

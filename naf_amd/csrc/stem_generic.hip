@@ -40,7 +40,7 @@ struct StemGenParams {
 };
 
 // per-workgroup GroupNorm sums: per-channel partial sums in LDS -> 8 groups -> fp64 atomics
-__device__ __forceinline__ void publish_stats(float* s1c, float* s2c, int C, double* stats_out, int b) {
+__device__ __forceinline__ void publish_stats(float* s1c, float* s2c, int C, double* stats_out, int B, int b) {
     __syncthreads();
     const int cpg = C / 8;
     if (threadIdx.x < 16) {
@@ -48,7 +48,7 @@ __device__ __forceinline__ void publish_stats(float* s1c, float* s2c, int C, dou
         const float* src = which ? s2c : s1c;
         float a = 0.f;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += src[c];
-        atomicAdd(&stats_out[(b * 8 + g) * 2 + which], (double)a);
+        atomicAdd(&naf_gn_slot(stats_out, B, b, blockIdx.x)[g * 2 + which], (double)a);
     }
 }
 }  // namespace
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NWG * 64) void stem_conv0_generic_kernel(const Stem
             }
         }
     }
-    if (p.stats_out != nullptr) publish_stats(s1c, s2c, C, p.stats_out, b);
+    if (p.stats_out != nullptr) publish_stats(s1c, s2c, C, p.stats_out, p.B, b);
 }
 
 // ---- GroupNorm -> SiLU -> Conv2d(C -> C) --------------------------------------------------------------------------------
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParam
     for (int c = tid; c < C; c += NWG * 64) {
         const int g = c / cpg;
         const double n = (double)p.H * (double)p.W * (double)cpg;
-        const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+        double s1, s2;
+        naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParam
             }
         }
     }
-    if (p.stats_out != nullptr) publish_stats(s1c, s2c, C, p.stats_out, b);
+    if (p.stats_out != nullptr) publish_stats(s1c, s2c, C, p.stats_out, p.B, b);
 }
 
 static int check_channels(int C, const char* who) {

@@ -61,7 +61,8 @@ __device__ __forceinline__ int reflect(int i, int n) {
 }
 
 // ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue, 4 no
-// LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins, 128 cycle counter
+// LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins, 128 cycle counter,
+// 512 every weight fragment is the first one (one 16-byte load per lane instead of 72: what the weight fetch costs a launch)
 // PLAIN: no GroupNorm, no SiLU -- y = conv(x) (+ bias if given): the data gradient of a layer is this kernel on the output
 // gradient with the flipped, transposed weights (stats_in == NULL in the C ABI); the ring commit is then a copy.
 // POOL (naf_stem_conv_keys_fwd; the branch's LAST layer; whole strips, segments a multiple of 16 rows starting on a multiple of
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n32 = lane & 31, half = lane >> 5;
+    long long rt_in = 0;
+    if constexpr ((ABL & 1024) != 0) rt_in = (long long)__builtin_amdgcn_s_memrealtime();   // probe: 100 MHz wall clock at entry
     // Workgroup -> tile: consecutive workgroups land on different XCDs (blockIdx % 8), each with its own L2.  Strips that are
     // neighbours in x re-read 8 of each other's 40 pixel columns, so one XCD takes a run of consecutive tiles (a whole row band at
     // G1) instead of every eighth strip (round 3: 350 MB of L2 misses per launch for 268 MB of input).  -DNAF_ROWS_NO_XCD_RUNS: dispatch order.
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         } else {
             const int g = tid >> 4;  // 16 channels per group
             const double n = (double)p.H * (double)p.W * 16.0;
-            const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+            double s1, s2;
+            naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
             const double mean = s1 / n;
             double var = s2 / n - mean * mean;
             var = var > 0.0 ? var : 0.0;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16);
+                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + ((ABL & 512) ? (size_t)0 : (size_t)t * C * C + ks * 16));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     long long tm0 = 0;
     long long rt0 = 0;
     if constexpr ((ABL & 128) != 0) { tm0 = (long long)__builtin_readcyclecounter(); rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if constexpr ((ABL & 1024) != 0) rt0 = (long long)__builtin_amdgcn_s_memrealtime();
     if (!edge) {
         // Whole strip, rows a multiple of four: the last body stops after its first double-step (input rows R, R + 1 for R rows:
         // the last real output row R is complete then) and the epilogue of that row runs below without the two drain row-steps
@@ -525,6 +530,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
 #pragma unroll
         for (int n = 0; n < NLD; ++n) asm volatile("" ::"v"(ld_dummy[n]));
     }
+    long long rt1 = 0;
+    if constexpr ((ABL & 1024) != 0) rt1 = (long long)__builtin_amdgcn_s_memrealtime();
     if constexpr ((ABL & 128) != 0) {   // probe: shader cycles per double-step of this wave (stats_out + 64 .. are scratch there)
         const long long tm1 = (long long)__builtin_readcyclecounter();
         if (lane == 0 && blockIdx.x < 64) p.stats_out[64 + blockIdx.x * 4 + wave] = (double)(tm1 - tm0) / (edge ? 2.0 * nbody : 2.0 * nbody - 1.0);
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         }
     }
 
-    if (!POOL && p.stats_out) {
+    if (!POOL && !(ABL & 2048) && p.stats_out) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float a = s1p[g], q = s2p[g];
@@ -626,9 +633,17 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
                 q += __shfl_xor(q, o);
             }
             if (lane == 0) {
-                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 0], (double)a);
-                atomicAdd(&p.stats_out[(b * 8 + wave * 2 + g) * 2 + 1], (double)q);
+                double* so = naf_gn_slot(p.stats_out, p.B, b, blockIdx.x);
+                atomicAdd(&so[(wave * 2 + g) * 2 + 0], (double)a);
+                atomicAdd(&so[(wave * 2 + g) * 2 + 1], (double)q);
             }
+        }
+    }
+    if constexpr ((ABL & 1024) != 0) {   // probe: entry, loop start, loop end, exit (after the row stores have left) of wave 0
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        if (tid == 0 && blockIdx.x < 512) {
+            double* o = p.stats_out + 4096 + blockIdx.x * 4;
+            o[0] = (double)rt_in; o[1] = (double)rt0; o[2] = (double)rt1; o[3] = (double)(long long)__builtin_amdgcn_s_memrealtime();
         }
     }
 }

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const StemWgradParam
     if (ACT && tid < WC) {
         const int g = tid >> 4;
         const double n = (double)p.H * (double)p.W * 16.0;
-        const double s1 = p.stats_in[(b * 8 + g) * 2 + 0], s2 = p.stats_in[(b * 8 + g) * 2 + 1];
+        double s1, s2;
+        naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
         var = var > 0.0 ? var : 0.0;

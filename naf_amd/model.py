@@ -207,7 +207,7 @@ class _HipStem(torch.autograd.Function):
         branches = (enc.encoder, enc.sem_encoder)
         hid = 128
         nlayer = len(_stem_layers(enc.encoder))
-        stats = torch.zeros((2, nlayer + 1, B, 8, 2), dtype=torch.float64, device=dev)
+        stats = ops.new_stats(B, dev, lead=(2, nlayer + 1))
         cat = torch.empty((B, H, W, 2 * hid), dtype=torch.bfloat16, device=dev)
         img = image.detach()
         if img.dtype not in (torch.float32, torch.bfloat16):
@@ -403,7 +403,7 @@ class ImageEncoder(nn.Module):
         branches = (self.encoder, self.sem_encoder)
         hid = self.encoder[0].out_channels
         nstage = 1 + 2 * (len(self.encoder) - 1)
-        stats = torch.zeros((2, nstage, B, 8, 2), dtype=torch.float64, device=dev)      # one memset for all sums
+        stats = ops.new_stats(B, dev, lead=(2, nstage))      # one memset for all sums
         cat = torch.empty((B, H, W, 2 * hid), dtype=torch.bfloat16, device=dev)
         bufs = [torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev) for _ in range(2)]
         for br, seq in enumerate(branches):

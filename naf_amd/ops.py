@@ -84,6 +84,36 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+STATS_SLOTS = 16   # NAF_STATS_SLOTS of include/naf_hip.h: partial copies of every GroupNorm-sum buffer
+
+
+def new_stats(B: int, device, lead: Tuple[int, ...] = ()) -> torch.Tensor:
+    """Zeroed GroupNorm-sum buffer(s) ``[*lead, STATS_SLOTS, B, 8, 2]`` (f64): a producing workgroup adds into one of the
+    ``STATS_SLOTS`` copies, consumers add them up (include/naf_hip.h, "guidance conv stem")."""
+    return torch.zeros((*lead, STATS_SLOTS, B, 8, 2), dtype=torch.float64, device=device)
+
+
+def stats_total(stats: torch.Tensor) -> torch.Tensor:
+    """``[..., STATS_SLOTS, B, 8, 2]`` -> the sums ``[..., B, 8, 2]``."""
+    return stats.sum(dim=-4)
+
+
+def stats_from_total(total: torch.Tensor) -> torch.Tensor:
+    """Sums ``[B, 8, 2]`` (e.g. computed by torch) as a buffer the stem entries read: copy 0 holds them, the rest is zero."""
+    st = new_stats(total.shape[0], total.device)
+    st[0] = total
+    return st
+
+
+def _stats_ptr(t: Optional[torch.Tensor], B: int, what: str):
+    if t is None:
+        return None
+    if tuple(t.shape) != (STATS_SLOTS, B, 8, 2) or t.dtype != torch.float64 or not t.is_contiguous():
+        raise ValueError(f"{what}: GroupNorm sums must be a contiguous f64 [{STATS_SLOTS}, {B}, 8, 2] tensor (ops.new_stats), "
+                         f"got {tuple(t.shape)} {t.dtype}")
+    return t.data_ptr()
+
+
 def _fill_stem_conv0(image, weight, bias, y, stats_out) -> StemConv0Args:
     B, Cin, H, W = image.shape
     Cout = int(weight.shape[0])
@@ -94,7 +124,7 @@ def _fill_stem_conv0(image, weight, bias, y, stats_out) -> StemConv0Args:
     a.channels = Cout
     a.image, a.weight, a.bias = image.data_ptr(), weight.data_ptr(), bias.data_ptr()
     a.y = y.data_ptr() if y is not None else None
-    a.stats_out = stats_out.data_ptr() if stats_out is not None else None
+    a.stats_out = _stats_ptr(stats_out, B, "stem_conv0")
     a.image_dtype, a.ksize, a.B, a.H, a.W = _DT[image.dtype], int(weight.shape[-1]), B, H, W
     a.image_stride = _strides4(image, (0, 1, 2, 3))
     a.y_stride = I64x3(int(y.stride(0)), int(y.stride(1)), int(y.stride(2))) if y is not None else I64x3(0, 0, 0)
@@ -105,7 +135,7 @@ def stem_conv0(image: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, y:
                stats_out: torch.Tensor) -> None:
     """Conv2d(3 -> 128, k in {1, 3}, reflect) + bias.  image [B,3,H,W] f32/bf16 (any strides); weight f32
     [128,3,k,k]; y: bf16 [B,H,W,128] view (128 channels contiguous) or None (statistics only);
-    stats_out f64 [B,8,2], pre-zeroed."""
+    stats_out: ``new_stats(B, device)`` (f64 [STATS_SLOTS,B,8,2], zeroed)."""
     _gpu(image, "image")
     lib = _lib.load()
     if image.dtype not in _DT:
@@ -120,7 +150,7 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
               w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor],
               first=None, keys=None) -> None:
     """GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, k in {1,3}, reflect) + bias on bf16 [B,H,W,128] views.
-    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats f64 [B,8,2] (stats_out pre-zeroed or None).
+    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats: f64 [STATS_SLOTS,B,8,2] buffers of ``new_stats`` (stats_out zeroed, or None).
     ``first=(image, conv0_weight, conv0_bias)`` (1x1 layers only, ``x=None``): the input is bf16(conv0(image))
     recomputed on the fly; ``stats_in`` then come from ``stem_conv0(..., y=None, ...)``.
     ``keys=(k_slice, tab_y, tab_x)`` (a branch's LAST layer, ``stats_out=None``): ``naf_stem_conv_keys_fwd`` -- the layer also
@@ -146,8 +176,8 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
     a.x, a.y, a.w_packed, a.bias = (None if first is not None else x.data_ptr()), y.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
     if f0 is not None:
         a.first = C.pointer(f0)
-    a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
-    a.stats_out = stats_out.data_ptr() if stats_out is not None else None
+    a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_conv")
+    a.stats_out = _stats_ptr(stats_out, B, "stem_conv")
     a.ksize = {1: 1, 9: 3}[int(taps)]
     a.channels = Cc
     a.B, a.H, a.W, a.eps = B, H, W, float(eps)
@@ -210,7 +240,7 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
     B, H, W, Cc = x.shape
     out = torch.empty((B, H + 2 * pad, W + 2 * pad, Cc), dtype=torch.bfloat16, device=x.device)
     a = _lib.StemActArgs()
-    a.x, a.a, a.gn_weight, a.gn_bias, a.stats_in = x.data_ptr(), out.data_ptr(), gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+    a.x, a.a, a.gn_weight, a.gn_bias, a.stats_in = x.data_ptr(), out.data_ptr(), gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_act")
     a.B, a.H, a.W, a.channels, a.pad, a.eps = B, H, W, Cc, int(pad), float(eps)
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
     a.a_stride = I64x3(int(out.stride(0)), int(out.stride(1)), int(out.stride(2)))
@@ -237,7 +267,7 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tenso
     a.dy, a.x, a.dw = dy.data_ptr(), x.data_ptr(), dw.data_ptr()
     a.db = db.data_ptr() if with_bias else None
     if stats_in is not None:
-        a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr()
+        a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_wgrad")
     else:
         a.gn_weight = a.gn_bias = a.stats_in = None
     a.ksize, a.B, a.H, a.W, a.eps = int(ksize), B, H, W, float(eps)
@@ -285,7 +315,7 @@ def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_w
     sums = torch.zeros((B, Cc, 2), dtype=torch.float64, device=x.device)
     a = _lib.StemActBwdArgs()
     a.da, a.x, a.dx = da.data_ptr(), x.data_ptr(), dx.data_ptr()
-    a.gn_weight, a.gn_bias, a.stats_in, a.sums = gn_weight.data_ptr(), gn_bias.data_ptr(), stats_in.data_ptr(), sums.data_ptr()
+    a.gn_weight, a.gn_bias, a.stats_in, a.sums = gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_act_bwd"), sums.data_ptr()
     a.B, a.H, a.W, a.channels, a.fold, a.phase, a.eps = B, H, W, Cc, int(bool(fold)), 0, float(eps)
     a.da_stride = I64x3(int(da.stride(0)), int(da.stride(1)), int(da.stride(2)))
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))

@@ -385,9 +385,9 @@ def test_stem_of_any_width_runs_on_hip_and_matches_the_oracle(dev, dim, shape):
         w, bias = p[f"{pre}.conv1.weight"], p[f"{pre}.conv1.bias"]
         gw, gb = p[f"{pre}.norm1.weight"], p[f"{pre}.norm1.bias"]
         xf = x.float()
-        st = torch.stack([xf.double().view(B, 8, -1).sum(-1), (xf.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1).to(dev)
+        st = ops.stats_from_total(torch.stack([xf.double().view(B, 8, -1).sum(-1), (xf.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1).to(dev))
         y = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
-        st_out = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+        st_out = ops.new_stats(B, dev)
         wp = w.permute(2, 3, 0, 1).reshape(ks * ks, hid, hid).contiguous().to(torch.bfloat16).to(dev)
         ops.stem_conv(xd, st, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
         a = F.silu(F.group_norm(xf, 8, gw, gb, eps=1e-5)).to(torch.bfloat16).float()
@@ -397,7 +397,7 @@ def test_stem_of_any_width_runs_on_hip_and_matches_the_oracle(dev, dim, shape):
         g1 = y.permute(0, 3, 1, 2).float().cpu()
         _assert_close(g1, r, 3e-2, 1.6e-2, f"dim {dim} layer k{ks}")
         rs = torch.stack([r.double().view(B, 8, -1).sum(-1), (r.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1)
-        assert torch.allclose(st_out.cpu(), rs, rtol=2e-3, atol=0.5)
+        assert torch.allclose(ops.stats_total(st_out).cpu(), rs, rtol=2e-3, atol=0.5)
 
 
 def test_denoising_configuration_runs_entirely_on_hip(dev):

@@ -29,7 +29,8 @@ def _layer_inputs(dev, B, H, W, ks, seed):
     gw, gb = 1.0 + O.hash_normal((128,), seed + 3, 0.1), O.hash_normal((128,), seed + 4, 0.1)
     xd = x.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
     g = x.double().view(B, 8, 16, H, W)
-    st_in = torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev)
+    from naf_amd import ops
+    st_in = ops.stats_from_total(torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev))
     wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
     return xd, st_in, gw.to(dev), gb.to(dev), wp, bias.to(dev)
 

@@ -144,13 +144,13 @@ def test_stem_conv0(dev, ks, shape):
     bias = O.hash_normal((128,), 63, 0.1)
     ref = F.conv2d(F.pad(img, (ks // 2,) * 4, mode="reflect") if ks == 3 else img, w, bias)
     y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
-    st = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+    st = ops.new_stats(B, dev)
     ops.stem_conv0(img.to(dev), w.to(dev), bias.to(dev), y, st)
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert_close(got, ref, 1e-5, 2 ** -8, f"conv0 k={ks}")
     g = ref.double().view(B, 8, 16, H, W)
-    assert torch.allclose(st[..., 0].cpu(), g.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(st[..., 1].cpu(), (g * g).sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(ops.stats_total(st)[..., 0].cpu(), g.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(ops.stats_total(st)[..., 1].cpu(), (g * g).sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("ks", [1, 3])
@@ -169,8 +169,8 @@ def test_stem_conv_layer(dev, ks, shape):
     ref = F.conv2d(F.pad(a, (ks // 2,) * 4, mode="reflect") if ks == 3 else a, w, bias)
     xd = x.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
     g = x.double().view(B, 8, 16, H, W)
-    st_in = torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev)
-    st_out = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+    st_in = ops.stats_from_total(torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev))
+    st_out = ops.new_stats(B, dev)
     y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
     wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
     ops.stem_conv(xd, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
@@ -178,8 +178,8 @@ def test_stem_conv_layer(dev, ks, shape):
     assert_close(got, ref, 2e-2, 1e-2, f"stem conv k={ks} {shape}")     # bf16 rounding of SiLU(GN(x)) at |x| ~ boundary
     assert float((got - ref).abs().mean()) <= 2e-3
     gr = ref.double().view(B, 8, 16, H, W)
-    assert torch.allclose(st_out[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
-    assert torch.allclose(st_out[..., 1].cpu(), (gr * gr).sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+    assert torch.allclose(ops.stats_total(st_out)[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+    assert torch.allclose(ops.stats_total(st_out)[..., 1].cpu(), (gr * gr).sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
 
 
 def test_stem_layers_fuzz_small_and_odd_sizes(dev):
@@ -197,11 +197,11 @@ def test_stem_layers_fuzz_small_and_odd_sizes(dev):
             b0 = O.hash_normal((128,), 63, 0.1)
             ref0 = F.conv2d(F.pad(img, (1,) * 4, mode="reflect") if ks == 3 else img, w0, b0)
             y0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
-            st0 = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+            st0 = ops.new_stats(B, dev)
             ops.stem_conv0(img.to(dev), w0.to(dev), b0.to(dev), y0, st0)
             assert_close(y0.float().cpu().permute(0, 3, 1, 2), ref0, 1e-5, 2 ** -8, f"conv0 k={ks} {B}x{H}x{W}")
             g0 = ref0.double().view(B, 8, 16, H, W)
-            assert torch.allclose(st0[..., 0].cpu(), g0.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+            assert torch.allclose(ops.stats_total(st0)[..., 0].cpu(), g0.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
             # the layer on top of it
             x = bf16r(ref0)
             w = bf16r(O.hash_normal((128, 128, ks, ks), 72, 1.0 / (11.3 * ks)))
@@ -210,15 +210,15 @@ def test_stem_layers_fuzz_small_and_odd_sizes(dev):
             a = bf16r(F.silu(F.group_norm(x, 8, gw, gb, 1e-5)))
             ref = F.conv2d(F.pad(a, (1,) * 4, mode="reflect") if ks == 3 else a, w, bias)
             gx = x.double().view(B, 8, 16, H, W)
-            st_in = torch.stack([gx.sum(dim=(2, 3, 4)), (gx * gx).sum(dim=(2, 3, 4))], dim=-1).to(dev)
-            st_out = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+            st_in = ops.stats_from_total(torch.stack([gx.sum(dim=(2, 3, 4)), (gx * gx).sum(dim=(2, 3, 4))], dim=-1).to(dev))
+            st_out = ops.new_stats(B, dev)
             y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
             wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
             ops.stem_conv(y0, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
             got = y.float().cpu().permute(0, 3, 1, 2)
             assert_close(got, ref, 3e-2, 1.5e-2, f"stem conv k={ks} {B}x{H}x{W}")
             gr = ref.double().view(B, 8, 16, H, W)
-            assert torch.allclose(st_out[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
+            assert torch.allclose(ops.stats_total(st_out)[..., 0].cpu(), gr.sum(dim=(2, 3, 4)), rtol=2e-3, atol=0.5)
 
 
 @pytest.mark.parametrize("shape", [(1, 20, 24), (2, 45, 67), (1, 160, 64)])
@@ -994,15 +994,17 @@ def test_first_1x1_layer_recomputes_conv0_bit_exactly(dev, shape, fmt):
     wp = (O.hash_normal((1, 128, 128), 606) * 0.09).to(torch.bfloat16).to(dev)
     cb = (O.hash_normal((128,), 607) * 0.1).to(dev)
     x0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
-    st = torch.zeros((4, B, 8, 2), dtype=torch.float64, device=dev)
+    st = ops.new_stats(B, dev, lead=(4,))
     ops.stem_conv0(img, w0, b0, x0, st[0])
     ops.stem_conv0(img, w0, b0, None, st[1])        # statistics only: from the image's moments (fp64), no matrix work
-    assert torch.allclose(st[0], st[1], rtol=2e-6, atol=1e-3), float((st[0] - st[1]).abs().max())
+    t0, t1 = ops.stats_total(st[0]), ops.stats_total(st[1])
+    assert torch.allclose(t0, t1, rtol=2e-6, atol=1e-3), float((t0 - t1).abs().max())
+    assert float(st[1][1:].abs().max()) == 0.0      # the moments' copies are cleared: copy 0 holds the sums
     ya, yb = torch.empty_like(x0), torch.empty_like(x0)
     ops.stem_conv(x0, st[0], gw, gb, 1e-5, wp, cb, ya, st[2])
     ops.stem_conv(None, st[0], gw, gb, 1e-5, wp, cb, yb, st[3], first=(img, w0, b0))     # same statistics: same bits
     assert torch.equal(ya, yb), float((ya.float() - yb.float()).abs().max())
-    assert torch.allclose(st[2], st[3], rtol=1e-12, atol=1e-9)
+    assert torch.allclose(ops.stats_total(st[2]), ops.stats_total(st[3]), rtol=1e-12, atol=1e-9)
     yc = torch.empty_like(x0)
     ops.stem_conv(None, st[1], gw, gb, 1e-5, wp, cb, yc, torch.zeros_like(st[3]), first=(img, w0, b0))
     assert float((ya.float() - yc.float()).abs().max()) <= 2.0 ** -6     # moments-based statistics: at most a bf16 ulp apart
@@ -1212,7 +1214,7 @@ def test_generic_conv0_statistics_and_null_check(dev):
         w = O.hash_normal((Cc, 3, ks, ks), 822 + ks).to(dev).contiguous()
         b = O.hash_normal((Cc,), 824).to(dev)
         y = torch.empty((B, H, W, Cc), dtype=torch.bfloat16, device=dev)
-        st = torch.zeros((B, 8, 2), dtype=torch.float64, device=dev)
+        st = ops.new_stats(B, dev)
         with pytest.raises(ValueError, match="NULL pointer"):
             ops.stem_conv0(img, w, b, y, None)
         ops.stem_conv0(img, w, b, y, st)
@@ -1221,7 +1223,7 @@ def test_generic_conv0_statistics_and_null_check(dev):
         r = F.conv2d(x.double(), w.double(), b.double()).float().cpu()        # [B, Cc, H, W]
         assert_close(y.float().permute(0, 3, 1, 2).cpu(), r, 1e-5, 2.0 ** -7, f"conv0 k{ks}")
         rs = torch.stack([r.double().view(B, 8, -1).sum(-1), (r.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1)
-        assert torch.allclose(st.cpu(), rs, rtol=1e-4, atol=1e-2)
+        assert torch.allclose(ops.stats_total(st).cpu(), rs, rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize("img_hw,lr,C,ksz", [

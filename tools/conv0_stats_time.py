@@ -4,7 +4,7 @@ from naf_amd import ops
 dev = torch.device("cuda:0")
 for S in (1024, 448):
     img = torch.rand(1, 3, S, S, device=dev); w0 = torch.randn(128, 3, 1, 1, device=dev) * 0.2; b0 = torch.randn(128, device=dev) * 0.1
-    st = torch.zeros(1, 8, 2, dtype=torch.float64, device=dev)
+    st = ops.new_stats(1, dev)
     def f():
         st.zero_(); ops.stem_conv0(img, w0, b0, None, st)
     for _ in range(3): f()

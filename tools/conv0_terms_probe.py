@@ -6,7 +6,7 @@ img = torch.randn(1, 3, 1024, 1024, device=dev)
 w = torch.randn(128, 3, 3, 3, device=dev) * 0.2
 b = torch.randn(128, device=dev)
 y = torch.empty(1, 1024, 1024, 128, dtype=torch.bfloat16, device=dev)
-st = torch.zeros(1, 8, 2, dtype=torch.float64, device=dev)
+st = ops.new_stats(1, dev)
 for _ in range(3): ops.stem_conv0(img, w, b, y, st)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()

@@ -14,8 +14,8 @@ def main():
         k = 1 if which == "c1" else 3
         y0 = (torch.randn(1, H, W, 128, device=dev)).to(torch.bfloat16)
         y1 = torch.empty_like(y0)
-        st = torch.zeros(2, 1, 8, 2, dtype=torch.float64, device=dev)
-        st[0, :, :, 1] = H * W * 16.0
+        st = ops.new_stats(1, dev, lead=(2,))
+        st[0, 0, :, :, 1] = H * W * 16.0
         gw, gb, bias = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.zeros(128, device=dev)
         wp = (torch.randn(k * k, 128, 128, device=dev) * (0.05 / k)).to(torch.bfloat16)
         fn = lambda: ops.stem_conv(y0, st[0], gw, gb, 1e-5, wp, bias, y1, st[1])

@@ -20,7 +20,7 @@ def main():
     torch.manual_seed(0)
     x = torch.randn(B, H, W, 128, device=dev).to(torch.bfloat16)
     g = x.float().double().view(B, H * W, 8, 16)
-    st = torch.stack([g.sum(dim=(1, 3)), (g * g).sum(dim=(1, 3))], dim=-1).contiguous()
+    st = ops.stats_from_total(torch.stack([g.sum(dim=(1, 3)), (g * g).sum(dim=(1, 3))], dim=-1).contiguous())
     cat = torch.empty(B, H, W, 256, dtype=torch.bfloat16, device=dev)
     keys = torch.empty(B, H // 16, W // 16, 256, dtype=torch.bfloat16, device=dev)
     gw, gb, bias = torch.ones(128, device=dev), torch.zeros(128, device=dev), torch.zeros(128, device=dev)

@@ -31,7 +31,7 @@ def main():
     print(f"{'branch':8s} {'layer':6s} | {'total mean':>10s} {'total max':>10s} {'rel rms':>8s} | {'layer mean':>10s} {'layer max':>10s} {'rel rms':>8s} | {'out rms':>8s}")
     for br, (seq, pre) in enumerate(((enc.encoder, "image_encoder.encoder"), (enc.sem_encoder, "image_encoder.sem_encoder"))):
         ks = seq[0].kernel_size[0]
-        stats = torch.zeros((5, 1, 8, 2), dtype=torch.float64, device=dev)
+        stats = ops.new_stats(1, dev, lead=(5,))
         bufs = [torch.empty((1, S, S, 128), dtype=torch.bfloat16, device=dev) for _ in range(2)]
         w0, b0 = seq[0].weight.detach().float().contiguous(), seq[0].bias.detach().float()
         ops.stem_conv0(imgd, w0, b0, bufs[0], stats[0])

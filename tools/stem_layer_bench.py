@@ -21,7 +21,7 @@ def main():
     img = torch.rand(B, 3, H, W, device=dev)
     y0 = torch.empty(B, H, W, 128, dtype=torch.bfloat16, device=dev)
     y1 = torch.empty_like(y0)
-    st = torch.zeros(4, B, 8, 2, dtype=torch.float64, device=dev)
+    st = ops.new_stats(B, dev, lead=(4,))
     gw, gb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
     bias = torch.zeros(128, device=dev)
     for k in (1, 3):

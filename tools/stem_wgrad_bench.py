@@ -7,7 +7,7 @@ for H in (448, 1024):
     x = torch.randn(1, H, H, 128, device=dev).to(torch.bfloat16)
     dy = torch.randn(1, H, H, 128, device=dev).to(torch.bfloat16)
     xd = x.double().reshape(1, -1, 8, 16)
-    st = torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1).contiguous()
+    st = ops.stats_from_total(torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1).contiguous())
     gw, gb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
     for k in (3, 1):
         for _ in range(3):
