@@ -34,6 +34,26 @@ def test_library_builds_and_exports_every_declared_symbol(built_lib):
     assert lib.naf_version() >= 100
 
 
+def test_groupnorm_sum_copies_match_header_and_version(built_lib):
+    """The number of partial copies of the GroupNorm-sum buffers is part of the ABI (0.3.0): header, Python host and the
+    version the library reports agree; the host-side helpers keep the [copies, B, 8, 2] layout."""
+    from naf_amd import ops
+    txt = open(os.path.join(ROOT, "include", "naf_hip.h")).read()
+    slots = int(re.search(r"#define\s+NAF_STATS_SLOTS\s+(\d+)", txt).group(1))
+    version = int(re.search(r"#define\s+NAF_HIP_VERSION\s+(\d+)", txt).group(1))
+    assert slots == ops.STATS_SLOTS == 16 and version >= 300
+    lib = C.CDLL(built_lib)
+    lib.naf_version.restype = C.c_int
+    assert lib.naf_version() == version
+    st = ops.new_stats(3, "cpu", lead=(2,))
+    assert tuple(st.shape) == (2, slots, 3, 8, 2) and st.dtype == torch.float64 and float(st.abs().sum()) == 0.0
+    tot = torch.arange(3 * 8 * 2, dtype=torch.float64).view(3, 8, 2)
+    buf = ops.stats_from_total(tot)
+    assert tuple(buf.shape) == (slots, 3, 8, 2) and torch.equal(ops.stats_total(buf), tot) and float(buf[1:].abs().sum()) == 0.0
+    with pytest.raises(ValueError, match="GroupNorm sums"):
+        ops._stats_ptr(tot, 3, "test")          # a 0.2.x-shaped buffer is refused before any launch
+
+
 def test_struct_layout_matches_header(built_lib):
     """sizeof of the ctypes mirrors == the C structs (checked through a tiny C probe compiled with gcc)."""
     import subprocess, tempfile
