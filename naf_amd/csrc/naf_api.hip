@@ -651,7 +651,10 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         static const bool fork_late = [] { const char* e = naf_knob("NAF_STEM_FORK_EARLY"); return !(e && atoi(e) != 0); }();
         for (int k = 0; k < 2; ++k) {
             const int br = k == 0 ? first : 1 - first;
-            lstream = (k == 0 && !fork_late) ? static_cast<naf_stream_t>(ax->s) : stream;
+            // Not even the statistics-only first convolution (the image's moments: two small kernels, 18 us) gains from the second
+            // stream (NAF_STEM_MOMENTS_AUX=1, A/B knob): G1 1.924-1.925 against 1.904-1.907 ms, G2 the same (profiles/r04_negative_results.txt)
+            static const bool moments_aux = [] { const char* e = naf_knob("NAF_STEM_MOMENTS_AUX"); return e && atoi(e) != 0; }();
+            lstream = (k == 0 && (!fork_late || (rec[br] && moments_aux))) ? static_cast<naf_stream_t>(ax->s) : stream;
             cur[br] = rec[br] ? nullptr : pp[br][0];
             const int rc = run_conv0(br, cur[br]);
             lstream = stream;
@@ -665,7 +668,10 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         for (int l = 0; l < a->nlayer; ++l)
             for (int k = 0; k < 2; ++k) {
                 const int br = k == 0 ? first : 1 - first;
-                lstream = k == 0 ? static_cast<naf_stream_t>(ax->s) : stream;
+                // A/B knob: the 1x1 branch on the caller's stream, the 3x3 branch on the second one (so that the stem ends on the caller's
+                // stream and the attention kernel does not wait for a cross-queue signal): G1 +0.3 %, G2 -1 % -- not adopted
+                static const bool swap_streams = [] { const char* e = naf_knob("NAF_STEM_SWAP"); return e && atoi(e) != 0; }();
+                lstream = ((k == 0) != swap_streams) ? static_cast<naf_stream_t>(ax->s) : stream;
                 void* y = (l == a->nlayer - 1) ? nullptr : pp[br][cur[br] == pp[br][0] ? 1 : 0];
                 if (l == timed && k == 1 && !mark_on(2, s)) return NAF_ERR_LAUNCH;
                 const int rc = run_layer(br, l, cur[br], y);
