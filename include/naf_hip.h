@@ -39,8 +39,9 @@ extern "C" {
  * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
  * that zero-initialise the structs stay source-compatible; since 0.2.0 new capabilities arrive as new entry points with their
  * own structs (naf_stem_conv_keys_fwd / naf_key_pool_args) instead of growing existing ones.  0.3.0 changed the LAYOUT of the
- * GroupNorm-sum buffers of the stem entry points ([B][8][2] -> [NAF_STATS_SLOTS][B][8][2], see "guidance conv stem"): a 0.2.x
- * host of those entries must be rebuilt and allocate the larger buffers; naf_forward and the attention entries are unchanged. */
+ * GroupNorm-sum buffers of the stem entry points ([B][8][2] -> [NAF_STATS_SLOTS][B][8][2], see "guidance conv stem") and the order
+ * of w_packed for the 3x3 layers of the default width (naf_stem_weight_index; also naf_stem_branch.conv_weight_packed of naf_forward):
+ * a 0.2.x host must be rebuilt, allocate the larger buffers and repack those weights; the attention entries are unchanged. */
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -100,8 +101,12 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   the default model, any other multiple of 16 up to 256 the general kernels of stem_generic.hip; "128" below reads C.
  * naf_stem_conv_fwd  : GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, ksize 1 or 3, reflect) + bias
  *   (one norm/act/conv triple of EncBlock.forward, convolutions.py:52-61).  x device bf16 with its
- *   stats_in; gn_weight/gn_bias f32 [128]; w_packed device bf16 [k*k][128 oc][128 ic]
- *   (= weight.permute(2,3,0,1)); y / stats_out as above (stats_out may be NULL).
+ *   stats_in; gn_weight/gn_bias f32 [128]; w_packed device bf16, k*k*C*C elements, element (tap, oc, ic) at
+ *   naf_stem_weight_index(ksize, C, tap, oc, ic): [k*k][C oc][C ic] (= weight.permute(2,3,0,1)) except for the 3x3 layers of
+ *   the default width (ksize 3, C = 128; since 0.3.0), whose kernel keeps all 288 KB of weights in registers and wants them in the
+ *   order its lanes hold them -- [9 taps][4 blocks of 32 oc][8 steps of 16 ic][2 halves of 8 ic][32 oc][8 ic], every load
+ *   instruction of a wave one contiguous KB (the [oc][ic] order cost each launch 4.7 us more, profiles/r04_stats_atomics.txt);
+ *   y / stats_out as above (stats_out may be NULL).
  *   `first` (optional, ksize 1 only): the layer is the FIRST residual-block convolution of the 1x1 branch and
  *   recomputes its input bf16(conv0(image)) from `first` (image, weight, bias of the 1x1 conv0; first->y and
  *   first->stats_out are ignored) instead of reading x, so that the conv0 activation never exists in memory;
@@ -144,9 +149,12 @@ typedef struct naf_stem_conv_args {
     const naf_stem_conv0_args* first; /* optional, see above */
 } naf_stem_conv_args;
 int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream);
+/* Index of element (tap = ty * ksize + tx, oc, ic) in w_packed for a layer of `channels` channels (host function, no device
+ * work; -1 for arguments out of range).  0.3.0. */
+int64_t naf_stem_weight_index(int32_t ksize, int32_t channels, int32_t tap, int32_t oc, int32_t ic);
 /* Plain mode: stats_in == gn_weight == gn_bias == NULL (bias may be NULL too) -> y = conv(x) (+ bias), no GroupNorm, no SiLU,
  * 128 channels.  It is the DATA GRADIENT of a layer (the backward train.py:127-137 needs): x = the gradient of the layer's
- * output, w_packed = the flipped, transposed weights [k*k][128 ic][128 oc] (= weight.flip(2,3).permute(2,3,1,0)).  For the
+ * output, w_packed = the flipped, transposed weights (those of Conv2d with weight.flip(2,3).transpose(0,1), packed as above).  For the
  * 3x3 layers (reflect padding) run it over the output gradient embedded in a 2-pixel ZERO border ((H+4) x (W+4)): rows /
  * columns 1 .. H+2 of the result are the gradient on the padded domain, whose border naf_stem_act_bwd(fold) folds back. */
 

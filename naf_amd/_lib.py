@@ -148,6 +148,7 @@ SIGNATURES = {
     "naf_version": (C.c_int, []),
     "naf_last_error": (C.c_char_p, []),
     "naf_axis_index_table": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
+    "naf_stem_weight_index": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "naf_axis_index_table_device": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "naf_stem_conv0_fwd": (C.c_int, [C.POINTER(StemConv0Args), C.c_void_p]),
     "naf_stem_conv_fwd": (C.c_int, [C.POINTER(StemConvArgs), C.c_void_p]),

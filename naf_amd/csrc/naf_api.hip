@@ -42,6 +42,14 @@ int naf_cu_count() {
 extern "C" {
 
 int naf_version(void) { return NAF_HIP_VERSION; }
+
+int64_t naf_stem_weight_index(int32_t ksize, int32_t channels, int32_t tap, int32_t oc, int32_t ic) {
+    const int C_ = channels == 0 ? 128 : channels;
+    if ((ksize != 1 && ksize != 3) || C_ % 16 != 0 || C_ < 16 || C_ > 256 || tap < 0 || tap >= ksize * ksize || oc < 0 || oc >= C_ || ic < 0 || ic >= C_) return -1;
+    if (ksize == 3 && C_ == 128)   // register order of stem_conv_rows_kernel: wave = oc / 32, k-step = ic / 16, lane = 32 * ((ic / 8) & 1) + oc % 32
+        return ((((int64_t)(tap * 4 + oc / 32) * 8 + ic / 16) * 2 + ((ic / 8) & 1)) * 32 + oc % 32) * 8 + ic % 8;
+    return ((int64_t)tap * C_ + oc) * C_ + ic;
+}
 const char* naf_last_error(void) { return g_err; }
 
 static int axis_table_validate(const void* out, int32_t L_out, int32_t L_in, int32_t k) {

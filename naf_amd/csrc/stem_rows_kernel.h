@@ -62,7 +62,8 @@ __device__ __forceinline__ int reflect(int i, int n) {
 
 // ABL: ablation bits for tools/stem_probe.hip only (library: 0).  1 no ring commit (GroupNorm+SiLU), 2 no epilogue, 4 no
 // LDS B-fragment reads, 8 no row stores, 16 no global loads, 32 no barrier, 64 no per-slot scheduling pins, 128 cycle counter,
-// 512 every weight fragment is the first one (one 16-byte load per lane instead of 72: what the weight fetch costs a launch)
+// 512 every weight fragment is the first one (one 16-byte load per lane instead of 72: what the weight fetch costs a launch),
+// 1024 wall-clock stamps, 2048 no GroupNorm-sum atomics, 4096 weights read in [tap][oc][ic] order (rounds 1-4.0: 32 lines per load instruction instead of 8)
 // PLAIN: no GroupNorm, no SiLU -- y = conv(x) (+ bias if given): the data gradient of a layer is this kernel on the output
 // gradient with the flipped, transposed weights (stats_in == NULL in the C ABI); the ring commit is then a copy.
 // POOL (naf_stem_conv_keys_fwd; the branch's LAST layer; whole strips, segments a multiple of 16 rows starting on a multiple of
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         ld1[n] = *reinterpret_cast<const u32x4_t*>(xbu + (int64_t)reflect(sy - 1 + 2 + rr, p.H) * p.xs[1] * 2 + col_off[n]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic.  Requested behind
+    // ---- weights -> registers (A fragments): lane (oc = 32*wave + n32, kg = half) holds 8 consecutive ic; w_packed is in exactly that
+    // order (naf_stem_weight_index), so every load instruction of a wave reads one contiguous KB.  Requested behind
     // the prologue's input loads (memory operations retire in order: the prologue must not wait for 295 KB of weights) and
     // ahead of its arithmetic; they land in AGPRs (the asm MFMAs' operand class), so that arithmetic does not compete with them.
     bf16x8_t wreg[72];
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                wreg[t * 8 + ks] = *reinterpret_cast<const bf16x8_t*>(wp + ((ABL & 512) ? (size_t)0 : (size_t)t * C * C + ks * 16));
+                wreg[t * 8 + ks] = (ABL & 4096) ? *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * C * C + ks * 16)
+                                                : *reinterpret_cast<const bf16x8_t*>(p.w + ((ABL & 512) ? (size_t)lane * 8 : (size_t)(((t * 4 + wave) * 8 + ks) * 64 + lane) * 8));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

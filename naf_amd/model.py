@@ -266,7 +266,7 @@ class _HipStem(torch.autograd.Function):
                 # weight / bias gradient: naf_stem_wgrad (pixel-contraction GEMM; a = SiLU(GroupNorm(x)) recomputed in its loader)
                 dw, db = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k, with_bias=True)
                 # data gradient: the same conv kernel, plain, on the flipped / transposed weights
-                wt = w.flip(2, 3).permute(2, 3, 1, 0).reshape(k * k, hid, hid).contiguous().to(torch.bfloat16)
+                wt = ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1))
                 if k == 3:
                     cur = (len(layers) - 1 - li) & 1
                     full = torch.empty_like(ext[cur])
@@ -384,14 +384,14 @@ class ImageEncoder(nn.Module):
         return self._hip_stem_ok() and self.encoder[0].out_channels == 128
 
     def _packed(self, conv: nn.Conv2d) -> torch.Tensor:
-        """bf16 [k*k, oc, ic] copy of a conv weight, cached until the parameter changes."""
+        """``ops.pack_conv_weight`` of a conv weight (bf16, the order naf_stem_conv_fwd reads), cached until the parameter changes."""
         cache = self.__dict__.setdefault("_wcache", {})
         w = conv.weight
         key = (w.data_ptr(), w._version, str(w.device))
         hit = cache.get(id(conv))
         if hit is None or hit[0] != key:
             k = w.shape[-1]
-            hit = (key, w.detach().permute(2, 3, 0, 1).reshape(k * k, w.shape[0], w.shape[1]).contiguous().to(torch.bfloat16))
+            hit = (key, ops.pack_conv_weight(w))
             cache[id(conv)] = hit
         return hit[1]
 

@@ -114,6 +114,32 @@ def _stats_ptr(t: Optional[torch.Tensor], B: int, what: str):
     return t.data_ptr()
 
 
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """``w_packed`` of ``naf_stem_conv_fwd`` for a Conv2d weight ``[oc, ic, k, k]`` (k in {1, 3}, oc == ic): bf16 ``[k*k, oc, ic]``
+    -- for the 3x3 layers of the default width (128 channels) holding the elements in the order the kernel's lanes keep them,
+    ``[9 taps][4 blocks of 32 oc][8 steps of 16 ic][2 halves of 8 ic][32 oc][8 ic]`` (``naf_stem_weight_index``), otherwise
+    plain ``weight.permute(2, 3, 0, 1)``.  The data gradient of a layer is the same kernel on
+    ``pack_conv_weight(weight.flip(2, 3).transpose(0, 1))``."""
+    oc, ic, k, k2 = weight.shape
+    if oc != ic or k != k2 or k not in (1, 3):
+        raise ValueError(f"pack_conv_weight: expected [C, C, k, k] with k in {{1, 3}}, got {tuple(weight.shape)}")
+    w = weight.detach().permute(2, 3, 0, 1).reshape(k * k, oc, ic)
+    if k == 3 and oc == 128:
+        # (t, wave, n32, ks, half, e) -> (t, wave, ks, half, n32, e)
+        w = w.reshape(9, 4, 32, 8, 2, 8).permute(0, 1, 3, 4, 2, 5).reshape(9, 128, 128)
+    return w.contiguous().to(torch.bfloat16)
+
+
+def unpack_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``pack_conv_weight``: the Conv2d weight ``[oc, ic, k, k]`` (bf16 values as fp32)."""
+    taps, oc, ic = w_packed.shape
+    k = {1: 1, 9: 3}[int(taps)]
+    w = w_packed.float()
+    if k == 3 and oc == 128:
+        w = w.reshape(9, 4, 8, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(9, 128, 128)
+    return w.reshape(k, k, oc, ic).permute(2, 3, 0, 1).contiguous()
+
+
 def _fill_stem_conv0(image, weight, bias, y, stats_out) -> StemConv0Args:
     B, Cin, H, W = image.shape
     Cout = int(weight.shape[0])
@@ -150,7 +176,7 @@ def stem_conv(x: Optional[torch.Tensor], stats_in: torch.Tensor, gn_weight: torc
               w_packed: torch.Tensor, bias: torch.Tensor, y: torch.Tensor, stats_out: Optional[torch.Tensor],
               first=None, keys=None) -> None:
     """GroupNorm(8,128) -> SiLU -> Conv2d(128 -> 128, k in {1,3}, reflect) + bias on bf16 [B,H,W,128] views.
-    w_packed: bf16 [k*k, 128, 128] (= weight.permute(2,3,0,1)); stats: f64 [STATS_SLOTS,B,8,2] buffers of ``new_stats`` (stats_out zeroed, or None).
+    w_packed: ``pack_conv_weight(conv.weight)`` (bf16 [k*k, C, C]); stats: f64 [STATS_SLOTS,B,8,2] buffers of ``new_stats`` (stats_out zeroed, or None).
     ``first=(image, conv0_weight, conv0_bias)`` (1x1 layers only, ``x=None``): the input is bf16(conv0(image))
     recomputed on the fly; ``stats_in`` then come from ``stem_conv0(..., y=None, ...)``.
     ``keys=(k_slice, tab_y, tab_x)`` (a branch's LAST layer, ``stats_out=None``): ``naf_stem_conv_keys_fwd`` -- the layer also
@@ -210,7 +236,7 @@ def _fill_key_pool(keys, x) -> KeyPoolArgs:
 
 def stem_conv_plain(x: torch.Tensor, w_packed: torch.Tensor, y: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
     """y = conv(x) (+ bias): ``naf_stem_conv_fwd`` without GroupNorm / SiLU, bf16 [B,H,W,128] views, reflect padding for the
-    3x3 kernel.  With ``w_packed`` = the flipped, transposed weights it is a layer's data gradient (see include/naf_hip.h)."""
+    3x3 kernel.  With ``w_packed = pack_conv_weight(weight.flip(2, 3).transpose(0, 1))`` it is a layer's data gradient (see include/naf_hip.h)."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape

@@ -54,6 +54,39 @@ def test_groupnorm_sum_copies_match_header_and_version(built_lib):
         ops._stats_ptr(tot, 3, "test")          # a 0.2.x-shaped buffer is refused before any launch
 
 
+@pytest.mark.parametrize("ks,Cc", [(3, 128), (1, 128), (3, 64), (1, 48), (3, 256)])
+def test_packed_weight_order_matches_the_library(built_lib, ks, Cc):
+    """ops.pack_conv_weight puts element (tap, oc, ic) where naf_stem_weight_index says the kernels read it (register order for
+    the 3x3 layers of the default width, [tap][oc][ic] everywhere else), unpack_conv_weight inverts it, and the index is a
+    permutation of the k*k*C*C elements; out-of-range arguments give -1."""
+    from naf_amd import ops
+    lib = C.CDLL(built_lib)
+    f = lib.naf_stem_weight_index
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int32] * 5
+    w = torch.arange(Cc * Cc * ks * ks, dtype=torch.float32).view(Cc, Cc, ks, ks) % 251          # exact in bf16
+    wp = ops.pack_conv_weight(w)
+    assert tuple(wp.shape) == (ks * ks, Cc, Cc) and wp.dtype == torch.bfloat16 and wp.is_contiguous()
+    flat = wp.float().flatten()
+    rng = np.random.RandomState(ks * 1000 + Cc)
+    seen = set()
+    for _ in range(3000):
+        t, oc, ic = int(rng.randint(ks * ks)), int(rng.randint(Cc)), int(rng.randint(Cc))
+        idx = f(ks, Cc, t, oc, ic)
+        assert 0 <= idx < flat.numel()
+        assert float(flat[idx]) == float(w[oc, ic, t // ks, t % ks]), (t, oc, ic, idx)
+        seen.add(idx)
+    if ks == 3 and Cc == 128:
+        all_idx = {f(3, 128, t, oc, ic) for t in range(9) for oc in range(0, 128, 7) for ic in range(128)}
+        assert len(all_idx) == 9 * len(range(0, 128, 7)) * 128                                   # injective
+        assert f(3, 128, 0, 1, 0) == 8 and f(3, 128, 0, 0, 8) == 32 * 8 and f(3, 128, 0, 0, 16) == 64 * 8 and f(3, 128, 0, 32, 0) == 8 * 64 * 8
+        assert f(3, 0, 4, 5, 6) == f(3, 128, 4, 5, 6)                                            # channels 0 = the default width
+    else:
+        assert f(ks, Cc, 0, 1, 0) == Cc and f(ks, Cc, 0, 0, 1) == 1
+    assert torch.equal(ops.unpack_conv_weight(wp), w)
+    assert f(ks, Cc, ks * ks, 0, 0) == -1 and f(ks, Cc, 0, Cc, 0) == -1 and f(2, Cc, 0, 0, 0) == -1 and f(ks, 24, 0, 0, 0) == -1
+
+
 def test_struct_layout_matches_header(built_lib):
     """sizeof of the ctypes mirrors == the C structs (checked through a tiny C probe compiled with gcc)."""
     import subprocess, tempfile

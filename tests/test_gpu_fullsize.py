@@ -388,7 +388,7 @@ def test_stem_of_any_width_runs_on_hip_and_matches_the_oracle(dev, dim, shape):
         st = ops.stats_from_total(torch.stack([xf.double().view(B, 8, -1).sum(-1), (xf.double() ** 2).view(B, 8, -1).sum(-1)], dim=-1).to(dev))
         y = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
         st_out = ops.new_stats(B, dev)
-        wp = w.permute(2, 3, 0, 1).reshape(ks * ks, hid, hid).contiguous().to(torch.bfloat16).to(dev)
+        wp = ops.pack_conv_weight(w).to(dev)
         ops.stem_conv(xd, st, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
         a = F.silu(F.group_norm(xf, 8, gw, gb, eps=1e-5)).to(torch.bfloat16).float()
         if ks == 3:

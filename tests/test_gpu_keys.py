@@ -31,7 +31,7 @@ def _layer_inputs(dev, B, H, W, ks, seed):
     g = x.double().view(B, 8, 16, H, W)
     from naf_amd import ops
     st_in = ops.stats_from_total(torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev))
-    wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
+    wp = ops.pack_conv_weight(w).to(dev)
     return xd, st_in, gw.to(dev), gb.to(dev), wp, bias.to(dev)
 
 

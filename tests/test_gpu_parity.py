@@ -172,7 +172,7 @@ def test_stem_conv_layer(dev, ks, shape):
     st_in = ops.stats_from_total(torch.stack([g.sum(dim=(2, 3, 4)), (g * g).sum(dim=(2, 3, 4))], dim=-1).to(dev))
     st_out = ops.new_stats(B, dev)
     y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
-    wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
+    wp = ops.pack_conv_weight(w).to(dev)
     ops.stem_conv(xd, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert_close(got, ref, 2e-2, 1e-2, f"stem conv k={ks} {shape}")     # bf16 rounding of SiLU(GN(x)) at |x| ~ boundary
@@ -213,7 +213,7 @@ def test_stem_layers_fuzz_small_and_odd_sizes(dev):
             st_in = ops.stats_from_total(torch.stack([gx.sum(dim=(2, 3, 4)), (gx * gx).sum(dim=(2, 3, 4))], dim=-1).to(dev))
             st_out = ops.new_stats(B, dev)
             y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
-            wp = w.permute(2, 3, 0, 1).reshape(ks * ks, 128, 128).contiguous().to(torch.bfloat16).to(dev)
+            wp = ops.pack_conv_weight(w).to(dev)
             ops.stem_conv(y0, st_in, gw.to(dev), gb.to(dev), 1e-5, wp, bias.to(dev), y, st_out)
             got = y.float().cpu().permute(0, 3, 1, 2)
             assert_close(got, ref, 3e-2, 1.5e-2, f"stem conv k={ks} {B}x{H}x{W}")

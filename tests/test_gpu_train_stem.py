@@ -39,13 +39,13 @@ def test_plain_convolution(dev, k, H, W):
     x = torch.randn(2, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
     w = (torch.randn(128, 128, k, k, generator=g) / (128 * k * k) ** 0.5).to(dev)
     b = torch.randn(128, generator=g).to(dev)
-    wp = w.permute(2, 3, 0, 1).reshape(k * k, 128, 128).contiguous().to(torch.bfloat16)
+    wp = ops.pack_conv_weight(w)
     y = torch.empty_like(x)
     ops.stem_conv_plain(x, wp, y, bias=b)
     xin = x.float().permute(0, 3, 1, 2)
     if k == 3:
         xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
-    ref = F.conv2d(xin, wp.float().reshape(k, k, 128, 128).permute(2, 3, 0, 1), b).permute(0, 2, 3, 1)
+    ref = F.conv2d(xin, ops.unpack_conv_weight(wp), b).permute(0, 2, 3, 1)
     err = (y.float() - ref).abs()
     assert float((err - 2 ** -8 * ref.abs()).max()) < 2e-3, float(err.max())     # one bf16 rounding of the output
     y2 = torch.empty_like(x)

@@ -43,12 +43,12 @@ int main(int argc, char** argv) {
     p.ys[0] = (int64_t)n; p.ys[1] = (int64_t)W * 128; p.ys[2] = 128;
     p.tiles_x = (W + 31) / 32;
     auto kern0 = stem_rows::stem_conv_rows_kernel<0, false>;
-    auto kern1 = stem_rows::stem_conv_rows_kernel<2048, false>;
+    auto kern1 = stem_rows::stem_conv_rows_kernel<4096, false>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES));
     for (int variant = 0; variant < 2; ++variant) {
     auto kern = variant ? kern1 : kern0;
-    printf("%s\n", variant ? "---- no GroupNorm-sum atomics at the end ----" : "---- library kernel ----");
+    printf("%s\n", variant ? "---- weights read in register order (1 KB contiguous per load instruction) ----" : "---- library kernel ----");
     auto timeit = [&](int nb, int seg_h) {
         p.seg_h = seg_h; p.segs_y = nb / p.tiles_x;
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nb), dim3(256), stem_rows::LDS_BYTES, 0, p);
@@ -83,13 +83,13 @@ int main(int argc, char** argv) {
     }
     {   // where a launch of 256 workgroups x 32 rows spends its time: 100 MHz wall clock stamps of every workgroup's wave 0
         auto kta = stem_rows::stem_conv_rows_kernel<1024, false>;
-        auto ktb = stem_rows::stem_conv_rows_kernel<1024 + 2048, false>;
+        auto ktb = stem_rows::stem_conv_rows_kernel<1024 + 4096, false>;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kta), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES));
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ktb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_rows::LDS_BYTES));
         for (int var = 0; var < 2; ++var)
         for (int seg_h : {4, 32}) {
             auto kt = var ? ktb : kta;
-            printf("%s", var ? "[no atomics] " : "[library]    ");
+            printf("%s", var ? "[reg order]  " : "[library]    ");
             const int nb = 256;
             p.seg_h = seg_h; p.segs_y = nb / p.tiles_x;
             for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kt, dim3(nb), dim3(256), stem_rows::LDS_BYTES, 0, p);
