@@ -35,9 +35,15 @@ struct XnaSlideParams {
 // whole 128-byte lines -- instead of one 64-byte piece per pixel and channel-tile pair (half a line per store instruction: the
 // stores were a quarter of the 11x11 kernel, profiles/r03_negative_results.txt).  Whole-row staging needs one tile per wave (STG)
 // and was slower there because every V^T fragment then feeds one MFMA instead of two.
+#ifdef NAF_SLIDE_STAMPS   // tools/xna_probe.hip: 100 MHz wall-clock stamps of every workgroup (entry, loop start, loop end, exit)
+__device__ unsigned long long g_slide_stamps[4096 * 4];
+#endif
 template <int KS, int DVT, typename OutT, int NW, bool ROPE, int TPWV = 2, bool STG = false, int ABL = 0, int HS = 0>
 __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams sp) {
     const XnaMfmaParams& p = sp.m;
+#ifdef NAF_SLIDE_STAMPS
+    const unsigned long long st_in = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int NT = NW * 64, TPW = TPWV;
     static_assert(!STG || (TPWV == 1 && sizeof(OutT) == 2 && (DVT % 32) == 0), "staged stores: bf16, one tile per wave, even channel-tile count");
     static_assert(HS == 0 || (!STG && TPWV == 2 && sizeof(OutT) == 2 && (HS == 64 || HS == 128) && DVT % HS == 0), "half-row staging: bf16, two tiles per wave");
@@ -186,6 +192,9 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
 #pragma unroll
     for (int u = 0; u < TPW; ++u) asm volatile("; xna slide first tiles landed" ::"v"(qf[u][0]), "v"(qf[u][1]));
     __syncthreads();
+#ifdef NAF_SLIDE_STAMPS
+    const unsigned long long st_loop = __builtin_amdgcn_s_memrealtime();
+#endif
 
     auto ka_of = [&](int mt) __attribute__((always_inline)) {
         const int row = (mt * 16 + 15 < NSLOT) ? mt * 16 + col : min(mt * 16 + col, NSLOT - 1);
@@ -496,6 +505,16 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
     // drain the (unused) prefetch past the last tile here (see xna_mfma_kernel.h on hipcc's waitcnt pass)
 #pragma unroll
     for (int u = 0; u < TPW; ++u) asm volatile("; xna slide loop drained" ::"v"(qf[u][0]), "v"(qf[u][1]));
+#ifdef NAF_SLIDE_STAMPS
+    {
+        const unsigned long long st_end = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the last cell's stores have left
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = g_slide_stamps + blockIdx.x * 4;
+            o[0] = st_in; o[1] = st_loop; o[2] = st_end; o[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // channels staged per flush of the half-row variant: 8-wave windows (one workgroup per CU anyway) whose LDS leaves room for the

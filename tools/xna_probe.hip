@@ -141,6 +141,33 @@ float run_slide(XnaMfmaParams p, int seg_len, int reps, const char* name, double
     CK(hipEventElapsedTime(&ms, a, b));
     ms /= reps;
     printf("slide seg %2d %-34s %8.4f ms  %8.1f GB/s (algorithmic)\n", seg_len, name, ms, bytes / ms / 1e6);
+#ifdef NAF_SLIDE_STAMPS
+    {
+        const int nb = sp.m.nblocks < 4096 ? (int)sp.m.nblocks : 4096;
+        std::vector<unsigned long long> h(4 * nb);
+        CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_slide_stamps), h.size() * 8));
+        unsigned long long t0 = ~0ull, t3 = 0;
+        for (int i = 0; i < nb; ++i) { t0 = std::min(t0, h[4 * i]); t3 = std::max(t3, h[4 * i + 3]); }
+        double ent = 0, entmax = 0, pro = 0, loop = 0, tail = 0, endspread = 0;
+        for (int i = 0; i < nb; ++i) {
+            const double e = (h[4 * i] - t0) / 100.0;
+            ent += e; entmax = std::max(entmax, e);
+            pro += (h[4 * i + 1] - h[4 * i]) / 100.0; loop += (h[4 * i + 2] - h[4 * i + 1]) / 100.0; tail += (h[4 * i + 3] - h[4 * i + 2]) / 100.0;
+            endspread += (t3 - h[4 * i + 3]) / 100.0;
+        }
+        if (getenv("NAF_PROBE_STAMP_XCD")) {
+            printf("      workgroup lifetime (us) by XCD (blockIdx %% 8): mean, min-max:");
+            for (int x = 0; x < 8; ++x) {
+                double a = 0, mn = 1e30, mx = 0; int c = 0;
+                for (int i = x; i < nb; i += 8) { const double d = (h[4 * i + 3] - h[4 * i]) / 100.0; a += d; mn = std::min(mn, d); mx = std::max(mx, d); ++c; }
+                printf("  %d: %.1f (%.1f-%.1f)", x, a / c, mn, mx);
+            }
+            printf("\n");
+        }
+        printf("      %d workgroups: first entry -> last exit %.1f us; entry after the first mean %.1f max %.1f; prologue %.1f, loop %.1f (%.2f per cell), tail %.1f, idle after exit %.1f us (means)\n",
+               nb, (t3 - t0) / 100.0, ent / nb, entmax, pro / nb, loop / nb, loop / nb / seg_len, tail / nb, endspread / nb);
+    }
+#endif
     return ms;
 }
 
