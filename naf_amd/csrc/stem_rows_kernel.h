@@ -327,17 +327,19 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
     // tile q's sums so far (the MFMA adds to them: an LDS float atomic per value is far slower than this read-modify-write of the
     // wave's own 16 bytes per lane) and the fragment of tile q, row g of `tile`: lane (n = lane & 15, G) gets pixels 4 G .. 4 G + 3
     // of the cell row, channel n
+    // (probe bits, tools/stem_rows_fixed_probe.hip: 8192 no sums read, 16384 no fragment read, 32768 no small MFMA, 65536 no sums write,
+    // 131072 no keys -- wrong keys, timing only)
     auto pool_rd = [&](const bf16_t* tile, int g, int q) __attribute__((always_inline)) {
-        pd = *((volatile NAF_LDS f32x4_t*)(psw_of() + q * 256));
-        pb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(tile + pb_off + (g * TW + (q >> 1) * 16) * PXE + (q & 1) * 32));
+        if constexpr (!(ABL & 8192)) pd = *((volatile NAF_LDS f32x4_t*)(psw_of() + q * 256));
+        if constexpr (!(ABL & 16384)) pb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(tile + pb_off + (g * TW + (q >> 1) * 16) * PXE + (q & 1) * 32));
     };
     auto pool_mm = [&]() __attribute__((always_inline)) {
-        asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(pd) : "v"(pa), "v"(pb));
+        if constexpr (!(ABL & 32768)) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(pd) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
     };
     // ... and back -- at least one MFMA slot behind pool_mm: the asm MFMA's result is invisible to the hazard recogniser
     auto pool_st = [&](int q, int h) __attribute__((always_inline)) {   // h = 0, 1 (ds_write_b64: free beside an MFMA)
-        *((volatile NAF_LDS f32x2_t*)(psw_of() + q * 256 + 2 * h)) = f32x2_t{pd[2 * h], pd[2 * h + 1]};
+        if constexpr (!(ABL & 65536)) *((volatile NAF_LDS f32x2_t*)(psw_of() + q * 256 + 2 * h)) = f32x2_t{pd[2 * h], pd[2 * h + 1]};
     };
     // the band whose last row is image row rl is complete: cell c's sums -> keys.  f0: sums (then cleared) and table values of the lane's position
     // 4 G + i (row tables for the row-sum waves, the cell's column tables otherwise), f1: rotation (rope.py:15-34) and the sum over
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void stem_conv_rows_kernel(const StemConvPa
             // POOL: the tile in the LDS holds image rows pr0 = sy - 5 + 2 d and pr0 + 1; pr0 & 15 == 15 (d = 2 mod 8: D = 0, it = 1 mod 4)
             // ends a band of cells -- the first time (d = 2) a band above the segment
             const int pr0 = sy - 5 + 2 * d;
-            const bool pfin = POOL && D == 0 && (it & 3) == 1 && it > 1;
+            const bool pfin = POOL && !(ABL & 131072) && D == 0 && (it & 3) == 1 && it > 1;
             (void)pr0; (void)pfin;
             // commit target: batch d + 2 = ring rows (4 it + 2 D + 4) % 8
             bf16_t* commit_base = ring + (D == 0 ? oth : oth + 2 * ROWE);

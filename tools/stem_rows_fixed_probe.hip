@@ -108,5 +108,38 @@ int main(int argc, char** argv) {
                    seg_h, (t3 - t0) / 100.0, lat / nb, lmax, pro / nb, loop / nb, tail / nb);
         }
     }
+    {   // the POOL instantiation (key pooling on the last layer) against the plain one, and what its parts cost: 256 workgroups x 128 rows
+        float *ty, *tx; bf16_t* keys;
+        CK(hipMalloc(&ty, (size_t)H * 32 * 4)); CK(hipMalloc(&tx, (size_t)W * 32 * 4)); CK(hipMalloc(&keys, (size_t)(H / 16) * (W / 16) * 256 * 2));
+        std::vector<float> ht((size_t)(H > W ? H : W) * 32);
+        for (size_t i = 0; i < ht.size(); ++i) ht[i] = (i & 16) ? 0.6f : 0.8f;
+        CK(hipMemcpy(ty, ht.data(), (size_t)H * 32 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(tx, ht.data(), (size_t)W * 32 * 4, hipMemcpyHostToDevice));
+        StemConvParams q = p;
+        q.stats_out = nullptr; q.kout = keys; q.tab_y = ty; q.tab_x = tx; q.kst[0] = (int64_t)(H / 16) * (W / 16) * 256; q.kst[1] = (int64_t)(W / 16) * 256; q.kst[2] = 256;
+        const int segs = 256 / q.tiles_x > 0 ? 256 / q.tiles_x : 1;
+        int seg_h = (H + segs - 1) / segs; seg_h = ((seg_h + 15) / 16) * 16; if (seg_h > stem_rows::POOL_ROWS) seg_h = stem_rows::POOL_ROWS;
+        q.seg_h = seg_h; q.segs_y = (H + seg_h - 1) / seg_h;
+        const int nb = q.tiles_x * q.segs_y;
+        printf("---- key pooling on the layer: %d workgroups x %d rows, us per launch (%d launches, two rounds) ----\n", nb, seg_h, reps);
+        auto run = [&](auto kern, size_t lds, const StemConvParams& pp, const char* name) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, pp);
+            CK(hipEventRecord(ea));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, 0, pp);
+            CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb));
+            float ms = 0; CK(hipEventElapsedTime(&ms, ea, eb));
+            printf("  %-52s %7.1f\n", name, ms / reps * 1e3f);
+        };
+        StemConvParams pn = q; pn.kout = nullptr; pn.stats_out = p.stats_out;
+        for (int round = 0; round < 2; ++round) {
+            run(stem_rows::stem_conv_rows_kernel<0, false, false>, stem_rows::LDS_BYTES, pn, "plain layer (with GroupNorm sums)");
+            run(stem_rows::stem_conv_rows_kernel<0, false, true>, stem_rows::LDS_BYTES_POOL, q, "layer + keys");
+            run(stem_rows::stem_conv_rows_kernel<131072, false, true>, stem_rows::LDS_BYTES_POOL, q, "  no keys (sums only)");
+            run(stem_rows::stem_conv_rows_kernel<131072 | 32768, false, true>, stem_rows::LDS_BYTES_POOL, q, "  no keys, no small MFMAs");
+            run(stem_rows::stem_conv_rows_kernel<131072 | 16384, false, true>, stem_rows::LDS_BYTES_POOL, q, "  no keys, no fragment (transposing) reads");
+            run(stem_rows::stem_conv_rows_kernel<131072 | 8192 | 65536, false, true>, stem_rows::LDS_BYTES_POOL, q, "  no keys, sums not read / written");
+            run(stem_rows::stem_conv_rows_kernel<131072 | 8192 | 16384 | 32768 | 65536, false, true>, stem_rows::LDS_BYTES_POOL, q, "  no keys, no chains at all (indicator only)");
+        }
+    }
     return 0;
 }
