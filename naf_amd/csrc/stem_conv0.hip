@@ -21,7 +21,7 @@ struct StemConv0Params {
     bf16_t* y;         // [B, H, W, >=128]
     const float* w;    // [128][3][KS][KS]
     const float* bias; // [128]
-    double* stats_out; // [B][8][2]
+    double* stats_out; // [NAF_STATS_SLOTS][B][8][2] (naf_gn_slot)
     int32_t B, H, W, gpr, ngroups;   // gpr = 32-pixel segments per row, ngroups = H * gpr
     int32_t is[4];     // {b unused, c, y, x} element strides (validated < 2^31 by the launcher)
     int64_t ibs;       // batch stride of the image
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv0_kernel(const StemConv0Param
     __syncthreads();
     if (tid < 16) {
         const float a = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        atomicAdd(&p.stats_out[(b * 8 + (tid & 7)) * 2 + (tid >> 3)], (double)a);
+        atomicAdd(&naf_gn_slot(p.stats_out, p.B, b, blockIdx.x)[(tid & 7) * 2 + (tid >> 3)], (double)a);
     }
 }
 
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
         float a = 0.f;
 #pragma unroll
         for (int wv = 0; wv < NWS; ++wv) a += red[wv * 16 + tid];
-        atomicAdd(&p.stats_out[(b * 8 + (tid & 7)) * 2 + (tid >> 3)], (double)a);
+        atomicAdd(&naf_gn_slot(p.stats_out, p.B, b, blockIdx.x)[(tid & 7) * 2 + (tid >> 3)], (double)a);
     }
 }
 
@@ -521,7 +521,8 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict_
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) atomicAdd(&stats[b * 16 + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 9)   // into the workgroup's copy of the sums (naf_gn_slot: atomics to one line are served one by one)
+        atomicAdd(&naf_gn_slot(stats, (int)gridDim.y, b, blockIdx.x)[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ bias,
@@ -529,7 +530,10 @@ __global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restri
     const int b = blockIdx.x, c = threadIdx.x;   // one thread per output channel
     double m[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) m[j] = stats[b * 16 + j];
+    for (int j = 0; j < 9; ++j) {   // the moments, added up over their copies
+        m[j] = 0.0;
+        for (int sl = 0; sl < NAF_STATS_SLOTS; ++sl) m[j] += stats[((size_t)sl * gridDim.x + b) * 16 + j];
+    }
     __syncthreads();                              // every thread has read the moments before the slots are overwritten
     const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], bc = bias[c];
     const double ws1 = w0 * m[0] + w1 * m[1] + w2 * m[2];
@@ -543,6 +547,10 @@ __global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restri
     if ((c & 15) == 0) {
         stats[(b * 8 + (c >> 4)) * 2 + 0] = s1;
         stats[(b * 8 + (c >> 4)) * 2 + 1] = s2;
+        for (int sl = 1; sl < NAF_STATS_SLOTS; ++sl) {   // the other copies held moments: the layer's consumer adds all copies up
+            stats[((size_t)sl * gridDim.x + b) * 16 + (c >> 4) * 2 + 0] = 0.0;
+            stats[((size_t)sl * gridDim.x + b) * 16 + (c >> 4) * 2 + 1] = 0.0;
+        }
     }
 }
 
