@@ -91,6 +91,8 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  * 17-20 us: profiles/r04_stats_atomics.txt.)  Since 0.3.0; 0.2.x had one copy.
  *
  * naf_stem_conv0_fwd : Conv2d(3 -> 128, ksize 1 or 3, reflect) + bias         (convolutions.py:68-75)
+ *   fp32 accumulation; products exact in fp32 for ksize 1, carried to 16 mantissa bits for ksize 3 at the default width (the sum
+ *   is within 2^-15 * sum |x||w| of the fp32 convolution before its one rounding to bf16);
  *   image device [B, 3, H, W] f32/bf16, element strides {b, c, y, x}; weight device f32 [128][3][k][k]
  *   (the module's own parameter), bias f32 [128]; y device bf16, strides {b, y, x}, 128 ch contiguous;
  *   stats_out accumulates sum / sum^2 of y per GroupNorm group (zeroed by the caller).  y may be NULL: statistics only

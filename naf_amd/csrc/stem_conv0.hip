@@ -264,7 +264,8 @@ __device__ __forceinline__ constexpr int split_xpart(int t) { return t == 0 ? 0 
 __device__ __forceinline__ constexpr int split_wpart(int t) { return t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 0 : 0; }
 }  // namespace
 
-// T0 = first term used: 0 -> all six (fp32-exact products), 3 -> the three largest (products carried to 16 mantissa bits).
+// T0 selects the terms: 0 -> all six (fp32-exact products); 3 -> the three of weight 2^0 and 2^-8, (x0 w1) | (x1 w0) (x0 w0): products
+// carried to 16 mantissa bits (the dropped terms are 2^-16 of the product each), half the MFMAs.
 #ifdef NAF_CONV0_TIMING   // tools/conv0_probe.hip: s_memtime sums per wave and phase
 __device__ unsigned long long g_conv0_tim[4096 * 8];
 #define C0_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
@@ -379,9 +380,10 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
             // of the current one (two register sets pinned by sched_barriers; left alone hipcc reads every fragment right in front of its
             // MFMA -- the 1x1 layer's lesson, round 3)
             {
-                // (weight part, first term, terms) of the groups from term T0 on: T0 = 0: w2 {0}, w1 {1, 2}, w0 {3, 4, 5}; T0 = 3: w0 {3, 4, 5}
-                constexpr int NGRP = T0 == 0 ? 3 : 1;
-                constexpr int GW[3] = {T0 == 0 ? 2 : 0, 1, 0}, GT0[3] = {T0 == 0 ? 0 : 3, 1, 3}, GN[3] = {T0 == 0 ? 1 : 3, 2, 3};
+                // (weight part, first term, terms) of the groups: T0 = 0: w2 {0}, w1 {1, 2}, w0 {3, 4, 5}; T0 = 3: w1 {2}, w0 {4, 5}
+                constexpr int NGRP = T0 == 0 ? 3 : 2;
+                constexpr int GW[3] = {T0 == 0 ? 2 : 1, T0 == 0 ? 1 : 0, 0}, GT0[3] = {T0 == 0 ? 0 : 2, T0 == 0 ? 1 : 4, 3},
+                              GN[3] = {1, 2, 3};
                 constexpr int NFR = NGRP * 2;                     // fragment pairs: (group, s)
                 bf16x8_t af[2][2];
                 auto frag = [&](int f, int slot) __attribute__((always_inline)) {
@@ -619,7 +621,12 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
             hipLaunchKernelGGL(kern, g8, blk8, lds, s, p);
             return naf_check_launch("stem_conv0_split_kernel");
         };
-        static const bool three = [] { const char* e = naf_knob("NAF_CONV0_TERMS"); return e && atoi(e) == 3; }();   // A/B knob
+        // Default since the end of round 4: products carried to 16 mantissa bits (three terms, 24 MFMAs per segment: 0.062-0.066 ms
+        // at 1024^2 against 0.080-0.085 with all six).  The sum then differs from the fp32 convolution by <= 2^-15 sum|x||w| (~3e-5
+        // absolute on unit-scale data) BEFORE its one rounding to bf16 (2^-9 relative): 0.3 % of the outputs land on the neighbouring
+        // bf16 value (0.008 % with six terms; tools/conv0_terms_probe.py) -- the reference's own GPU path multiplies in TF32 or bf16 here.
+        // NAF_CONV0_TERMS=6 (with NAF_HIP_KNOBS=1): all six terms.
+        static const bool three = [] { const char* e = naf_knob("NAF_CONV0_TERMS"); return !(e && atoi(e) == 6); }();
         if (three) return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 3>) : launch(stem_conv0_split_kernel<float, 3>);
         return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 0>) : launch(stem_conv0_split_kernel<float, 0>);
     }

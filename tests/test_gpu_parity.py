@@ -147,10 +147,13 @@ def test_stem_conv0(dev, ks, shape):
     st = ops.new_stats(B, dev)
     ops.stem_conv0(img.to(dev), w.to(dev), bias.to(dev), y, st)
     got = y.float().cpu().permute(0, 3, 1, 2)
-    assert_close(got, ref, 1e-5, 2 ** -8, f"conv0 k={ks}")
+    # one rounding to bf16 (2^-8 |ref| with the tie at a binade's lower end) on top of the kernel's own error before it: products exact
+    # in fp32 for the 1x1 layer, carried to 16 bits for the 3x3 layer (<= 2^-15 sum|x||w|, ~3e-5 here: include/naf_hip.h)
+    assert_close(got, ref, 1e-5 if ks == 1 else 6e-5, 2 ** -8, f"conv0 k={ks}")
     g = ref.double().view(B, 8, 16, H, W)
-    assert torch.allclose(ops.stats_total(st)[..., 0].cpu(), g.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(ops.stats_total(st)[..., 1].cpu(), (g * g).sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+    atol = 1e-3 if ks == 1 else 1e-2          # 3x3: the sums of ~1e4 products carried to 16 bits
+    assert torch.allclose(ops.stats_total(st)[..., 0].cpu(), g.sum(dim=(2, 3, 4)), rtol=1e-5, atol=atol)
+    assert torch.allclose(ops.stats_total(st)[..., 1].cpu(), (g * g).sum(dim=(2, 3, 4)), rtol=1e-5, atol=atol)
 
 
 @pytest.mark.parametrize("ks", [1, 3])
@@ -199,9 +202,9 @@ def test_stem_layers_fuzz_small_and_odd_sizes(dev):
             y0 = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
             st0 = ops.new_stats(B, dev)
             ops.stem_conv0(img.to(dev), w0.to(dev), b0.to(dev), y0, st0)
-            assert_close(y0.float().cpu().permute(0, 3, 1, 2), ref0, 1e-5, 2 ** -8, f"conv0 k={ks} {B}x{H}x{W}")
+            assert_close(y0.float().cpu().permute(0, 3, 1, 2), ref0, 1e-5 if ks == 1 else 6e-5, 2 ** -8, f"conv0 k={ks} {B}x{H}x{W}")
             g0 = ref0.double().view(B, 8, 16, H, W)
-            assert torch.allclose(ops.stats_total(st0)[..., 0].cpu(), g0.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3)
+            assert torch.allclose(ops.stats_total(st0)[..., 0].cpu(), g0.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-3 if ks == 1 else 1e-2)
             # the layer on top of it
             x = bf16r(ref0)
             w = bf16r(O.hash_normal((128, 128, ks, ks), 72, 1.0 / (11.3 * ks)))
@@ -1268,17 +1271,28 @@ def test_sliding_window_kernel_matches_oracle(dev, B, C, lr, out_sz, ksz, out_dt
 
 @pytest.mark.parametrize("feat_dtype", [torch.bfloat16, torch.float32])
 def test_single_call_forward_equals_composed_calls(dev, feat_dtype):
-    """naf_forward (the whole forward in one foreign call) == the same kernels launched one by one, bit for bit."""
+    """naf_forward (the whole forward in one foreign call) == the same kernels launched one by one: bit for bit where both run the same
+    kernels (8 x 8 pixel cells: keys from the pooling pass in both); on 16 x 16 pixel cells the one call takes its keys from the last
+    stem layers (naf_stem_conv_keys_fwd) while the composed path runs the pooling pass -- the keys then differ by at most one bf16
+    rounding, the outputs by one bf16 step on a handful of values (cf. test_forward_with_and_without_key_fusion_agree)."""
     p = O.make_params(seed=41)
     m = _load_model(dev, p, kernel_size=5)
     img = O.hash_normal((2, 3, 96, 128), 961).to(dev)
+    ft8 = O.hash_normal((2, 128, 12, 16), 963).to(dev).to(feat_dtype)
+    assert m._forward_plan(img, ft8, (96, 128)) is not None
+    a8 = m(img, ft8, (96, 128))
+    m.single_call = False
+    b8 = m(img, ft8, (96, 128))
+    m.single_call = True
+    assert a8.dtype == b8.dtype and torch.equal(a8, b8)
     ft = O.hash_normal((2, 128, 6, 8), 962).to(dev).to(feat_dtype)
     assert m._forward_plan(img, ft, (96, 128)) is not None
     a = m(img, ft, (96, 128))
     m.single_call = False
     b = m(img, ft, (96, 128))
     m.single_call = True
-    assert a.dtype == b.dtype and torch.equal(a, b)
+    d = (a.float() - b.float()).abs()
+    assert a.dtype == b.dtype and float(d.max()) <= 4e-3 and float(d.mean()) <= 1e-6, (float(d.max()), float(d.mean()))
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (96, 128), kernel_size=5)
     assert_close(a.float().cpu(), ref, 2e-2, 1e-2, "single-call forward vs oracle")
     # a different architecture (other window per axis) falls back to the composed path

@@ -14,7 +14,7 @@ int naf_cu_count() { return 256; }
 int main() {
     const int H = 1024, W = 1024;
     float *img, *w, *b; double* st; void* y;
-    CK(hipMalloc(&img, (size_t)3 * H * W * 4)); CK(hipMalloc(&w, 128 * 27 * 4)); CK(hipMalloc(&b, 128 * 4)); CK(hipMalloc(&st, 16 * 8));
+    CK(hipMalloc(&img, (size_t)3 * H * W * 4)); CK(hipMalloc(&w, 128 * 27 * 4)); CK(hipMalloc(&b, 128 * 4)); CK(hipMalloc(&st, NAF_STATS_SLOTS * 16 * 8)); CK(hipMemset(st, 0, NAF_STATS_SLOTS * 16 * 8));
     CK(hipMalloc(&y, (size_t)H * W * 128 * 2));
     std::vector<float> h((size_t)3 * H * W);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8) / 16777216.0f - 0.5f;

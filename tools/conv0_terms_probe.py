@@ -14,4 +14,9 @@ for _ in range(50): ops.stem_conv0(img, w, b, y, st)
 e1.record(); torch.cuda.synchronize()
 ref = torch.nn.functional.conv2d(torch.nn.functional.pad(img.double(), (1,1,1,1), mode="reflect"), w.double(), b.double()).permute(0,2,3,1)
 err = (y.double() - ref).abs()
-print(os.environ.get("NAF_CONV0_TERMS", "6"), "terms: %.4f ms" % (e0.elapsed_time(e1) / 50), "max err vs fp64 / bf16 ulp: %.3f" % float((err / (ref.abs() * 2**-8 + 1e-6)).max()), "mismatch vs bf16(ref): %.5f" % float((y != ref.to(torch.bfloat16)).float().mean()))
+rb = ref.to(torch.bfloat16)
+mis = (y != rb)
+ulp = (rb.double().abs() * 2.0 ** -7).clamp_min(1e-30)          # one bf16 unit in the last place is 2^-8 .. 2^-7 of the value
+print(os.environ.get("NAF_CONV0_TERMS", "default"), "terms: %.4f ms;" % (e0.elapsed_time(e1) / 50),
+      "outputs that are not bf16(fp64 conv): %.4f %%, of those more than one unit away: %d;" % (100 * float(mis.float().mean()), int(((y.double() - rb.double()).abs() > 1.01 * ulp).sum())),
+      "max |y - ref| / (|ref| 2^-8 + 1e-5): %.3f" % float((err / (ref.abs() * 2 ** -8 + 1e-5)).max()))
