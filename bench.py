@@ -158,7 +158,7 @@ def measure_traffic_live(workload, per_gpu_batch, timeout_s=90):
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--per-gpu-batch", str(per_gpu_batch), "--steps", "3",
-                   "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"]
+                   "--warmup", "1", "--settle-seconds", "0", "--no-cpu-baseline", "--no-live-traffic"]
             # a plain single-GPU child, also when this process is rank 0 of a multi-GPU run (no launcher variables, same device)
             env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                                        "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "NAF_BENCH_BACKEND")}

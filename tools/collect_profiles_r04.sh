@@ -47,7 +47,7 @@ cat $out/kernel_stats.csv
 for w in G1 G2-k7 G2-k11 G2-k15 G3 G4 REF448; do
   for c in FETCH_SIZE WRITE_SIZE; do
     d=$out/pmc_${w}_$c
-    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > $d.log 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python $R/bench.py --workload $w --steps 3 --warmup 1 --settle-seconds 0 --no-cpu-baseline --no-live-traffic > $d.log 2>&1)
   done
 done
 python3 - $out > $out/pmc_hbm_traffic.txt <<'PY'
