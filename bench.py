@@ -202,12 +202,23 @@ def _self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _planned_streams(model):
+    """Streams the one-call forward used (2 = the encoder branches side by side on a stream this host lends), None outside that mode."""
+    plan = (model.__dict__.get("_plan_cache") or (None, None))[1]
+    return plan.planned_streams() if plan is not None else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 on one GPU = ~2 s of device time, so that "
                     "a utilisation sampler sees the timed region; 30 on several GPUs, where a step is the whole 64-image batch)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2), help="stream layout of the one-call forward: 0 = the library's "
+                    "plan (naf_forward_streams), 1 = one stream, 2 = the two encoder branches side by side whenever possible (A/B)")
+    ap.add_argument("--conv0-exact", action="store_true", help="NAF_FWD_CONV0_EXACT: exact fp32 products in the 3x3 first convolution (A/B)")
+    ap.add_argument("--no-cold-reading", action="store_true", help="skip the first reading (W warm-ups + K steps before the settle "
+                    "phase, reported as ms_per_step_no_settle)")
     ap.add_argument("--settle-seconds", type=float, default=0.3, help="part of the set-up, before the W warm-up steps: run the step "
                     "for this long so that the device has left its idle power state (a process that starts timing 10 ms after its "
                     "first launch measures the clock ramp: 20 timed steps read 3 %% slower than 1000); 0 disables it")
@@ -299,6 +310,8 @@ def main():
         image = torch.randn(B, 3, out, out, device=dev, generator=g)
         feats = torch.randn(B, C, lr, lr, device=dev, generator=g).to(torch.bfloat16)
 
+    ops.ForwardPlan.streams = args.streams
+    ops.ForwardPlan.conv0_exact = bool(args.conv0_exact)
     timer = EventTimer()
     # phase events on every 8th step: seven extra event records between the kernels of a step cost 0.03-0.05 ms (1.5-2 %) of a
     # 2.25 ms G1 step when taken every step (gpurun r9b: 2.270 vs 2.228 ms), a quarter of a percent this way
@@ -327,6 +340,30 @@ def main():
 
     with torch.no_grad():
         o = None
+        # Reading 1 (SURVEY 8d / test/forward_speed.py:31-52, the protocol of rounds 1-3): W warm-up steps from idle, then the same
+        # --steps timed the same way, BEFORE any settle phase -- reported as ms_per_step_no_settle so that driver numbers stay
+        # comparable across rounds.  Reading 2 (ms_per_step, `value`): after the settle phase below.
+        el_cold = None
+        if args.settle_seconds > 0 and not args.no_cold_reading:
+            for _ in range(args.warmup):
+                o = step()
+            del o
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            for _ in range(args.steps):
+                o = step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el_cold = time.perf_counter() - t0c
+            if world > 1:
+                tc = torch.tensor([el_cold], dtype=torch.float64, device=dev)
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+                el_cold = float(tc.item())
         settle_steps = 0
         if args.settle_seconds > 0:      # set-up, like the plan / table / workspace creation of the first call: not a timed or counted step
             t_settle = time.perf_counter()
@@ -482,6 +519,8 @@ def main():
         line = {
             "metric": "upsampled Mpixels/sec (NAF forward)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            # the same W warm-ups + K steps taken BEFORE the settle phase (the protocol of rounds 1-3): comparable across rounds
+            "ms_per_step_no_settle": round(el_cold * 1e3 / args.steps, 4) if el_cold else None,
             "settle": {"seconds": args.settle_seconds, "steps": settle_steps,
                        "what": "untimed set-up before the warm-up steps: the step is run for this long so that the device has left its idle power state"},
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
@@ -497,7 +536,8 @@ def main():
                        "input_distribution": (None if world == 1 else "rank 0 -> RCCL scatter (naf_amd.dist.scatter_batch), before the timed region"),
                        "scope": ("attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)")
                                 + (", hipGraph replay" if args.graph else ""),
-                       "weights": "random-init NAF() defaults (dim 256, 4 heads)"},
+                       "weights": "random-init NAF() defaults (dim 256, 4 heads)",
+                       "streams": _planned_streams(model)},
             "roofline": roof,
             "phases_ms": {k: v for k, v in phases.items() if v is not None},
         }

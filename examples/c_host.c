@@ -44,8 +44,8 @@ static void* to_device(const void* host, size_t bytes) {
 int main(int argc, char** argv) {
     if (argc != 14) { fprintf(stderr, "usage: %s params image features out B H W h w C ksize Ho Wo\n", argv[0]); return 1; }
     /* the argument structs carry no size field: header and library must agree in major.minor (include/naf_hip.h) */
-    if (naf_version() / 100 != NAF_HIP_VERSION / 100) {
-        fprintf(stderr, "libnaf_hip.so is version %d, this host was built against %d\n", naf_version(), NAF_HIP_VERSION);
+    if (naf_abi_check(NAF_HIP_VERSION) != NAF_OK) {
+        fprintf(stderr, "%s\n", naf_last_error());
         return 1;
     }
     const int B = atoi(argv[5]), H = atoi(argv[6]), W = atoi(argv[7]), h = atoi(argv[8]), w = atoi(argv[9]), C = atoi(argv[10]);
@@ -100,8 +100,17 @@ int main(int argc, char** argv) {
     a.workspace_bytes = naf_forward_workspace_bytes(&a);
     CK(hipMalloc(&a.workspace, a.workspace_bytes));
 
-    NK(naf_forward(&a, NULL));           /* stream 0 */
-    CK(hipDeviceSynchronize());
+    /* the two encoder branches side by side: this host lends the library a second stream and two events for the call (the
+     * library owns none); naf_forward(&a, stream) is the same forward on the one stream */
+    hipStream_t stream;
+    CK(hipDeviceSynchronize());           /* the RoPE tables were built on the NULL stream; `stream` does not wait for it */
+    CK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    naf_forward_aux aux;
+    NK(naf_forward_aux_create(&aux));
+    NK(naf_forward_ex(&a, &aux, 0u, stream));
+    CK(hipStreamSynchronize(stream));     /* the lent stream was joined back into `stream` before the call returned */
+    NK(naf_forward_aux_destroy(&aux));
+    CK(hipStreamDestroy(stream));
 
     float* host_out = (float*)malloc(nout * 4);
     CK(hipMemcpy(host_out, out, nout * 4, hipMemcpyDeviceToHost));

@@ -15,9 +15,9 @@
  *   - plain C types only; every pointer marked "device" is a HIP device pointer owned by the caller.
  *   - the library allocates, retains and frees NO device memory; outputs and workspaces are the
  *     caller's.  Launches are asynchronous on the caller's hipStream_t (passed as void*), on the
- *     caller's current device.  Functions are re-entrant.  The only HIP objects the library owns are one
- *     non-blocking stream and two events per device, created on naf_forward's first call there (it runs the two
- *     encoder branches side by side and joins them back into the caller's stream before it returns).
+ *     caller's current device.  Functions are re-entrant and the library keeps NO global mutable state beyond
+ *     once-initialised kernel attributes: it owns no stream, no event, no memory.  (0.2.0 - 0.3.x kept one stream and two
+ *     events per device inside naf_forward; since 0.4.0 the second stream of the forward is the caller's: naf_forward_aux.)
  *   - return value 0 = success; non-zero = error, text via naf_last_error() (thread-local).
  *     Nothing throws or aborts across the ABI.  Argument checks mirror the reference's failure modes
  *     (NATTEN: odd kernel, kernel*dilation <= extent; einops: channels divisible by heads).
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 300 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 400 /* major*10000 + minor*100 + patch */
 /* Binary compatibility: the argument structs carry no size field, so a host must be BUILT against the header of the library it
  * loads whenever the minor version differs (compare naf_version() / 100 with NAF_HIP_VERSION / 100 at start-up, as
  * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
@@ -41,7 +41,19 @@ extern "C" {
  * own structs (naf_stem_conv_keys_fwd / naf_key_pool_args) instead of growing existing ones.  0.3.0 changed the LAYOUT of the
  * GroupNorm-sum buffers of the stem entry points ([B][8][2] -> [NAF_STATS_SLOTS][B][8][2], see "guidance conv stem") and the order
  * of w_packed for the 3x3 layers of the default width (naf_stem_weight_index; also naf_stem_branch.conv_weight_packed of naf_forward):
- * a 0.2.x host must be rebuilt, allocate the larger buffers and repack those weights; the attention entries are unchanged. */
+ * a 0.2.x host must be rebuilt, allocate the larger buffers and repack those weights; the attention entries are unchanged.
+ * 0.4.0 makes that break DETECTABLE: the entry points that read or write GroupNorm-sum buffers are exported under names that
+ * carry the copy count (naf_stem_conv0_fwd -> naf_stem_conv0_fwd_s16, ...; the #defines below keep the source names), so a binary
+ * built against a 0.2.x / 0.3.x header fails to resolve them at load time instead of overrunning its [B][8][2] buffers, and
+ * naf_abi_check(NAF_HIP_VERSION) lets a host compare the header it was compiled with against the library it loaded in one call.
+ * 0.4.0 also appends `flags` to naf_stem_conv0_args and adds naf_forward_ex / naf_forward_aux (caller-owned second stream);
+ * naf_forward itself is unchanged in signature and now runs on the caller's stream only. */
+#define naf_stem_conv0_fwd naf_stem_conv0_fwd_s16
+#define naf_stem_conv_fwd naf_stem_conv_fwd_s16
+#define naf_stem_conv_keys_fwd naf_stem_conv_keys_fwd_s16
+#define naf_stem_act_fwd naf_stem_act_fwd_s16
+#define naf_stem_act_bwd naf_stem_act_bwd_s16
+#define naf_stem_wgrad naf_stem_wgrad_s16
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -69,6 +81,9 @@ enum naf_xna_path {
 /* ---- library ------------------------------------------------------------------------------- */
 int naf_version(void);
 const char* naf_last_error(void);
+/* NAF_OK when a host compiled against a header of version `header_version` (pass NAF_HIP_VERSION) may call this library:
+ * same major and minor version.  NAF_ERR_INVALID (with the two versions in naf_last_error()) otherwise.  0.4.0. */
+int naf_abi_check(int header_version);
 
 /* ---- host helper: which low-res rows/cols a hi-res query attends to (one axis) ------------------
  * Replaces, for one axis, NATTEN's neighbourhood rule composed with the reference's nearest-exact
@@ -92,7 +107,7 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *
  * naf_stem_conv0_fwd : Conv2d(3 -> 128, ksize 1 or 3, reflect) + bias         (convolutions.py:68-75)
  *   fp32 accumulation; products exact in fp32 for ksize 1, carried to 16 mantissa bits for ksize 3 at the default width (the sum
- *   is within 2^-15 * sum |x||w| of the fp32 convolution before its one rounding to bf16);
+ *   is within 2^-15 * sum |x||w| of the fp32 convolution before its one rounding to bf16; flags & NAF_CONV0_EXACT: exact products);
  *   image device [B, 3, H, W] f32/bf16, element strides {b, c, y, x}; weight device f32 [128][3][k][k]
  *   (the module's own parameter), bias f32 [128]; y device bf16, strides {b, y, x}, 128 ch contiguous;
  *   stats_out accumulates sum / sum^2 of y per GroupNorm group (zeroed by the caller).  y may be NULL: statistics only
@@ -118,6 +133,11 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
 #ifndef NAF_STATS_SLOTS
 #define NAF_STATS_SLOTS 16 /* copies of every GroupNorm-sum buffer (part of the ABI: a library built with another value is another ABI) */
 #endif
+/* Bytes of ONE GroupNorm-sum buffer for a batch of B images as THIS library lays it out ([NAF_STATS_SLOTS][B][8][2] fp64): what a
+ * host allocates per `stats` pointer instead of hard-coding the shape (0 for B <= 0).  0.4.0. */
+size_t naf_stem_stats_bytes(int32_t B);
+/* naf_stem_conv0_args.flags */
+#define NAF_CONV0_EXACT 1 /* ksize 3, default width: all six bf16-split terms (products exact in fp32) instead of the default three */
 typedef struct naf_stem_conv0_args {
     const void* image;
     void* y;
@@ -130,6 +150,8 @@ typedef struct naf_stem_conv0_args {
     int32_t channels;    /* output channels: 0 or 128 = the default width's kernels; any multiple of 16 in [16, 256] otherwise */
     int64_t image_stride[4];
     int64_t y_stride[3];
+    int32_t flags;       /* 0.4.0: NAF_CONV0_* bits; 0 = defaults */
+    int32_t reserved;
 } naf_stem_conv0_args;
 int naf_stem_conv0_fwd(const naf_stem_conv0_args* a, naf_stream_t stream);
 
@@ -431,9 +453,11 @@ typedef struct naf_xna_bwd_args {
  * idx_x like the table-driven kernel AND `workspace` (per-query softmax statistics, 16 bytes per query); without a workspace
  * the call runs the table-driven kernel instead.  It adds into the zeroed dk_lr / dv_lr like the other kernels (one read-add-write per key, or fp32
  * atomics where a key tile's rows are shared between waves).
- * Inputs must be FINITE on the NAF_XNA_ROWS kernel: it skips the upper half of a 32-slot chunk that no lane needs and lets the
- * stale copies of earlier inputs in its LDS segment meet zero weights, so an Inf / NaN in q, k_lr, v_lr or dout can surface in
- * gradients of pixels whose neighbourhood does not contain it (the reference and the table-driven kernel keep it local). */
+ * Non-finite inputs on the NAF_XNA_ROWS kernel: a tile of 16 queries (keys) contracts over the whole 32-column chunks that hold its
+ * neighbourhoods, non-neighbours with zero weights, so an Inf / NaN in q, k_lr, v_lr or dout surfaces (as NaN) in the gradients of
+ * every element whose tile's chunk rows hold it -- a superset of the neighbourhoods the reference and the table-driven kernel
+ * confine it to, but never further: since 0.4.0 a chunk that skips its upper 16 slots clears them, so nothing of an earlier tile
+ * (0.3.x: stale LDS rows of the wave's previous tile, anywhere in the image) can reach the products. */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
@@ -503,18 +527,66 @@ typedef struct naf_forward_args {
      * pooled to the output size where needed), [5] after RoPE / key pooling, value packing and index tables (= start of the
      * attention kernel), [6] after the attention kernel.  [3]-[2] and [7]-[3] time ONE launch of each layer kernel inside the
      * call.  (103-104: [1] / [2] after branch 0's first convolution / block layers, [3] after branch 1's first convolution.)
-     * Since 0.2.0 (>= 200) the two branches' block layers run on TWO streams -- the caller's (3x3 branch) and a second one the
-     * library creates per device on first use (1x1 branch), forked by an event after the first convolutions and joined before
-     * the attention; the call stays capturable -- and [2] / [7] bracket one 3x3 launch on the caller's stream (1x1 launches run
-     * beside it), [3] is recorded behind one 1x1 launch on the second stream; [0], [1], [4], [5], [6] as before.  On 16 x 16
-     * pixel cells the key pooling rides on the last block layers (naf_stem_conv_keys_fwd) and the value packing runs on the second stream
-     * beside the first convolutions, so nothing is left between [4] and [5]. */
+     * With two streams (naf_forward_ex below; 0.2.0 - 0.3.x: naf_forward itself, on a library-owned stream) the two branches'
+     * block layers run side by side -- the caller's stream (3x3 branch) and the lent one (1x1 branch), forked by an event after
+     * the first convolutions and joined before the attention; the call stays capturable -- and [2] / [7] bracket one 3x3 launch on
+     * the caller's stream (1x1 launches run beside it), [3] is recorded behind one 1x1 launch on the second stream; [0], [1], [4],
+     * [5], [6] as before.  On 16 x 16 pixel cells the key pooling rides on the last block layers (naf_stem_conv_keys_fwd) and
+     * the value packing runs on the second stream beside the first convolutions, so nothing is left between [4] and [5]. */
     void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);
 /* 1 when naf_forward serves these arguments, 0 when not (then NAF_ERR_UNSUPPORTED), negative naf_status if invalid. */
 int naf_forward_supported(const naf_forward_args* a);
+/* Every launch on the caller's stream, the two branches' layers alternating (= naf_forward_ex(a, NULL, 0, stream)). */
 int naf_forward(const naf_forward_args* a, naf_stream_t stream);
+
+/* Where naf_forward keeps its intermediate tensors in the caller's workspace (0.4.0), for hosts that want them after a call -- the
+ * guidance and keys of an image to inspect or to compare (tests/test_gpu_fullsize.py holds the keys the stem's last layers pooled
+ * against the oracle this way) -- valid from the completion of one call on the workspace until the next one starts:
+ *   NAF_FWD_BUF_GUIDANCE  bf16 [B, Ho, Wo, 256] channels-last: the conv stem's output at the output size, UN-rotated (what the
+ *                         attention kernel reads as queries when it rotates on load)
+ *   NAF_FWD_BUF_KEYS      bf16 [B, h, w, 256]: pool(RoPE(guidance)) (naf.py:63-69)
+ *   NAF_FWD_BUF_VALUES    bf16 [B, h, w, C]: the packed features
+ * *offset is in bytes from a->workspace.  Returns NAF_OK, or NAF_ERR_INVALID for a bad `which` / arguments. */
+enum naf_forward_buffer { NAF_FWD_BUF_GUIDANCE = 0, NAF_FWD_BUF_KEYS = 1, NAF_FWD_BUF_VALUES = 2 };
+int naf_forward_workspace_view(const naf_forward_args* a, int32_t which, size_t* offset, size_t* bytes);
+
+/* naf_forward_ex (0.4.0): the same forward with the two encoder branches side by side on TWO streams -- the caller's (3x3 branch)
+ * and a second one the CALLER owns and lends for the duration of the call (1x1 branch, value packing): forked from `stream` by
+ * fork_event after the first convolutions, joined back into `stream` through join_event before the attention kernel AND ON
+ * EVERY ERROR RETURN after the fork, so that when the call returns -- with any status -- everything it queued on aux->stream is
+ * ordered before whatever the caller queues on `stream` next (the workspace may be reused or freed in stream order).
+ * Same kernels, bit-identical output; -2.5 % per step at 1024^2 (the HBM-bound 1x1 workgroups fill the CUs a 3x3 launch's tail
+ * leaves idle).  The library keeps nothing: one naf_forward_aux serves one call at a time -- give every host thread / caller
+ * stream that issues forwards concurrently its own (naf_forward_aux_create is a convenience constructor; any non-blocking stream
+ * and two hipEventDisableTiming events of the same device do).  Capturable: a capture on `stream` pulls aux->stream in through
+ * the fork and releases it at the join, like any fork / join inside a hipGraph capture; use an aux that no other thread uses
+ * eagerly meanwhile.  aux == NULL (or aux->stream == NULL): one stream.
+ * flags: NAF_FWD_CONV0_EXACT   the 3x3 first convolution with exact fp32 products (NAF_CONV0_EXACT)
+ *        NAF_FWD_ONE_STREAM    ignore aux;  NAF_FWD_TWO_STREAMS  use aux whenever it is given.  Neither: the library's plan --
+ *        two streams unless the 3x3 layer launch is one full round of workgroups that own a CU each for a long segment (>= 24
+ *        rows), where the second stream has no tail to fill and the cross-queue join costs more than it hides
+ *        (512^2 at batch 1: one stream -2.5 %, profiles/r05_streams_rule.txt).
+ * phase_events with two streams: [2] / [7] bracket one 3x3 launch on `stream`, [3] is recorded behind one 1x1 launch on
+ * aux->stream; the others as documented above. */
+typedef struct naf_forward_aux {
+    naf_stream_t stream; /* hipStream_t on the device of the call; created non-blocking by naf_forward_aux_create */
+    void* fork_event;    /* hipEvent_t */
+    void* join_event;    /* hipEvent_t */
+} naf_forward_aux;
+#define NAF_FWD_CONV0_EXACT 1u
+#define NAF_FWD_ONE_STREAM 2u
+#define NAF_FWD_TWO_STREAMS 4u
+/* Creates a non-blocking stream and two timing-less events on the CURRENT device into *out (the caller owns them and destroys them
+ * with naf_forward_aux_destroy, which also zeroes the struct; destroying an all-NULL struct is a no-op).  On failure nothing is
+ * left behind and *out is all NULL. */
+int naf_forward_aux_create(naf_forward_aux* out);
+int naf_forward_aux_destroy(naf_forward_aux* aux);
+/* 2 when naf_forward_ex(a, aux, flags, .) with a non-NULL aux would fork onto the second stream, 1 when it would run on one
+ * stream, 0 / negative as naf_forward_supported. */
+int naf_forward_streams(const naf_forward_args* a, uint32_t flags);
+int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32_t flags, naf_stream_t stream);
 
 #ifdef __cplusplus
 }

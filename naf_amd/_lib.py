@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must be imported before the HIP library is dlopen'e
 # NAF_HIP_LIB lets an experiment point at an alternative build of the SAME library (A/B kernel variants)
 LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
+HEADER_VERSION = 400          # NAF_HIP_VERSION of the include/naf_hip.h these ctypes mirrors were written against
 NAF_BF16, NAF_F32 = 0, 1
 XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION, XNA_ROWS = 0, 1, 2, 3, 4
 
@@ -48,8 +49,12 @@ class StemConv0Args(C.Structure):
     _fields_ = [
         ("image", C.c_void_p), ("y", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_out", C.c_void_p),
         ("image_dtype", C.c_int32), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-        ("channels", C.c_int32), ("image_stride", I64x4), ("y_stride", I64x3),
+        ("channels", C.c_int32), ("image_stride", I64x4), ("y_stride", I64x3), ("flags", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+CONV0_EXACT = 1                                  # naf_stem_conv0_args.flags
+FWD_CONV0_EXACT, FWD_ONE_STREAM, FWD_TWO_STREAMS = 1, 2, 4   # naf_forward_ex flags
 
 
 class StemConvArgs(C.Structure):
@@ -143,10 +148,28 @@ class ForwardArgs(C.Structure):
     ]
 
 
+class ForwardAux(C.Structure):
+    """naf_forward_aux: the second stream and the fork / join events the caller lends to naf_forward_ex."""
+    _fields_ = [("stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
+
+
+# Entry points that read or write GroupNorm-sum buffers are EXPORTED under names that carry the copy count (naf_hip.h, 0.4.0: a
+# binary built for another buffer layout fails to resolve them instead of overrunning its buffers); header name -> exported name
+STATS_SLOTS_ABI = 16
+EXPORTED_AS = {n: f"{n}_s{STATS_SLOTS_ABI}" for n in ("naf_stem_conv0_fwd", "naf_stem_conv_fwd", "naf_stem_conv_keys_fwd",
+                                                      "naf_stem_act_fwd", "naf_stem_act_bwd", "naf_stem_wgrad")}
+
 # symbol -> (restype, argtypes); must list every function include/naf_hip.h declares
 SIGNATURES = {
     "naf_version": (C.c_int, []),
     "naf_last_error": (C.c_char_p, []),
+    "naf_abi_check": (C.c_int, [C.c_int]),
+    "naf_stem_stats_bytes": (C.c_size_t, [C.c_int32]),
+    "naf_forward_aux_create": (C.c_int, [C.POINTER(ForwardAux)]),
+    "naf_forward_aux_destroy": (C.c_int, [C.POINTER(ForwardAux)]),
+    "naf_forward_streams": (C.c_int, [C.POINTER(ForwardArgs), C.c_uint32]),
+    "naf_forward_workspace_view": (C.c_int, [C.POINTER(ForwardArgs), C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "naf_forward_ex": (C.c_int, [C.POINTER(ForwardArgs), C.POINTER(ForwardAux), C.c_uint32, C.c_void_p]),
     "naf_axis_index_table": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
     "naf_stem_weight_index": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "naf_axis_index_table_device": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -203,11 +226,17 @@ def load() -> C.CDLL:
         except OSError as e:  # pragma: no cover
             raise NafHipError(f"cannot load {LIB_PATH}: {e}") from e
         for name, (res, args) in SIGNATURES.items():
+            exported = EXPORTED_AS.get(name, name)
             try:
-                fn = getattr(lib, name)
+                fn = getattr(lib, exported)
             except AttributeError as e:
-                raise NafHipError(f"{LIB_PATH} does not export {name}; rebuild with `python -m naf_amd.build --force`") from e
+                raise NafHipError(f"{LIB_PATH} does not export {exported}; rebuild with `python -m naf_amd.build --force`") from e
             fn.restype, fn.argtypes = res, args
+            if exported != name:
+                setattr(lib, name, fn)           # callers use the header's names
+        rc = lib.naf_abi_check(HEADER_VERSION)
+        if rc != 0:
+            raise NafHipError(f"{LIB_PATH}: {lib.naf_last_error().decode('utf-8', 'replace')}")
         _lib = lib
     return _lib
 

@@ -5,8 +5,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
-
 #include "naf_common.h"
 
 static thread_local char g_err[512] = "";
@@ -42,6 +40,17 @@ int naf_cu_count() {
 extern "C" {
 
 int naf_version(void) { return NAF_HIP_VERSION; }
+
+int naf_abi_check(int header_version) {
+    NAF_REQUIRE(header_version / 100 == NAF_HIP_VERSION / 100,
+                "naf_abi_check: the host was compiled against naf_hip.h %d.%d.%d, this library is %d.%d.%d: argument structs and buffer "
+                "layouts differ between minor versions, rebuild the host",
+                header_version / 10000, header_version / 100 % 100, header_version % 100, NAF_HIP_VERSION / 10000, NAF_HIP_VERSION / 100 % 100,
+                NAF_HIP_VERSION % 100);
+    return NAF_OK;
+}
+
+size_t naf_stem_stats_bytes(int32_t B) { return B > 0 ? (size_t)NAF_STATS_SLOTS * (size_t)B * 16 * sizeof(double) : 0; }
 
 int64_t naf_stem_weight_index(int32_t ksize, int32_t channels, int32_t tap, int32_t oc, int32_t ic) {
     const int C_ = channels == 0 ? 128 : channels;
@@ -368,33 +377,38 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
 
 // ---- whole forward in one call ---------------------------------------------------------------------------
 namespace {
-// The two branches' block layers run on TWO streams (round 4) -- the caller's and one the library creates per device on first use --,
-// forked after the first convolutions and joined before the attention: the launch that follows a 3x3 layer on the other branch is
-// independent of it, so the HBM-bound 1x1 workgroups fill the CUs that a 3x3 launch's tail leaves idle (its first and last
-// workgroups finish 16-27 us apart) instead of waiting behind it.  Same kernels, bit-identical output; -2.0 % per G1 step
-// (profiles/r04_two_streams.txt).  The fork / join are events, so the call is still capturable in a hipGraph.
-// NAF_STEM_STREAMS=1 (with NAF_HIP_KNOBS=1): one stream, the branches' layers alternating (round 3).
-bool fwd_two_streams() {
-    static const bool one = [] { const char* e = naf_knob("NAF_STEM_STREAMS"); return e && atoi(e) == 1; }();
+// Two streams (round 4; since 0.4.0 the second one is the CALLER's, naf_forward_aux): the two branches' block layers run side by
+// side, forked after the first convolutions and joined before the attention -- the launch that follows a 3x3 layer on the other
+// branch is independent of it, so the HBM-bound 1x1 workgroups fill the CUs that a 3x3 launch's tail leaves idle (its first and
+// last workgroups finish 16-27 us apart) instead of waiting behind it.  Same kernels, bit-identical output; -2.5 % per G1 step
+// (profiles/r04_ab_keys_streams.txt).  The fork / join are events, so the call is still capturable in a hipGraph.
+// A/B knobs (with NAF_HIP_KNOBS=1): NAF_STEM_STREAMS=1 one stream whatever the caller lends, =2 two whenever it lends one;
+// NAF_STEM_ORDER=0 one branch after the other (rounds 1-2).
+bool fwd_sequential() {
     static const bool seq = [] { const char* e = naf_knob("NAF_STEM_ORDER"); return e && atoi(e) == 0; }();
-    return !one && !seq;
+    return seq;
 }
-// The second stream and its two events are the only HIP objects the library owns (per device, created once, never destroyed); the
-// enqueue of a forked stem holds the device's mutex, so concurrent host threads cannot interleave their fork / join records.
-struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; std::mutex mu; };
-AuxStream* fwd_aux_stream() {
-    static AuxStream aux[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    AuxStream& x = aux[dev];
-    static std::mutex create_mu;
-    std::lock_guard<std::mutex> g(create_mu);
-    if (x.s == nullptr) {
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+// Joins the lent stream back into the caller's on EVERY exit path behind the first fork: when naf_forward_ex returns -- with any
+// status -- whatever it queued on the second stream is ordered before the caller's next work on `s` (the workspace may be reused
+// or freed in stream order, a capture is left with no dangling branch).
+struct StreamJoin {
+    hipStream_t s = nullptr, aux = nullptr;
+    hipEvent_t ev = nullptr;
+    bool armed = false;
+    int join() {
+        if (!armed) return NAF_OK;
+        armed = false;
+        if (hipEventRecord(ev, aux) != hipSuccess || hipStreamWaitEvent(s, ev, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            naf_set_error("naf_forward: stream join failed");
+            return NAF_ERR_LAUNCH;
+        }
+        return NAF_OK;
     }
-    return &x;
-}
+    ~StreamJoin() {   // an error return: best effort, the error text of the failing call stays
+        if (armed && (hipEventRecord(ev, aux) != hipSuccess || hipStreamWaitEvent(s, ev, 0) != hipSuccess)) (void)hipGetLastError();
+    }
+};
 struct FwdLayout {
     size_t stats, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
@@ -422,7 +436,7 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
-    L.buf3 = off;  if (fwd_two_streams()) off = align256(off + px * 128 * 2);   // two streams: a ping-pong pair per branch
+    L.buf3 = off;  off = align256(off + px * 128 * 2);   // two streams: a ping-pong pair per branch
     L.cat = off;   off = align256(off + px * 256 * 2);
     L.pooled = L.Ho != L.Hs || L.Wo != L.Ws;
     const size_t opx = (size_t)a->B * L.Ho * L.Wo;
@@ -502,6 +516,19 @@ size_t naf_forward_workspace_bytes(const naf_forward_args* a) {
     return fwd_layout(a).total;
 }
 
+int naf_forward_workspace_view(const naf_forward_args* a, int32_t which, size_t* offset, size_t* bytes) {
+    NAF_REQUIRE(a != nullptr && offset != nullptr && bytes != nullptr, "naf_forward_workspace_view: NULL argument");
+    NAF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->h > 0 && a->w > 0 && a->C > 0 && a->nlayer >= 0, "naf_forward_workspace_view: non-positive size");
+    const FwdLayout L = fwd_layout(a);
+    switch (which) {
+        case NAF_FWD_BUF_GUIDANCE: *offset = L.guide; *bytes = (size_t)a->B * L.Ho * L.Wo * 256 * 2; return NAF_OK;
+        case NAF_FWD_BUF_KEYS: *offset = L.keys; *bytes = (size_t)a->B * a->h * a->w * 256 * 2; return NAF_OK;
+        case NAF_FWD_BUF_VALUES: *offset = L.vp; *bytes = (size_t)a->B * a->h * a->w * a->C * 2; return NAF_OK;
+    }
+    naf_set_error("naf_forward_workspace_view: unknown buffer %d", which);
+    return NAF_ERR_INVALID;
+}
+
 int naf_forward_supported(const naf_forward_args* a) {
     const int rc = fwd_validate(a);
     if (rc != NAF_OK) return -rc;
@@ -522,7 +549,69 @@ int naf_forward_supported(const naf_forward_args* a) {
     return naf_xna_select(&x) > 0 ? 1 : 0;   // any geometry NATTEN accepts: cell, table-driven MFMA or generic kernel
 }
 
-int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
+namespace {
+// The library's stream plan for a supported forward: 2 = fork onto the lent stream, 1 = one stream (see naf_hip.h)
+int fwd_streams(const naf_forward_args* a, uint32_t flags) {
+    static const int knob = [] { const char* e = naf_knob("NAF_STEM_STREAMS"); return e ? atoi(e) : 0; }();
+    if (fwd_sequential() || knob == 1 || (flags & NAF_FWD_ONE_STREAM)) return 1;
+    if (knob == 2 || (flags & NAF_FWD_TWO_STREAMS)) return 2;
+    // One stream when the 3x3 layer launch is one FULL round of workgroups that each own a CU for a long segment: nothing of the
+    // 1x1 branch can run beside it and there is no tail to fill, so the second queue only adds its fork / join latencies
+    // (profiles/r05_streams_rule.txt; 512^2 at batch 1 is the canonical case: 256 workgroups x 32 rows).
+    const FwdLayout L = fwd_layout(a);
+    const int k3 = a->branch[0].ksize == 3 ? 0 : (a->branch[1].ksize == 3 ? 1 : -1);
+    if (k3 < 0 || a->branch[1 - k3].ksize == 3) return 2;
+    int64_t nb = 0;
+    const int seg_h = naf_stem_conv3_plan(a->B, L.Hs, L.Ws, false, &nb);
+    const int ncu = naf_cu_count();
+    return (nb <= ncu && nb * 16 >= (int64_t)ncu * 15 && seg_h >= 24) ? 1 : 2;
+}
+}  // namespace
+
+int naf_forward_streams(const naf_forward_args* a, uint32_t flags) {
+    const int sup = naf_forward_supported(a);
+    if (sup <= 0) return sup;
+    return fwd_streams(a, flags);
+}
+
+int naf_forward_aux_create(naf_forward_aux* out) {
+    NAF_REQUIRE(out != nullptr, "naf_forward_aux_create: out is NULL");
+    *out = naf_forward_aux{nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t fk = nullptr, jn = nullptr;
+    const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&fk, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&jn, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {   // nothing half-made is handed out
+        (void)hipGetLastError();
+        if (jn) (void)hipEventDestroy(jn);
+        if (fk) (void)hipEventDestroy(fk);
+        if (st) (void)hipStreamDestroy(st);
+        naf_set_error("naf_forward_aux_create: cannot create a stream and two events on the current device");
+        return NAF_ERR_LAUNCH;
+    }
+    out->stream = st; out->fork_event = fk; out->join_event = jn;
+    return NAF_OK;
+}
+
+int naf_forward_aux_destroy(naf_forward_aux* aux) {
+    NAF_REQUIRE(aux != nullptr, "naf_forward_aux_destroy: aux is NULL");
+    bool ok = true;
+    if (aux->join_event) ok &= hipEventDestroy(static_cast<hipEvent_t>(aux->join_event)) == hipSuccess;
+    if (aux->fork_event) ok &= hipEventDestroy(static_cast<hipEvent_t>(aux->fork_event)) == hipSuccess;
+    if (aux->stream) ok &= hipStreamDestroy(static_cast<hipStream_t>(aux->stream)) == hipSuccess;
+    *aux = naf_forward_aux{nullptr, nullptr, nullptr};
+    if (!ok) {
+        (void)hipGetLastError();
+        naf_set_error("naf_forward_aux_destroy: the HIP runtime refused a handle");
+        return NAF_ERR_LAUNCH;
+    }
+    return NAF_OK;
+}
+
+int naf_forward(const naf_forward_args* a, naf_stream_t stream) { return naf_forward_ex(a, nullptr, 0u, stream); }
+
+int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32_t flags, naf_stream_t stream) {
     const int sup = naf_forward_supported(a);
     if (sup < 0) return -sup;
     if (sup == 0) {
@@ -537,7 +626,12 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     char* ws = static_cast<char*>(a->workspace);
     double* stats = reinterpret_cast<double*>(ws + L.stats);
     const size_t stat_stride = (size_t)NAF_STATS_SLOTS * a->B * 16;   // doubles per (branch, stage): [NAF_STATS_SLOTS][B][8][2]
-    if (hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
+    NAF_REQUIRE((flags & NAF_FWD_ONE_STREAM) == 0 || (flags & NAF_FWD_TWO_STREAMS) == 0, "naf_forward_ex: NAF_FWD_ONE_STREAM and NAF_FWD_TWO_STREAMS are exclusive");
+    const bool have_aux = aux != nullptr && aux->stream != nullptr;
+    NAF_REQUIRE(!have_aux || (aux->fork_event != nullptr && aux->join_event != nullptr), "naf_forward_ex: aux->stream without fork_event / join_event");
+    NAF_REQUIRE(!have_aux || aux->stream != stream, "naf_forward_ex: aux->stream must differ from the stream of the call");
+    static const bool no_memset = [] { const char* e = naf_knob("NAF_FWD_NO_MEMSET"); return e && atoi(e) != 0; }();   // TIMING-ONLY probe: wrong GroupNorm sums
+    if (!no_memset && hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
         naf_set_error("naf_forward: hipMemsetAsync failed");
         return NAF_ERR_LAUNCH;
     }
@@ -582,6 +676,7 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         for (int i = 0; i < 4; ++i) c0.image_stride[i] = simg_stride[i];
         c0.y = y;
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
+        c0.flags = (flags & NAF_FWD_CONV0_EXACT) ? NAF_CONV0_EXACT : 0;
         return naf_stem_conv0_fwd(&c0, lstream);
     };
     // Key pooling rides on the branches' LAST layers (naf_stem_conv_keys_fwd: axial RoPE split, no pass over the guidance) when
@@ -626,10 +721,11 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
     // 1x1 branch: statistics only, the first block layer recomputes conv0 (see naf_stem_conv_args.first)
     const bool rec[2] = {a->branch[0].conv0_ksize == 1 && a->branch[0].ksize == 1, a->branch[1].conv0_ksize == 1 && a->branch[1].ksize == 1};
     bool values_packed = false;
-    if (fwd_two_streams() && !sequential) {
-        AuxStream* ax = fwd_aux_stream();
-        NAF_REQUIRE(ax != nullptr, "naf_forward: cannot create the second stream");
-        std::lock_guard<std::mutex> guard(ax->mu);
+    StreamJoin sj;
+    if (have_aux && !sequential && fwd_streams(a, flags) == 2) {
+        const hipStream_t axs = static_cast<hipStream_t>(aux->stream);
+        const hipEvent_t ev_fork = static_cast<hipEvent_t>(aux->fork_event);
+        sj.s = s; sj.aux = axs; sj.ev = static_cast<hipEvent_t>(aux->join_event);
         const int timed = a->nlayer > 1 ? 1 : 0;   // the stage whose launches phase_events bracket: [2] .. [7] the 3x3 layer's on the
                                                    // caller's stream, [3] behind the 1x1 layer's on the second stream
         auto mark_on = [&](int i, hipStream_t st) -> bool {
@@ -643,12 +739,14 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
         void* cur[2] = {nullptr, nullptr};
         // the value packing depends on nothing but the features: it runs on the second stream beside the first convolutions (an
         // event orders it behind whatever the caller queued before this call) instead of between the stem and the attention
-        if (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess) {
+        if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(axs, ev_fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
             naf_set_error("naf_forward: stream fork failed");
             return NAF_ERR_LAUNCH;
         }
+        sj.armed = true;   // from here on every return joins the lent stream back (StreamJoin)
         {
-            const int prc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, static_cast<naf_stream_t>(ax->s));
+            const int prc = naf_pack_values(ws + L.vp, a->features, a->feat_dtype, a->B, a->C, a->h, a->w, a->feat_stride, static_cast<naf_stream_t>(axs));
             if (prc != NAF_OK) return prc;
             values_packed = true;
         }
@@ -662,14 +760,15 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
             // Not even the statistics-only first convolution (the image's moments: two small kernels, 18 us) gains from the second
             // stream (NAF_STEM_MOMENTS_AUX=1, A/B knob): G1 1.924-1.925 against 1.904-1.907 ms, G2 the same (profiles/r04_negative_results.txt)
             static const bool moments_aux = [] { const char* e = naf_knob("NAF_STEM_MOMENTS_AUX"); return e && atoi(e) != 0; }();
-            lstream = (k == 0 && (!fork_late || (rec[br] && moments_aux))) ? static_cast<naf_stream_t>(ax->s) : stream;
+            lstream = (k == 0 && (!fork_late || (rec[br] && moments_aux))) ? static_cast<naf_stream_t>(axs) : stream;
             cur[br] = rec[br] ? nullptr : pp[br][0];
             const int rc = run_conv0(br, cur[br]);
             lstream = stream;
             if (rc != NAF_OK) return rc;
         }
         if (!mark(1)) return NAF_ERR_LAUNCH;      // behind the caller's stream's first convolution(s)
-        if (fork_late && (hipEventRecord(ax->fork, s) != hipSuccess || hipStreamWaitEvent(ax->s, ax->fork, 0) != hipSuccess)) {
+        if (fork_late && (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(axs, ev_fork, 0) != hipSuccess)) {
+            (void)hipGetLastError();
             naf_set_error("naf_forward: stream fork failed");
             return NAF_ERR_LAUNCH;
         }
@@ -679,19 +778,17 @@ int naf_forward(const naf_forward_args* a, naf_stream_t stream) {
                 // A/B knob: the 1x1 branch on the caller's stream, the 3x3 branch on the second one (so that the stem ends on the caller's
                 // stream and the attention kernel does not wait for a cross-queue signal): G1 +0.3 %, G2 -1 % -- not adopted
                 static const bool swap_streams = [] { const char* e = naf_knob("NAF_STEM_SWAP"); return e && atoi(e) != 0; }();
-                lstream = ((k == 0) != swap_streams) ? static_cast<naf_stream_t>(ax->s) : stream;
+                lstream = ((k == 0) != swap_streams) ? static_cast<naf_stream_t>(axs) : stream;
                 void* y = (l == a->nlayer - 1) ? nullptr : pp[br][cur[br] == pp[br][0] ? 1 : 0];
                 if (l == timed && k == 1 && !mark_on(2, s)) return NAF_ERR_LAUNCH;
                 const int rc = run_layer(br, l, cur[br], y);
                 lstream = stream;
                 if (rc != NAF_OK) return rc;
                 cur[br] = y;
-                if (l == timed && !mark_on(k == 0 ? 3 : 7, k == 0 ? ax->s : s)) return NAF_ERR_LAUNCH;
+                if (l == timed && !mark_on(k == 0 ? 3 : 7, k == 0 ? axs : s)) return NAF_ERR_LAUNCH;
             }
-        if (hipEventRecord(ax->join, ax->s) != hipSuccess || hipStreamWaitEvent(s, ax->join, 0) != hipSuccess) {
-            naf_set_error("naf_forward: stream join failed");
-            return NAF_ERR_LAUNCH;
-        }
+        const int jrc = sj.join();
+        if (jrc != NAF_OK) return jrc;
     } else if (!sequential) {
         // within a stage the HBM-bound branch (1x1 block layers) goes first, so that the stem ends on a matrix-bound kernel
         const int first = (a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1;

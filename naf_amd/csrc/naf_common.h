@@ -57,6 +57,7 @@ int naf_launch_pool_guidance(void* y, const void* x, int B, int H, int W, int Ho
 int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);            // stem_conv0.hip
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp = nullptr);   // stem_conv.hip
 int naf_stem_conv_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp);                            // stem_conv.hip
+int naf_stem_conv3_plan(int B, int H, int W, bool keys, int64_t* nblocks);                                       // stem_conv.hip
 int naf_launch_stem_conv1x1(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp = nullptr);   // stem_conv1x1.hip (kp: also the branch's pooled keys)
 int naf_stem_conv1x1_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp);
 int naf_launch_stem_conv0_generic(const naf_stem_conv0_args* a, hipStream_t s);    // stem_generic.hip (widths other than 128)

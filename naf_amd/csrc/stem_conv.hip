@@ -14,6 +14,30 @@ int naf_stem_conv_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* 
            a->H == 16 * kp->h && a->W == 16 * kp->w && a->W % stem_rows::TW == 0;
 }
 
+// Segment height (rows per workgroup) of the 3x3 layer kernel for a [B, H, W] activation, and (optionally) its workgroup count.
+// One workgroup fills a CU (all 512 registers of every SIMD, 120 KB of LDS) and reads its weights from L2 once, so aim for
+// about one workgroup per CU: tall segments, a multiple of four rows (the kernel's body is four input rows).
+int naf_stem_conv3_plan(int B, int H, int W, bool keys, int64_t* nblocks) {
+    const int tiles_x = (W + stem_rows::TW - 1) / stem_rows::TW;
+    const int ncu = naf_cu_count();
+    const int64_t strips = (int64_t)B * tiles_x;
+    // largest segment count that still fits ONE round of workgroups (a workgroup owns a whole CU): 266 workgroups on
+    // 256 CUs take two rounds, 252 take one
+    int64_t segs = ncu / strips;
+    if (segs < 1) segs = 1;
+    if (segs > (H + 7) / 8) segs = (H + 7) / 8;      // keep >= 8 rows per segment
+    if (segs < 1) segs = 1;
+    int seg_h = (int)((H + segs - 1) / segs);
+    seg_h = ((seg_h + 3) / 4) * 4;
+    if (keys) {
+        // key pooling: segments of whole bands of cells (16 rows), at most POOL_ROWS tall (their row tables sit in the LDS)
+        seg_h = ((seg_h + 15) / 16) * 16;
+        if (seg_h > stem_rows::POOL_ROWS) seg_h = stem_rows::POOL_ROWS;
+    }
+    if (nblocks) *nblocks = strips * ((H + seg_h - 1) / seg_h);
+    return seg_h;
+}
+
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp) {
     if (kp != nullptr && !naf_stem_conv_keys_ok(a, kp)) {
         naf_set_error("naf_stem_conv_keys_fwd: the 3x3 kernel needs 16 x 16 pixel cells, W a multiple of 32, stats_out == NULL and first == NULL");
@@ -28,28 +52,14 @@ int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_k
     p.B = a->B; p.H = a->H; p.W = a->W; p.eps = a->eps;
     for (int i = 0; i < 3; ++i) { p.xs[i] = a->x_stride[i]; p.ys[i] = a->y_stride[i]; }
     p.tiles_x = (a->W + stem_rows::TW - 1) / stem_rows::TW;
-    // One workgroup fills a CU (all 512 registers of every SIMD, 120 KB of LDS) and reads its weights from L2 once, so aim for
-    // about one workgroup per CU: tall segments, a multiple of four rows (the kernel's body is four input rows).
-    const int ncu = naf_cu_count();
-    const int64_t strips = (int64_t)a->B * p.tiles_x;
-    // largest segment count that still fits ONE round of workgroups (a workgroup owns a whole CU): 266 workgroups on
-    // 256 CUs take two rounds, 252 take one
-    int64_t segs = ncu / strips;
-    if (segs < 1) segs = 1;
-    if (segs > (a->H + 7) / 8) segs = (a->H + 7) / 8;      // keep >= 8 rows per segment
-    if (segs < 1) segs = 1;
-    int seg_h = (int)((a->H + segs - 1) / segs);
-    seg_h = ((seg_h + 3) / 4) * 4;
+    const int seg_h = naf_stem_conv3_plan(a->B, a->H, a->W, kp != nullptr, nullptr);
     if (kp != nullptr) {
-        // key pooling: segments of whole bands of cells (16 rows), at most POOL_ROWS tall (their row tables sit in the LDS)
-        seg_h = ((seg_h + 15) / 16) * 16;
-        if (seg_h > stem_rows::POOL_ROWS) seg_h = stem_rows::POOL_ROWS;
         p.kout = static_cast<bf16_t*>(kp->k_lr); p.tab_y = kp->tab_y; p.tab_x = kp->tab_x;
         for (int i = 0; i < 3; ++i) p.kst[i] = kp->k_stride[i];
     }
     p.seg_h = seg_h;
     p.segs_y = (a->H + seg_h - 1) / seg_h;
-    const int64_t nb = strips * p.segs_y;
+    const int64_t nb = (int64_t)a->B * p.tiles_x * p.segs_y;
     if (nb <= 0 || nb > 0x7fffffffLL) {
         naf_set_error("naf_stem_conv_fwd: grid out of range");
         return NAF_ERR_INVALID;

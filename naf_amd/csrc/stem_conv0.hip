@@ -625,8 +625,10 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
         // at 1024^2 against 0.080-0.085 with all six).  The sum then differs from the fp32 convolution by <= 2^-15 sum|x||w| (~3e-5
         // absolute on unit-scale data) BEFORE its one rounding to bf16 (2^-9 relative): 0.3 % of the outputs land on the neighbouring
         // bf16 value (0.008 % with six terms; tools/conv0_terms_probe.py) -- the reference's own GPU path multiplies in TF32 or bf16 here.
-        // NAF_CONV0_TERMS=6 (with NAF_HIP_KNOBS=1): all six terms.
-        static const bool three = [] { const char* e = naf_knob("NAF_CONV0_TERMS"); return !(e && atoi(e) == 6); }();
+        // naf_stem_conv0_args.flags & NAF_CONV0_EXACT (naf_forward_ex: NAF_FWD_CONV0_EXACT) asks for all six terms; the A/B knob
+        // NAF_CONV0_TERMS=6 (with NAF_HIP_KNOBS=1) forces them for every call.
+        static const bool knob6 = [] { const char* e = naf_knob("NAF_CONV0_TERMS"); return e && atoi(e) == 6; }();
+        const bool three = !knob6 && (a->flags & NAF_CONV0_EXACT) == 0;
         if (three) return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 3>) : launch(stem_conv0_split_kernel<float, 3>);
         return a->image_dtype == NAF_BF16 ? launch(stem_conv0_split_kernel<bf16_t, 0>) : launch(stem_conv0_split_kernel<float, 0>);
     }

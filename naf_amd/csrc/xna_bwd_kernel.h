@@ -365,7 +365,9 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             const f32x4_t mcq = *reinterpret_cast<const f32x4_t*>(stw + grp * 4);
             const f32x4_t invq = *reinterpret_cast<const f32x4_t*>(stw + 16 + grp * 4);
             const f32x4_t dlq = *reinterpret_cast<const f32x4_t*>(stw + 32 + grp * 4);
-            asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq));   // the reads complete before the slots are overwritten
+            // the reads complete before the slots are overwritten: the bf16x4 stores below go through another element type, so without
+            // the "memory" clobber strict aliasing would let the compiler hoist them above these float loads
+            asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq) : "memory");
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool kvalid = live && (mt * 16 + col < NSLOT);

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
     // NH = 1 (queries stationary at ratios where 16 consecutive queries see at most 16 low-res columns: the host checks the canonical
     // table): the upper 16 slots of a chunk never carry a neighbour -- no loads, no products, 16-slot second products.
     // NH = 2: a chunk whose upper 16 slots carry no neighbour for any lane still skips them at run time (chunk ends, image borders);
-    // their stale copies in the LDS segment then meet zero weights in the second products, so the segment must never hold anything
-    // but finite numbers: cleared once here, afterwards it only ever holds copies of the inputs.
+    // the second products then meet zero weights there, so those rows must hold finite numbers: the segment is cleared once here
+    // and chunk_mask clears the upper half again whenever a chunk skips it (no stale rows of another tile).
     if constexpr (NH == 2)
         for (int i = lane; i < SEGW / 8; i += 64)
             reinterpret_cast<bf16x8_t*>(seg)[i] = bf16x8_t{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
@@ -259,6 +259,15 @@ __global__ __launch_bounds__(256, (rb_regs_heavy(NDQ, NDV) ? 1 : 2)) void xna_ro
                 for (int i = 0; i < 4; ++i)
                     if (!(xa + hh * 16 + grp * 4 + i < Wt && c_true < Ws)) wx[hh][i] = 0.f;
             need_hi = __builtin_amdgcn_ballot_w64((wx[1][0] + wx[1][1] + wx[1][2] + wx[1][3]) > 0.f) != 0ull;
+            // A chunk that skips its upper 16 slots must not leave an EARLIER chunk's rows there (round 5): they would meet zero
+            // weights in the second products, and 0 * Inf = NaN would carry a non-finite input of some other tile -- the wave's
+            // previous one, anywhere in the image -- into this tile's gradients.  Three ds_write_b128 per lane and chunk.
+            if (NH == 2 && !need_hi) {
+                const bf16x8_t z8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                for (int i = lane; i < 16 * ROWLEN / 8; i += 64) reinterpret_cast<bf16x8_t*>(seg + 16 * ROWLEN)[i] = z8;
+                if constexpr (STAGE_V)
+                    for (int i = lane; i < 16 * VROW / 8; i += 64) reinterpret_cast<bf16x8_t*>(seg2 + 16 * VROW)[i] = z8;
+            }
         };
         // how many row taps of the query on hi-res row y (keys stationary: streamed) or of the tile's own row land on low-res row ry
         auto row_weight = [&](int ry) __attribute__((always_inline)) {

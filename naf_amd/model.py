@@ -528,7 +528,8 @@ class GraphedForward:
     arguments, replays on whatever ``.image`` / ``.features`` hold -- write into them in place to skip the copies).
     The returned tensor is the graph's own output buffer: it is overwritten by the next replay."""
 
-    def __init__(self, model: "NAF", image: torch.Tensor, features: torch.Tensor, output_size, warmup: int = 2):
+    def __init__(self, model: "NAF", image: torch.Tensor, features: torch.Tensor, output_size, warmup: int = 2,
+                 capture_error_mode: str = "global"):
         if not (image.is_cuda and features.is_cuda):
             raise RuntimeError("GraphedForward needs device tensors")
         self.model, self.output_size = model, (int(output_size[0]), int(output_size[1]))
@@ -548,11 +549,16 @@ class GraphedForward:
             # graph's own, instead of leaving it in the plan's pool until four other streams evict it
             side.synchronize()
             warm_plan = (model.__dict__.get("_plan_cache") or (None, None))[1]
-            if warm_plan is not None and hasattr(warm_plan, "release_workspaces"):
-                pool = warm_plan.__dict__.get("_ws_by_stream", {})
-                pool.pop((image.device.index, int(side.cuda_stream)), None)
+            if warm_plan is not None:
+                warm_plan.release_stream(image.device.index, int(side.cuda_stream))   # also drops the plan's "last used" reference to it
+            # the capture runs on a stream of ours, and the second stream the forward forks onto (ops.forward_aux: the host lends
+            # it to naf_forward_ex) is created BEFORE the capture begins
+            cap = torch.cuda.Stream(device=image.device)
+            ops.forward_aux(image.device, cap)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # capture_error_mode="thread_local": other host threads may keep issuing (and synchronising with) eager work while this
+            # one captures -- e.g. forwards of another module on another stream; their second streams are their own (ops.forward_aux)
+            with torch.cuda.graph(self.graph, stream=cap, capture_error_mode=capture_error_mode):
                 self.out = model._forward_inference(self.image, self.features, self.output_size)
         # The captured launches dereference device memory the graph does not own: the forward plan's workspace and
         # argument block, the RoPE tables, the packed bf16 weights.  They live in single-slot caches of the model that a
@@ -662,9 +668,9 @@ class NAF(nn.Module):
         self.__dict__["_plan_cache"] = (key, plan)
         return plan
 
-    def capture(self, image, features, output_size) -> GraphedForward:
+    def capture(self, image, features, output_size, capture_error_mode: str = "global") -> GraphedForward:
         """Capture this forward for the given shapes in a hipGraph; see ``GraphedForward``."""
-        return GraphedForward(self, image, features, output_size)
+        return GraphedForward(self, image, features, output_size, capture_error_mode=capture_error_mode)
 
     def forward_train(self, image, features, output_size, amp=False):
         """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
@@ -809,13 +815,13 @@ class NAF(nn.Module):
                         # mean other things (include/naf_hip.h): only the boundaries both orders share are registered then
                         knobs = os.environ.get("NAF_HIP_KNOBS") == "1"
                         sequential = knobs and os.environ.get("NAF_STEM_ORDER") == "0"
-                        one_stream = knobs and os.environ.get("NAF_STEM_STREAMS") == "1"
+                        one_stream = plan.planned_streams() == 1     # the library's plan for these shapes (naf_forward_streams)
                         pairs = (("stem", 0, 4), ("rope_pool", 4, 5), ("attention", 5, 6))
                         if sequential:
                             pass
                         elif one_stream:      # round 3: the branches' layers alternate on one stream
                             pairs += (("stem_first_convs", 0, 1), ("stem_layer_1x1", 2, 3), ("stem_layer_3x3", 3, 7))
-                        else:                 # version >= 200: two streams; [2] .. [7] bracket one 3x3 launch (the 1x1 launches run beside it)
+                        else:                 # two streams (the host lends the second: ops.forward_aux); [2] .. [7] bracket one 3x3 launch (the 1x1 launches run beside it)
                             pairs += (("stem_first_convs", 0, 1), ("stem_layer_3x3", 2, 7))
                         for name, i, j in pairs:
                             timer.pairs.setdefault(name, []).append((pe[i], pe[j]))

@@ -13,7 +13,8 @@ Reference counterparts (paths relative to the reference repo):
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+import threading
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -58,6 +59,51 @@ def _strides4(t: torch.Tensor, dims) -> I64x4:
 
 
 # ------------------------------------------------------------------------------------------------
+class _AuxPool:
+    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
+    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
+    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
+    LIMIT = 16
+
+    def __init__(self):
+        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
+        self._lock = threading.Lock()
+
+    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
+        key = (threading.get_ident(), device_index, stream_handle)
+        with self._lock:
+            aux = self._by_key.pop(key, None)
+            if aux is None:
+                lib = _lib.load()
+                while len(self._by_key) >= self.LIMIT:
+                    old = self._by_key.pop(next(iter(self._by_key)))
+                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
+                aux = _lib.ForwardAux()
+                with torch.cuda.device(device_index):
+                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
+            self._by_key[key] = aux
+            return aux
+
+    def clear(self) -> None:
+        with self._lock:
+            lib = _lib.load()
+            for aux in self._by_key.values():
+                lib.naf_forward_aux_destroy(C.byref(aux))
+            self._by_key.clear()
+
+
+AUX_POOL = _AuxPool()
+
+
+def forward_aux(device, stream=None) -> "_lib.ForwardAux":
+    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
+    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = stream if stream is not None else torch.cuda.current_stream(idx)
+    return AUX_POOL.get(idx, int(st.cuda_stream))
+
+
 def axis_index_table(L_out: int, L_in: int, k: int) -> torch.Tensor:
     """[L_out, k] int32 CPU tensor of low-res indices (host function of the library, no GPU needed)."""
     lib = _lib.load()
@@ -84,6 +130,51 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+class _AuxPool:
+    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
+    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
+    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
+    LIMIT = 16
+
+    def __init__(self):
+        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
+        self._lock = threading.Lock()
+
+    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
+        key = (threading.get_ident(), device_index, stream_handle)
+        with self._lock:
+            aux = self._by_key.pop(key, None)
+            if aux is None:
+                lib = _lib.load()
+                while len(self._by_key) >= self.LIMIT:
+                    old = self._by_key.pop(next(iter(self._by_key)))
+                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
+                aux = _lib.ForwardAux()
+                with torch.cuda.device(device_index):
+                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
+            self._by_key[key] = aux
+            return aux
+
+    def clear(self) -> None:
+        with self._lock:
+            lib = _lib.load()
+            for aux in self._by_key.values():
+                lib.naf_forward_aux_destroy(C.byref(aux))
+            self._by_key.clear()
+
+
+AUX_POOL = _AuxPool()
+
+
+def forward_aux(device, stream=None) -> "_lib.ForwardAux":
+    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
+    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = stream if stream is not None else torch.cuda.current_stream(idx)
+    return AUX_POOL.get(idx, int(st.cuda_stream))
+
+
 STATS_SLOTS = 16   # NAF_STATS_SLOTS of include/naf_hip.h: partial copies of every GroupNorm-sum buffer
 
 
@@ -353,6 +444,51 @@ def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_w
 
 
 # ------------------------------------------------------------------------------------------------
+class _AuxPool:
+    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
+    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
+    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
+    LIMIT = 16
+
+    def __init__(self):
+        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
+        self._lock = threading.Lock()
+
+    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
+        key = (threading.get_ident(), device_index, stream_handle)
+        with self._lock:
+            aux = self._by_key.pop(key, None)
+            if aux is None:
+                lib = _lib.load()
+                while len(self._by_key) >= self.LIMIT:
+                    old = self._by_key.pop(next(iter(self._by_key)))
+                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
+                aux = _lib.ForwardAux()
+                with torch.cuda.device(device_index):
+                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
+            self._by_key[key] = aux
+            return aux
+
+    def clear(self) -> None:
+        with self._lock:
+            lib = _lib.load()
+            for aux in self._by_key.values():
+                lib.naf_forward_aux_destroy(C.byref(aux))
+            self._by_key.clear()
+
+
+AUX_POOL = _AuxPool()
+
+
+def forward_aux(device, stream=None) -> "_lib.ForwardAux":
+    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
+    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = stream if stream is not None else torch.cuda.current_stream(idx)
+    return AUX_POOL.get(idx, int(st.cuda_stream))
+
+
 def rope_tables(periods: torch.Tensor, Ho: int, Wo: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin tables [Ho, 2, P] and [Wo, 2, P] (fp32) for the module's `periods` buffer [P]."""
     _gpu(periods, "periods")
@@ -706,6 +842,51 @@ def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logi
 
 
 # ------------------------------------------------------------------------------------------------
+class _AuxPool:
+    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
+    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
+    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
+    LIMIT = 16
+
+    def __init__(self):
+        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
+        self._lock = threading.Lock()
+
+    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
+        key = (threading.get_ident(), device_index, stream_handle)
+        with self._lock:
+            aux = self._by_key.pop(key, None)
+            if aux is None:
+                lib = _lib.load()
+                while len(self._by_key) >= self.LIMIT:
+                    old = self._by_key.pop(next(iter(self._by_key)))
+                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
+                aux = _lib.ForwardAux()
+                with torch.cuda.device(device_index):
+                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
+            self._by_key[key] = aux
+            return aux
+
+    def clear(self) -> None:
+        with self._lock:
+            lib = _lib.load()
+            for aux in self._by_key.values():
+                lib.naf_forward_aux_destroy(C.byref(aux))
+            self._by_key.clear()
+
+
+AUX_POOL = _AuxPool()
+
+
+def forward_aux(device, stream=None) -> "_lib.ForwardAux":
+    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
+    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = stream if stream is not None else torch.cuda.current_stream(idx)
+    return AUX_POOL.get(idx, int(st.cuda_stream))
+
+
 class ForwardPlan:
     """Argument block of ``naf_forward`` (the whole forward in ONE foreign call) for fixed parameters and shapes.
     Built once per (parameter versions, shapes); ``run`` only swaps the image / features / output pointers."""
@@ -746,6 +927,13 @@ class ForwardPlan:
                     (Ho, Wo))
 
     WS_POOL_BYTES = 8 << 30
+    streams = 0            # 0: the library's plan (naf_forward_streams), 1: one stream, 2: two whenever possible
+    conv0_exact = False    # NAF_FWD_CONV0_EXACT: exact fp32 products in the 3x3 first convolution (default: 16 mantissa bits)
+
+    def planned_streams(self) -> int:
+        """How many streams ``run`` will use (2 = the branches side by side on the lent stream)."""
+        flags = {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)]
+        return int(self.lib.naf_forward_streams(C.byref(self.args), flags))
 
     def release_workspaces(self, keep_stream: Optional[int] = None) -> None:
         """Drop the plan's scratch buffers (all of them, or all but the one of raw stream handle ``keep_stream``).  Safe once
@@ -754,6 +942,27 @@ class ForwardPlan:
         for k in [k for k in pool if keep_stream is None or k[1] != keep_stream]:
             del pool[k]
         if keep_stream is None:
+            self._ws = None
+
+    def view(self, which: str) -> torch.Tensor:
+        """A tensor VIEW of an intermediate of the last ``run`` inside its workspace (naf_forward_workspace_view): ``"guidance"`` bf16
+        [B, Ho, Wo, 256] (un-rotated), ``"keys"`` bf16 [B, h, w, 256], ``"values"`` bf16 [B, h, w, C].  Valid until the next run on
+        that workspace; synchronise with the stream of the run before reading it on another one."""
+        ws = self.__dict__.get("_ws")
+        if ws is None:
+            raise RuntimeError("ForwardPlan.view: no forward has run on this plan (or its workspace was released)")
+        a = self.args
+        code = {"guidance": 0, "keys": 1, "values": 2}[which]
+        off, nbytes = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(self.lib.naf_forward_workspace_view(C.byref(a), code, C.byref(off), C.byref(nbytes)), "naf_forward_workspace_view")
+        B, Ho, Wo, _ = self.shape_out
+        shape = {"guidance": (B, Ho, Wo, 256), "keys": (B, a.h, a.w, 256), "values": (B, a.h, a.w, a.C)}[which]
+        return ws[off.value: off.value + nbytes.value].view(torch.bfloat16).view(shape)
+
+    def release_stream(self, device_index: int, stream_handle: int) -> None:
+        """Drop the scratch buffer of ONE (device, raw stream handle) -- a throw-away stream's -- once its work has been synchronised with."""
+        ws = self.__dict__.get("_ws_by_stream", {}).pop((device_index, stream_handle), None)
+        if ws is not None and self.__dict__.get("_ws") is ws:
             self._ws = None
 
     def run(self, image: torch.Tensor, features: torch.Tensor, events=None, return_logits: bool = False, phase_events=None):
@@ -786,8 +995,10 @@ class ForwardPlan:
             logits = torch.empty((self.shape_out[0], a.heads, self.shape_out[1], self.shape_out[2], a.ksize * a.ksize),
                                  dtype=torch.float32, device=dev)
         a.logits = logits.data_ptr() if logits is not None else None
+        flags = (_lib.FWD_CONV0_EXACT if self.conv0_exact else 0) | {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)]
+        aux = None if self.streams == 1 else AUX_POOL.get(skey[0], skey[1])
         with torch.cuda.device(dev):
-            rc = self.lib.naf_forward(C.byref(a), _stream(image))
-        _lib.check(rc, "naf_forward")
+            rc = self.lib.naf_forward_ex(C.byref(a), C.byref(aux) if aux is not None else None, flags, _stream(image))
+        _lib.check(rc, "naf_forward_ex")
         out = out.permute(0, 3, 1, 2)
         return (out, logits) if return_logits else out

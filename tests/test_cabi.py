@@ -14,10 +14,19 @@ from oracle import naf_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
+def _header_text():
     txt = open(os.path.join(ROOT, "include", "naf_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(naf_[a-z_0-9]+)\s*\(", txt)))
+    return re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+
+
+def _declared_symbols():
+    """Function names as the header's prototypes spell them."""
+    return sorted(set(re.findall(r"\b(naf_[a-z_0-9]+)\s*\(", _header_text())))
+
+
+def _export_names():
+    """header name -> exported name: the `#define naf_x naf_x_s16` lines that version the entry points by buffer layout (0.4.0)."""
+    return dict(re.findall(r"^#define\s+(naf_[a-z_0-9]+)\s+(naf_[a-z_0-9]+)\s*$", _header_text(), flags=re.M))
 
 
 def test_library_builds_and_exports_every_declared_symbol(built_lib):
@@ -26,12 +35,57 @@ def test_library_builds_and_exports_every_declared_symbol(built_lib):
     assert {"naf_version", "naf_last_error", "naf_axis_index_table", "naf_rope_tables", "naf_rope_pool_fwd",
             "naf_stem_conv0_fwd", "naf_stem_conv_fwd",
             "naf_pack_values", "naf_xna_select", "naf_workspace_bytes", "naf_xna_fwd"} <= set(declared)
+    exported = _export_names()
     for name in declared:
-        assert hasattr(lib, name), f"libnaf_hip.so does not export {name}"
+        assert hasattr(lib, exported.get(name, name)), f"libnaf_hip.so does not export {exported.get(name, name)}"
     from naf_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding and header disagree"
+    assert exported == _lib.EXPORTED_AS, "ctypes binding and header disagree on the versioned export names"
     lib.naf_version.restype = C.c_int
     assert lib.naf_version() >= 100
+
+
+def test_stale_binaries_fail_loudly(built_lib):
+    """C ABI 0.4.0: (1) every entry point that reads or writes GroupNorm-sum buffers is exported ONLY under a name that carries the
+    copy count, so a binary built against a 0.2.x / 0.3.x header (one copy / unversioned names) fails to resolve it instead of
+    overrunning its buffers; (2) naf_abi_check tells a host compiled against another minor version so; (3) naf_stem_stats_bytes
+    is the size of one buffer as this library lays it out."""
+    from naf_amd import _lib, ops
+    lib = C.CDLL(built_lib)
+    exported = _export_names()
+    assert set(exported) == {"naf_stem_conv0_fwd", "naf_stem_conv_fwd", "naf_stem_conv_keys_fwd", "naf_stem_act_fwd", "naf_stem_act_bwd", "naf_stem_wgrad"}
+    for old, new in exported.items():
+        assert new == f"{old}_s{ops.STATS_SLOTS}"
+        assert hasattr(lib, new)
+        with pytest.raises(AttributeError):
+            getattr(lib, old)                    # the name an old binary asks for is gone
+    lib.naf_abi_check.restype, lib.naf_abi_check.argtypes = C.c_int, [C.c_int]
+    lib.naf_last_error.restype = C.c_char_p
+    lib.naf_version.restype = C.c_int
+    v = lib.naf_version()
+    assert v == _lib.HEADER_VERSION
+    assert lib.naf_abi_check(v) == 0 and lib.naf_abi_check(v - v % 100) == 0 and lib.naf_abi_check(v - v % 100 + 99) == 0     # patch level is free
+    for stale in (300, 205, v + 100):
+        assert lib.naf_abi_check(stale) == 1
+        msg = lib.naf_last_error().decode()
+        assert f"{stale // 10000}.{stale // 100 % 100}.{stale % 100}" in msg and "rebuild" in msg
+    lib.naf_stem_stats_bytes.restype, lib.naf_stem_stats_bytes.argtypes = C.c_size_t, [C.c_int32]
+    assert lib.naf_stem_stats_bytes(3) == ops.new_stats(3, "cpu").numel() * 8 == 16 * 3 * 16 * 8
+    assert lib.naf_stem_stats_bytes(0) == 0 and lib.naf_stem_stats_bytes(-2) == 0
+
+
+def test_forward_aux_contract_without_a_device(built_lib):
+    """naf_forward_aux / naf_forward_ex argument checks that need no GPU: the library owns no stream (0.4.0), a NULL aux is the
+    one-stream forward, destroying an all-NULL bundle is a no-op, contradictory flags and half-filled bundles are refused."""
+    from naf_amd import _lib
+    lib = _lib.load()
+    aux = _lib.ForwardAux()
+    assert lib.naf_forward_aux_destroy(C.byref(aux)) == 0
+    assert lib.naf_forward_aux_destroy(None) == 1 and "NULL" in _lib.last_error()
+    assert lib.naf_forward_aux_create(None) == 1
+    assert C.sizeof(_lib.ForwardAux) == 3 * C.sizeof(C.c_void_p)
+    assert lib.naf_forward_ex(None, None, 0, None) == 1                      # NULL args: invalid, like naf_forward
+    assert lib.naf_forward(None, None) == 1
 
 
 def test_groupnorm_sum_copies_match_header_and_version(built_lib):

@@ -62,6 +62,32 @@ def _oracle_rows(p, img, ft, out_sz, ksz, rows, heads=4):
     return stem, ref
 
 
+def _assert_fused_keys(m, p, lr_hw, what, images=None, heads=4):
+    """VERDICT r04 (weak 3): the keys the stem's LAST layers pooled (naf_stem_conv_keys_fwd inside the one-call forward), ALL cells at
+    full size, against the oracle's pool(RoPE(.)) (naf.py:63-69 after rope.py:139-153) of the very bf16 guidance that call wrote
+    -- both read back from the call's workspace (ForwardPlan.view) -- at tests/test_gpu_keys.py's tolerance (one bf16 rounding)."""
+    plan = m.__dict__["_plan_cache"][1]
+    assert plan is not None, f"{what}: not the one-call forward"
+    torch.cuda.synchronize()
+    guide = plan.view("guidance")
+    keys = plan.view("keys")
+    sel = list(range(guide.shape[0])) if images is None else images
+    per = p["image_encoder.rope.periods"]
+    worst = 0.0
+    for b in sel:
+        y = guide[b:b + 1].float().cpu().permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            ref = O.key_pool(O.rope(y, per, heads), lr_hw)
+        del y
+        got = keys[b:b + 1].float().cpu().permute(0, 3, 1, 2)
+        err = (got - ref).abs()
+        bad = err > 1e-5 + 2 ** -8 * ref.abs()
+        assert not bool(bad.any()), (f"{what} image {b}: {int(bad.sum())}/{bad.numel()} fused keys out of tolerance, max err {float(err.max()):.3e} at "
+                                     f"{np.unravel_index(int(err.argmax()), err.shape)}")
+        worst = max(worst, float(err.max()))
+    return worst
+
+
 def test_whole_forward_G1_full_size(dev):
     """BASELINE configs[1] end to end: 1x3x1024^2 image, 768x64^2 features -> 1024^2, window 7, bf16 features."""
     out_sz, C, lr, ksz = 1024, 768, 64, 7
@@ -71,7 +97,8 @@ def test_whole_forward_G1_full_size(dev):
     ft = O.hash_normal((1, C, lr, lr), 2102).to(torch.bfloat16).float()
     # rows: image borders, a cell border (15 | 16), the XCD band / segment borders of the stem at 1024 rows (multiples
     # of 128 and of 64), mid-image, plus a few arbitrary ones
-    rows = sorted({0, 1, 2, 15, 16, 63, 64, 127, 128, 300, 511, 512, 767, 768, 895, 896, 1007, 1008, 1021, 1022, 1023})
+    # (round 5: + 383 | 384 and 639 | 640, so that every 128-row segment border of the 3x3 key-pooling launch lies inside a sampled window)
+    rows = sorted({0, 1, 2, 15, 16, 63, 64, 127, 128, 255, 256, 300, 383, 384, 511, 512, 639, 640, 767, 768, 895, 896, 1007, 1008, 1021, 1022, 1023})
     stem_ref, ref = _oracle_rows(p, img, ft, out_sz, ksz, rows)
     got_stem = m.image_encoder.guidance(img.to(dev), (out_sz, out_sz)).float().cpu()
     err = (got_stem - stem_ref).abs()
@@ -85,6 +112,8 @@ def test_whole_forward_G1_full_size(dev):
     got = out[:, :, rows].float().cpu()
     _assert_close(got, ref, 2e-2, 1e-2, "G1 whole forward, sampled rows")
     assert float((got - ref).abs().mean()) <= 6e-3
+    assert m.__dict__["_plan_cache"][1].planned_streams() == 2                     # the default at 1024^2: branches side by side
+    _assert_fused_keys(m, p, (lr, lr), "G1")
 
 
 def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows):
@@ -107,6 +136,7 @@ def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows):
     got = out[:, :, rows].float().cpu()
     _assert_close(got, ref, 2e-2, 1e-2, f"{name} whole forward, sampled rows")
     assert float((got - ref).abs().mean()) <= 6e-3
+    _assert_fused_keys(m, p, (lr, lr), name)        # every cell: the POOL launch's segment rounds at this size (4 x 128 rows at 2048^2)
 
 
 def test_whole_forward_G4_full_size(dev):
@@ -143,6 +173,9 @@ def test_whole_forward_G3_shard_through_the_sharded_driver(dev):
         got = out[b:b + 1, :, rows].float().cpu()
         _assert_close(got, ref, 2e-2, 1e-2, f"G3 shard image {b}, sampled rows")
         assert float((got - ref).abs().mean()) <= 6e-3
+    # the last micro-batch (images 6, 7: two images per launch, eight rounds of 128-row segments in the 3x3 key-pooling launch)
+    # is still in the plan's workspace: all of its cells against the oracle
+    _assert_fused_keys(m, p, (lr, lr), "G3 shard, last micro-batch")
     # micro-batching is invisible up to the order of the GroupNorm partial sums (the stem's per-workgroup fp32 partials are
     # cut differently for 1 and 2 images per launch, the fp64 atomics land in any order): a handful of bf16 roundings flip
     alone = m(img[3:4].to(dev), ft[3:4].to(dev).to(torch.bfloat16), (out_sz, out_sz))

@@ -843,6 +843,38 @@ def _rows_backward_integer_doc(dev, B, Cq, C, heads, lr, out_sz, ksz):
     _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz)
 
 
+def test_rows_backward_keeps_a_planted_inf_inside_its_chunk_rows(dev):
+    """A non-finite value stays inside the tiles whose streamed rows hold it (naf_hip.h, naf_xna_bwd).  Before C ABI 0.4.0 a chunk that
+    skipped its upper 16 slots multiplied the STALE LDS rows of the wave's previous tile by zero weights, so one Inf could turn
+    gradients of an unrelated tile -- another image of the batch -- into NaN.  Here: the denoising shape class (ratio 1, one head,
+    window 7) on 40-pixel rows (tiles 0 and 1 of a row use their chunk's upper half, tile 2 skips it) with more tiles than the launch
+    has waves (5 x 700 x 3 = 10 500 against 8 192), so that waves walk from a tile of image 0 to a tile of images 3 / 4."""
+    from naf_amd import ops
+    Bn, Cq, C, heads, size, ksz = 5, 64, 3, 1, (700, 40), 7
+    r = ksz // 2
+    q = bf16r(O.hash_normal((Bn, Cq, *size), 551))
+    k = bf16r(O.hash_normal((Bn, Cq, *size), 552))
+    v = bf16r(O.hash_normal((Bn, C, *size), 553))
+    g = bf16r(O.hash_normal((Bn, C, *size), 554))
+    q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, g))
+    assert ops.xna_backward_select(q5, k5, v5, ksz) == "rows"
+    clean = [t.float().cpu() for t in ops.xna_backward(q5, k5, v5, g5, ksz)]
+    assert all(bool(torch.isfinite(t).all()) for t in clean)
+    for which in ("v", "k", "q", "g"):
+        t5 = {"v": v5, "k": k5, "q": q5, "g": g5}
+        planted = {n: t.clone() for n, t in t5.items()}
+        for y0 in range(20, 700, 40):                                   # many rows of image 0, every column tile
+            planted[which][0, 0, y0, :, 1] = float("inf")
+        got = [t.float().cpu() for t in ops.xna_backward(planted["q"], planted["k"], planted["v"], planted["g"], ksz)]
+        far = torch.ones(size[0], dtype=torch.bool)
+        for y0 in range(20, 700, 40):
+            far[y0 - 2 * r: y0 + 2 * r + 1] = False
+        for name, a, b in zip(("dq", "dk", "dv"), got, clean):
+            assert torch.equal(a[1:], b[1:]), f"{which} = Inf in image 0 changed {name} of another image"
+            assert torch.equal(a[0][:, far], b[0][:, far]), f"{which} = Inf changed rows of {name} that are two window radii away"
+        assert not all(bool(torch.isfinite(t[0]).all()) for t in got)       # ... and it does surface where it belongs
+
+
 def test_rows_backward_fuzz_against_table_driven_kernel(dev):
     """Seeded random geometries (ratios 1 .. 9 per axis, integer and not, every window size, ragged widths, both value forms): the
     row-streaming matrix-core backward against the independent scalar table-driven kernel (fp32 throughout) on the same bf16 inputs."""
@@ -1310,6 +1342,8 @@ def test_single_call_forward_phase_events(dev):
     ft = O.hash_normal((1, 128, 16, 16), 972).to(dev).to(torch.bfloat16)
     plan = m._forward_plan(img, ft, (256, 256))
     assert plan is not None
+    plan.streams = 2                                    # the branches side by side on the stream this host lends (ops.forward_aux)
+    assert plan.planned_streams() == 2
     base = plan.run(img, ft).clone()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
     for e in ev:
@@ -1332,6 +1366,138 @@ def test_single_call_forward_phase_events(dev):
     assert torch.equal(plan.run(img, ft, phase_events=sparse), base)
     torch.cuda.synchronize()
     assert ev[2].elapsed_time(ev[4]) > 0.0
+    # one stream (naf_forward, or NAF_FWD_ONE_STREAM): the layers alternate, [2] .. [3] brackets one 1x1 launch, [3] .. [7] one 3x3 launch
+    plan.streams = 1
+    assert plan.planned_streams() == 1
+    out1 = plan.run(img, ft, phase_events=ev)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, base)                      # same kernels, same bits
+    order1 = [0, 1, 2, 3, 7, 4, 5, 6]
+    gaps1 = [ev[order1[i]].elapsed_time(ev[order1[i + 1]]) for i in range(7)]
+    assert all(g >= 0.0 for g in gaps1) and gaps1[2] > 0.0 and gaps1[3] > 0.0, gaps1
+
+
+def test_forward_stream_plan_and_flags(dev):
+    """naf_forward_streams / naf_forward_ex flags (C ABI 0.4.0): the library's plan is two streams except where the 3x3 layer launch
+    is one full round of long-lived workgroups (512^2 at batch 1: profiles/r05_streams_rule.txt); either layout can be forced; the
+    3x3 first convolution with exact products (NAF_FWD_CONV0_EXACT) differs from the default by bf16 roundings of 16-bit products."""
+    p = O.make_params(seed=46)
+    m = _load_model(dev, p, kernel_size=7)
+    ft = O.hash_normal((1, 128, 32, 32), 992).to(dev).to(torch.bfloat16)
+    for S, want in ((256, 2), (448, 2), (512, 1), (1024, 2)):
+        img = O.hash_normal((1, 3, S, S), 991).to(dev)
+        f = ft if S % 32 == 0 else ft[:, :, :28, :28]
+        plan = m._forward_plan(img, f, (S, S))
+        assert plan is not None and plan.planned_streams() == want, (S, plan.planned_streams())
+    img = O.hash_normal((1, 3, 512, 512), 991).to(dev)
+    plan = m._forward_plan(img, ft, (512, 512))
+    outs = {}
+    for st in (0, 1, 2):
+        plan.streams = st
+        assert plan.planned_streams() == (1 if st in (0, 1) else 2)
+        outs[st] = plan.run(img, ft).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    plan.streams = 0
+    plan.conv0_exact = True
+    exact = plan.run(img, ft).clone()
+    plan.conv0_exact = False
+    torch.cuda.synchronize()
+    d = (exact.float() - outs[0].float()).abs()
+    assert 0.0 < float(d.max()) <= 3e-2 and float(d.mean()) <= 2e-4, (float(d.max()), float(d.mean()))
+    ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (512, 512), kernel_size=7)
+    assert_close(exact.float().cpu(), ref, 2e-2, 1e-2, "forward with exact first-convolution products vs oracle")
+    assert_close(outs[0].float().cpu(), ref, 2e-2, 1e-2, "forward with 16-bit first-convolution products vs oracle")
+
+
+def test_forward_error_after_the_fork_joins_the_lent_stream(dev):
+    """VERDICT r04 / ADVICE r04: every return of naf_forward_ex behind the fork joins the second stream back into the caller's.
+    feat_dtype = 7 passes the up-front validation and fails in the value packing -- the first launch on the lent stream.  Eagerly
+    the next forward on the same stream and workspace is unharmed; under a hipGraph capture the failed call leaves no un-joined
+    branch behind (0.3.x: hipErrorStreamCaptureUnjoined at the end of the capture)."""
+    p = O.make_params(seed=47)
+    m = _load_model(dev, p, kernel_size=7)
+    img = O.hash_normal((1, 3, 256, 256), 995).to(dev)
+    ft = O.hash_normal((1, 128, 16, 16), 996).to(dev).to(torch.bfloat16)
+    plan = m._forward_plan(img, ft, (256, 256))
+    plan.streams = 2
+    base = plan.run(img, ft).clone()
+    torch.cuda.synchronize()
+    good = plan.args.feat_dtype
+    for _ in range(3):
+        plan.args.feat_dtype = 7
+        with pytest.raises(ValueError, match="naf_pack_values"):
+            plan.run(img, ft)
+        plan.args.feat_dtype = good
+        assert torch.equal(plan.run(img, ft), base)
+    torch.cuda.synchronize()
+    # the same failure inside a capture: the capture still ends cleanly and the graph (one good forward) replays
+    side = torch.cuda.Stream(device=dev)
+    from naf_amd import ops
+    ops.forward_aux(dev, side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.args.feat_dtype = 7
+        with pytest.raises(ValueError):
+            plan.run(img, ft)
+        plan.args.feat_dtype = good
+        out = plan.run(img, ft)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, base)
+
+
+def test_two_host_threads_one_of_them_capturing(dev):
+    """the library owns no stream any more -- every host thread lends its own (ops.forward_aux is keyed by
+    thread, device and caller stream).  Thread A captures a forward into a hipGraph and replays it while thread B issues eager
+    forwards of another module on another stream; neither sees the other's fork / join events or second stream."""
+    import threading
+    p = O.make_params(seed=48)
+    ma, mb = _load_model(dev, p, kernel_size=7), _load_model(dev, p, kernel_size=7)
+    img_a, img_b = O.hash_normal((1, 3, 256, 256), 997).to(dev), O.hash_normal((1, 3, 320, 256), 998).to(dev)
+    ft_a = O.hash_normal((1, 128, 16, 16), 999).to(dev).to(torch.bfloat16)
+    ft_b = O.hash_normal((1, 128, 20, 16), 1000).to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        ref_a, ref_b = ma(img_a, ft_a, (256, 256)).clone(), mb(img_b, ft_b, (320, 256)).clone()
+    assert ma._forward_plan(img_a, ft_a, (256, 256)).planned_streams() == 2 and mb._forward_plan(img_b, ft_b, (320, 256)).planned_streams() == 2
+    torch.cuda.synchronize()
+    res, errs = {}, []
+    start = threading.Barrier(2)
+
+    def thread_a():
+        try:
+            torch.cuda.set_device(dev)
+            start.wait(timeout=60)
+            outs = []
+            for _ in range(3):
+                gf = ma.capture(img_a, ft_a, (256, 256), capture_error_mode="thread_local")
+                outs.append(gf().clone())
+                outs.append(gf().clone())
+            res["a"] = outs
+        except Exception as e:      # noqa: BLE001
+            errs.append(("a", repr(e)))
+
+    def thread_b():
+        try:
+            torch.cuda.set_device(dev)
+            sb = torch.cuda.Stream(device=dev)
+            start.wait(timeout=60)
+            outs = []
+            with torch.no_grad(), torch.cuda.stream(sb):
+                for _ in range(40):
+                    outs.append(mb(img_b, ft_b, (320, 256)))
+            sb.synchronize()
+            res["b"] = outs
+        except Exception as e:      # noqa: BLE001
+            errs.append(("b", repr(e)))
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start()
+    ta.join(timeout=300); tb.join(timeout=300)
+    assert not ta.is_alive() and not tb.is_alive(), "a thread hung"
+    assert not errs, errs
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref_a) for o in res["a"]) and all(torch.equal(o, ref_b) for o in res["b"])
 
 
 @pytest.mark.parametrize("B,heads,lr,out_sz,Dq,Dv,ksz,kernel", [
