@@ -50,6 +50,8 @@ WORKLOADS = {
     # the reference's own published timing point (test/test_results.json:243-256, A100-40GB, fp32):
     # image 448^2, DINO-S features 384 x 28^2 -> 448^2, NAF() default window 9: 56.24 ms = 3.57 Mpix/s
     "REF448": (384, 28, 448, 9),
+    # VERDICT r04 item 3's small-image line: 256^2, C = 768, 16^2 features, window 7
+    "S256": (768, 16, 256, 7),
 }
 PUBLISHED_MPIX = {"REF448": 3.57}   # BASELINE.md numbers for the exact configuration (other hardware)
 

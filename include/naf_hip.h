@@ -565,9 +565,10 @@ int naf_forward_workspace_view(const naf_forward_args* a, int32_t which, size_t*
  * eagerly meanwhile.  aux == NULL (or aux->stream == NULL): one stream.
  * flags: NAF_FWD_CONV0_EXACT   the 3x3 first convolution with exact fp32 products (NAF_CONV0_EXACT)
  *        NAF_FWD_ONE_STREAM    ignore aux;  NAF_FWD_TWO_STREAMS  use aux whenever it is given.  Neither: the library's plan --
- *        two streams unless the 3x3 layer launch is one full round of workgroups that own a CU each for a long segment (>= 24
- *        rows), where the second stream has no tail to fill and the cross-queue join costs more than it hides
- *        (512^2 at batch 1: one stream -2.5 %, profiles/r05_streams_rule.txt).
+ *        two streams unless the 3x3 layer launch takes every CU in one round of short segments (12 .. 40 rows per workgroup:
+ *        512^2 at batch 1, 256^2 at batch 2 or 4), where nothing of the 1x1 branch can run beside it and its workgroups then
+ *        stand in the next 3x3 launch's way: one stream -2 ... -4.5 % there, two streams -1.5 ... -13 % everywhere else
+ *        (interleaved sweep over sizes and batches, profiles/r05_streams_rule.txt).
  * phase_events with two streams: [2] / [7] bracket one 3x3 launch on `stream`, [3] is recorded behind one 1x1 launch on
  * aux->stream; the others as documented above. */
 typedef struct naf_forward_aux {

@@ -410,7 +410,7 @@ struct StreamJoin {
     }
 };
 struct FwdLayout {
-    size_t stats, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t stats, mom, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
     int Ho, Wo;   // output size
@@ -433,6 +433,7 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.img = off;
     if (L.shrunk) off = align256(off + px * 3 * sizeof(float));
     L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * NAF_STATS_SLOTS * a->B * 16 * sizeof(double));
+    L.mom = off;   off = align256(off + naf_conv0_moments_scratch_bytes(a->B));   // partial image moments of the 1x1 branch's statistics-only first convolution
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
@@ -555,16 +556,19 @@ int fwd_streams(const naf_forward_args* a, uint32_t flags) {
     static const int knob = [] { const char* e = naf_knob("NAF_STEM_STREAMS"); return e ? atoi(e) : 0; }();
     if (fwd_sequential() || knob == 1 || (flags & NAF_FWD_ONE_STREAM)) return 1;
     if (knob == 2 || (flags & NAF_FWD_TWO_STREAMS)) return 2;
-    // One stream when the 3x3 layer launch is one FULL round of workgroups that each own a CU for a long segment: nothing of the
-    // 1x1 branch can run beside it and there is no tail to fill, so the second queue only adds its fork / join latencies
-    // (profiles/r05_streams_rule.txt; 512^2 at batch 1 is the canonical case: 256 workgroups x 32 rows).
+    // One stream when the 3x3 layer launch takes EVERY CU (a workgroup owns a whole CU) in one round of SHORT segments, 12 .. 40 rows:
+    // nothing of the 1x1 branch can start beside such a launch, and the 1x1 workgroups that move in as its CUs drain then hold
+    // registers / LDS the next 3x3 launch needs whole -- with launches of <= ~60 us that stall outweighs the tail they fill.
+    // Interleaved sweep, two / one stream per forward (profiles/r05_streams_rule.txt): 256 wg x 16 rows 1.046, 256 x 32 1.019-1.022;
+    // but 256 x 8 0.866 (launches of ~15 us: the second queue hides launch latency), 256 x 64 0.979, 256 x 128 0.985 (long
+    // segments: tail filling wins), and every launch that leaves CUs free (224 .. 252 wg) 0.875-0.983.
     const FwdLayout L = fwd_layout(a);
     const int k3 = a->branch[0].ksize == 3 ? 0 : (a->branch[1].ksize == 3 ? 1 : -1);
     if (k3 < 0 || a->branch[1 - k3].ksize == 3) return 2;
     int64_t nb = 0;
     const int seg_h = naf_stem_conv3_plan(a->B, L.Hs, L.Ws, false, &nb);
     const int ncu = naf_cu_count();
-    return (nb <= ncu && nb * 16 >= (int64_t)ncu * 15 && seg_h >= 24) ? 1 : 2;
+    return (nb <= ncu && nb > ncu - 4 && seg_h >= 12 && seg_h <= 40) ? 1 : 2;
 }
 }  // namespace
 
@@ -630,8 +634,17 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
     const bool have_aux = aux != nullptr && aux->stream != nullptr;
     NAF_REQUIRE(!have_aux || (aux->fork_event != nullptr && aux->join_event != nullptr), "naf_forward_ex: aux->stream without fork_event / join_event");
     NAF_REQUIRE(!have_aux || aux->stream != stream, "naf_forward_ex: aux->stream must differ from the stream of the call");
-    static const bool no_memset = [] { const char* e = naf_knob("NAF_FWD_NO_MEMSET"); return e && atoi(e) != 0; }();   // TIMING-ONLY probe: wrong GroupNorm sums
-    if (!no_memset && hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
+    // The GroupNorm-sum buffers start at zero.  Default architecture (round 5): the FIRST launch of the forward is the 1x1 branch's
+    // statistics-only first convolution (image moments), and that kernel zeroes them on its way (its own nine sums travel as
+    // per-workgroup partials in the workspace, nothing to zero for them) -- no hipMemsetAsync, whose fill kernel sat in front of the stem.
+    // Anything else (a first launch that adds into the sums by atomics): the memset.  NAF_FWD_MEMSET=1 (with NAF_HIP_KNOBS=1): always (A/B).
+    const bool rec0[2] = {a->branch[0].conv0_ksize == 1 && a->branch[0].ksize == 1, a->branch[1].conv0_ksize == 1 && a->branch[1].ksize == 1};
+    const int first_launched = fwd_sequential() ? 0 : ((a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1);
+    static const bool force_memset = [] { const char* e = naf_knob("NAF_FWD_MEMSET"); return e && atoi(e) != 0; }();
+    static const bool stats_knobs = [] { return naf_knob("NAF_STEM_FORK_EARLY") != nullptr || naf_knob("NAF_STEM_MOMENTS_AUX") != nullptr; }();
+    const size_t nstats = (size_t)2 * (a->nlayer + 1) * stat_stride;
+    bool zero_by_moments = rec0[first_launched] && !force_memset && !stats_knobs && nstats <= 0x7fffffffu;
+    if (!zero_by_moments && hipMemsetAsync(stats, 0, nstats * sizeof(double), s) != hipSuccess) {
         naf_set_error("naf_forward: hipMemsetAsync failed");
         return NAF_ERR_LAUNCH;
     }
@@ -677,6 +690,10 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
         c0.y = y;
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
         c0.flags = (flags & NAF_FWD_CONV0_EXACT) ? NAF_CONV0_EXACT : 0;
+        if (zero_by_moments && br == first_launched) {   // the forward's first launch: image moments + zeroing of every GroupNorm-sum buffer
+            zero_by_moments = false;                     // (once)
+            return naf_launch_stem_conv0(&c0, static_cast<hipStream_t>(lstream), reinterpret_cast<double*>(ws + L.mom), stats, (int)nstats);
+        }
         return naf_stem_conv0_fwd(&c0, lstream);
     };
     // Key pooling rides on the branches' LAST layers (naf_stem_conv_keys_fwd: axial RoPE split, no pass over the guidance) when

@@ -1384,9 +1384,9 @@ def test_forward_stream_plan_and_flags(dev):
     p = O.make_params(seed=46)
     m = _load_model(dev, p, kernel_size=7)
     ft = O.hash_normal((1, 128, 32, 32), 992).to(dev).to(torch.bfloat16)
-    for S, want in ((256, 2), (448, 2), (512, 1), (1024, 2)):
+    for S, want in ((256, 2), (448, 2), (512, 1), (640, 2), (1024, 2)):
         img = O.hash_normal((1, 3, S, S), 991).to(dev)
-        f = ft if S % 32 == 0 else ft[:, :, :28, :28]
+        f = ft if S % 32 == 0 else ft[:, :, :S // 16, :S // 16]
         plan = m._forward_plan(img, f, (S, S))
         assert plan is not None and plan.planned_streams() == want, (S, plan.planned_streams())
     img = O.hash_normal((1, 3, 512, 512), 991).to(dev)
