@@ -410,7 +410,7 @@ struct StreamJoin {
     }
 };
 struct FwdLayout {
-    size_t stats, mom, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t stats, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
     int Ho, Wo;   // output size
@@ -433,7 +433,6 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.img = off;
     if (L.shrunk) off = align256(off + px * 3 * sizeof(float));
     L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * NAF_STATS_SLOTS * a->B * 16 * sizeof(double));
-    L.mom = off;   off = align256(off + naf_conv0_moments_scratch_bytes(a->B));   // partial image moments of the 1x1 branch's statistics-only first convolution
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
@@ -634,17 +633,11 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
     const bool have_aux = aux != nullptr && aux->stream != nullptr;
     NAF_REQUIRE(!have_aux || (aux->fork_event != nullptr && aux->join_event != nullptr), "naf_forward_ex: aux->stream without fork_event / join_event");
     NAF_REQUIRE(!have_aux || aux->stream != stream, "naf_forward_ex: aux->stream must differ from the stream of the call");
-    // The GroupNorm-sum buffers start at zero.  Default architecture (round 5): the FIRST launch of the forward is the 1x1 branch's
-    // statistics-only first convolution (image moments), and that kernel zeroes them on its way (its own nine sums travel as
-    // per-workgroup partials in the workspace, nothing to zero for them) -- no hipMemsetAsync, whose fill kernel sat in front of the stem.
-    // Anything else (a first launch that adds into the sums by atomics): the memset.  NAF_FWD_MEMSET=1 (with NAF_HIP_KNOBS=1): always (A/B).
-    const bool rec0[2] = {a->branch[0].conv0_ksize == 1 && a->branch[0].ksize == 1, a->branch[1].conv0_ksize == 1 && a->branch[1].ksize == 1};
-    const int first_launched = fwd_sequential() ? 0 : ((a->branch[0].ksize <= a->branch[1].ksize) ? 0 : 1);
-    static const bool force_memset = [] { const char* e = naf_knob("NAF_FWD_MEMSET"); return e && atoi(e) != 0; }();
-    static const bool stats_knobs = [] { return naf_knob("NAF_STEM_FORK_EARLY") != nullptr || naf_knob("NAF_STEM_MOMENTS_AUX") != nullptr; }();
-    const size_t nstats = (size_t)2 * (a->nlayer + 1) * stat_stride;
-    bool zero_by_moments = rec0[first_launched] && !force_memset && !stats_knobs && nstats <= 0x7fffffffu;
-    if (!zero_by_moments && hipMemsetAsync(stats, 0, nstats * sizeof(double), s) != hipSuccess) {
+    // The GroupNorm-sum buffers start at zero.  (Round 5 tried to drop this memset -- the forward's first launch, the image-moments
+    // kernel of the 1x1 branch, zeroed the buffers and kept its own sums as per-workgroup partials: G2-k7 0.612-0.615 ms against
+    // 0.601-0.603 with the memset, 256^2 0.2448 against 0.2434, interleaved; profiles/r05_negative_results.txt.  The fill kernel
+    // overlaps the tail of whatever ran before; the kernel that replaced it did not.)
+    if (hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
         naf_set_error("naf_forward: hipMemsetAsync failed");
         return NAF_ERR_LAUNCH;
     }
@@ -690,10 +683,6 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
         c0.y = y;
         for (int i = 0; i < 3; ++i) c0.y_stride[i] = dense[i];
         c0.flags = (flags & NAF_FWD_CONV0_EXACT) ? NAF_CONV0_EXACT : 0;
-        if (zero_by_moments && br == first_launched) {   // the forward's first launch: image moments + zeroing of every GroupNorm-sum buffer
-            zero_by_moments = false;                     // (once)
-            return naf_launch_stem_conv0(&c0, static_cast<hipStream_t>(lstream), reinterpret_cast<double*>(ws + L.mom), stats, (int)nstats);
-        }
         return naf_stem_conv0_fwd(&c0, lstream);
     };
     // Key pooling rides on the branches' LAST layers (naf_stem_conv_keys_fwd: axial RoPE split, no pass over the guidance) when

@@ -54,8 +54,7 @@ int naf_launch_pack_values(void* vp, const void* v, int v_dtype, int B, int C, i
 int naf_launch_preshrink(float* out, const void* img, int dtype, int B, int H, int W, int Hs, int Ws, const int64_t* st, hipStream_t s);   // resize.hip
 int naf_launch_pool_guidance(void* y, const void* x, int B, int H, int W, int Ho, int Wo, int C, hipStream_t s);   // pool.hip
 
-int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s, double* moments_scratch = nullptr, double* zero = nullptr, int nzero = 0);   // stem_conv0.hip
-size_t naf_conv0_moments_scratch_bytes(int B);                                 // stem_conv0.hip
+int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s);            // stem_conv0.hip
 int naf_launch_stem_conv(const naf_stem_conv_args* a, hipStream_t s, const naf_key_pool_args* kp = nullptr);   // stem_conv.hip
 int naf_stem_conv_keys_ok(const naf_stem_conv_args* a, const naf_key_pool_args* kp);                            // stem_conv.hip
 int naf_stem_conv3_plan(int B, int H, int W, bool keys, int64_t* nblocks);                                       // stem_conv.hip

@@ -481,16 +481,10 @@ __global__ __launch_bounds__(NWS * 64, 1) void stem_conv0_split_kernel(const Ste
 // overwrites with the 16 group sums.
 // Round 3: four pixels per 16-byte (8-byte for bf16) load where the rows allow it (the scalar walk was latency-bound).  Folding the
 // second kernel into the last workgroup to finish (counter + fences) was measured and is slower: 29 us against 13.5 + 4.6.
-// naf_forward's variant (round 5; partial != NULL): every workgroup WRITES its nine sums to partial[b][workgroup][16] -- no atomics, so
-// nothing has to be zeroed for them -- and the launch, the first of the forward, also zeroes `nzero` doubles at `zero` (every other
-// GroupNorm-sum buffer of the call): the forward needs no hipMemsetAsync (its fill kernel sat 5-18 us in front of the stem).
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict__ img, int64_t ibs, int is1, int is2, int is3, int H, int W,
-                                                            double* __restrict__ stats, int vec4, double* __restrict__ partial,
-                                                            double* __restrict__ zero, int nzero) {
+                                                            double* __restrict__ stats, int vec4) {
     const int b = blockIdx.y;
-    if (zero != nullptr)
-        for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nzero; i += gridDim.x * gridDim.y * 256) zero[i] = 0.0;
     const T* ib = img + (int64_t)b * ibs;
     double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // S1[0..2], S2: 00 01 02 11 12 22
     const int64_t npx = (int64_t)H * W;
@@ -529,33 +523,18 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const T* __restrict_
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
-        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (partial != nullptr) partial[((size_t)b * gridDim.x + blockIdx.x) * 16 + threadIdx.x] = v;
-        else atomicAdd(&naf_gn_slot(stats, (int)gridDim.y, b, blockIdx.x)[threadIdx.x], v);   // the workgroup's copy of the sums (naf_gn_slot: atomics to one line are served one by one)
-    }
+    if (threadIdx.x < 9)   // into the workgroup's copy of the sums (naf_gn_slot: atomics to one line are served one by one)
+        atomicAdd(&naf_gn_slot(stats, (int)gridDim.y, b, blockIdx.x)[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restrict__ stats, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                double npx, const double* __restrict__ partial, int nparts) {
+                                                                double npx) {
     const int b = blockIdx.x, c = threadIdx.x;   // one thread per output channel
     double m[9];
-    if (partial != nullptr) {   // naf_forward's variant: the moments workgroups' partial sums, 16 lanes each taking every 16th, then a shuffle tree
-        const int sub = c & 15;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            double v = 0.0;
-            for (int i = sub; i < nparts; i += 16) v += partial[((size_t)b * nparts + i) * 16 + j];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            m[j] = v;
-        }
-    } else {
 #pragma unroll
     for (int j = 0; j < 9; ++j) {   // the moments, added up over their copies
         m[j] = 0.0;
         for (int sl = 0; sl < NAF_STATS_SLOTS; ++sl) m[j] += stats[((size_t)sl * gridDim.x + b) * 16 + j];
-    }
     }
     __syncthreads();                              // every thread has read the moments before the slots are overwritten
     const double w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], bc = bias[c];
@@ -577,10 +556,7 @@ __global__ __launch_bounds__(128) void conv0_moment_sums_kernel(double* __restri
     }
 }
 
-// naf_forward only: scratch of naf_conv0_moments_scratch_bytes(B) for the moments' partial sums + the doubles the launch zeroes
-size_t naf_conv0_moments_scratch_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 256 * 16 * sizeof(double); }
-
-int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s, double* moments_scratch, double* zero, int nzero) {
+int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s) {
     StemConv0Params p;
     p.img = a->image;
     p.y = static_cast<bf16_t*>(a->y);
@@ -598,8 +574,7 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s, double* m
     if (a->y == nullptr && a->ksize == 1) {   // statistics of the 1x1 layer: from the image's moments, no matrix work
         const int64_t npx = (int64_t)a->H * a->W;
         int nb = (int)((npx + 256 * 4 - 1) / (256 * 4));     // one 4-pixel load per lane and channel; 9 fp64 atomics per workgroup land on the same 9 addresses
-        int cap = naf_cu_count();   // measured (gpurun r11h): 32 / 64 / 128 / 256 / 1024 workgroups -> 25.2 / 16.3 / 12.0 / 11.7 / 21.6 us
-        if (cap > 256) cap = 256;   // the partial-sum scratch holds 256 workgroups per image
+        const int cap = naf_cu_count();   // measured (gpurun r11h): 32 / 64 / 128 / 256 / 1024 workgroups -> 25.2 / 16.3 / 12.0 / 11.7 / 21.6 us
         nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
         const dim3 g((uint32_t)nb, (uint32_t)a->B), blk(256);
         const int64_t* is = a->image_stride;
@@ -608,12 +583,11 @@ int naf_launch_stem_conv0(const naf_stem_conv0_args* a, hipStream_t s, double* m
                           reinterpret_cast<uintptr_t>(a->image) % (4 * esz) == 0) ? 1 : 0;
         if (a->image_dtype == NAF_BF16)
             hipLaunchKernelGGL(conv0_moments_kernel<bf16_t>, g, blk, 0, s, static_cast<const bf16_t*>(a->image), a->image_stride[0],
-                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4, moments_scratch, zero, nzero);
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4);
         else
             hipLaunchKernelGGL(conv0_moments_kernel<float>, g, blk, 0, s, static_cast<const float*>(a->image), a->image_stride[0],
-                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4, moments_scratch, zero, nzero);
-        hipLaunchKernelGGL(conv0_moment_sums_kernel, dim3((uint32_t)a->B), dim3(128), 0, s, a->stats_out, a->weight, a->bias, (double)npx,
-                           static_cast<const double*>(moments_scratch), nb);
+                               (int)a->image_stride[1], (int)a->image_stride[2], (int)a->image_stride[3], a->H, a->W, a->stats_out, vec4);
+        hipLaunchKernelGGL(conv0_moment_sums_kernel, dim3((uint32_t)a->B), dim3(128), 0, s, a->stats_out, a->weight, a->bias, (double)npx);
         return naf_check_launch("conv0_moments_kernel");
     }
     p.ngroups = (int32_t)ng;

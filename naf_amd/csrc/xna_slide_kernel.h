@@ -483,7 +483,14 @@ __global__ __launch_bounds__(NW * 64) void xna_slide_kernel(const XnaSlideParams
             }
             }
 
-            // consume the prefetch below the stores (exact vmcnt waits: the stores stay in flight)
+            // consume the prefetch below the stores.  NOTE (round 5, from the ISA): the stores above sit behind `if (okv[u])`, a
+            // wave-uniform BRANCH, and hipcc's waitcnt pass merges the two paths to "no store is guaranteed younger than the pending
+            // loads": the waits below are vmcnt(11) / (10) / (4) / (0) and the column's vmcnt(1) / (0), i.e. every pass and every cell
+            // ends with a drain of the wave's own 16 stores.  With the stores made unconditional by a compile-time "whole tiles" flag
+            // the counts become exact (vmcnt(27) ... (16), no wait for the column) -- and the kernel is NOT faster: G2-k15 0.1892-0.1913
+            // vs 0.1868-0.1898 ms, k11 0.1470-0.1481 vs 0.1431-0.1477, and the 7 x 7 cell kernel with the same change is 2-7 % SLOWER
+            // (G1 0.460-0.477 vs 0.433-0.441 ms alone, G3 0.534-0.543 vs 0.517-0.531 in the forward): the drain throttles a wave's
+            // outstanding row stores, which the memory system prefers.  Reverted; profiles/r05_negative_results.txt.
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
