@@ -52,6 +52,9 @@ WORKLOADS = {
     "REF448": (384, 28, 448, 9),
     # VERDICT r04 item 3's small-image line: 256^2, C = 768, 16^2 features, window 7
     "S256": (768, 16, 256, 7),
+    # cells other than 16 x 16 pixels at the reference's timing size: a patch-14 backbone's grid (448 / 14 = 32) and a ratio-8 call
+    "P14": (384, 32, 448, 9),
+    "R8": (384, 56, 448, 9),
 }
 PUBLISHED_MPIX = {"REF448": 3.57}   # BASELINE.md numbers for the exact configuration (other hardware)
 
