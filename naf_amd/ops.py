@@ -12,6 +12,7 @@ Reference counterparts (paths relative to the reference repo):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import threading
 from typing import Dict, Optional, Tuple
@@ -59,51 +60,6 @@ def _strides4(t: torch.Tensor, dims) -> I64x4:
 
 
 # ------------------------------------------------------------------------------------------------
-class _AuxPool:
-    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
-    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
-    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
-    LIMIT = 16
-
-    def __init__(self):
-        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
-        self._lock = threading.Lock()
-
-    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
-        key = (threading.get_ident(), device_index, stream_handle)
-        with self._lock:
-            aux = self._by_key.pop(key, None)
-            if aux is None:
-                lib = _lib.load()
-                while len(self._by_key) >= self.LIMIT:
-                    old = self._by_key.pop(next(iter(self._by_key)))
-                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
-                aux = _lib.ForwardAux()
-                with torch.cuda.device(device_index):
-                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
-            self._by_key[key] = aux
-            return aux
-
-    def clear(self) -> None:
-        with self._lock:
-            lib = _lib.load()
-            for aux in self._by_key.values():
-                lib.naf_forward_aux_destroy(C.byref(aux))
-            self._by_key.clear()
-
-
-AUX_POOL = _AuxPool()
-
-
-def forward_aux(device, stream=None) -> "_lib.ForwardAux":
-    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
-    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = stream if stream is not None else torch.cuda.current_stream(idx)
-    return AUX_POOL.get(idx, int(st.cuda_stream))
-
-
 def axis_index_table(L_out: int, L_in: int, k: int) -> torch.Tensor:
     """[L_out, k] int32 CPU tensor of low-res indices (host function of the library, no GPU needed)."""
     lib = _lib.load()
@@ -130,51 +86,6 @@ def device_index_table(L_out: int, L_in: int, k: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
-class _AuxPool:
-    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
-    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
-    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
-    LIMIT = 16
-
-    def __init__(self):
-        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
-        self._lock = threading.Lock()
-
-    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
-        key = (threading.get_ident(), device_index, stream_handle)
-        with self._lock:
-            aux = self._by_key.pop(key, None)
-            if aux is None:
-                lib = _lib.load()
-                while len(self._by_key) >= self.LIMIT:
-                    old = self._by_key.pop(next(iter(self._by_key)))
-                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
-                aux = _lib.ForwardAux()
-                with torch.cuda.device(device_index):
-                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
-            self._by_key[key] = aux
-            return aux
-
-    def clear(self) -> None:
-        with self._lock:
-            lib = _lib.load()
-            for aux in self._by_key.values():
-                lib.naf_forward_aux_destroy(C.byref(aux))
-            self._by_key.clear()
-
-
-AUX_POOL = _AuxPool()
-
-
-def forward_aux(device, stream=None) -> "_lib.ForwardAux":
-    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
-    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = stream if stream is not None else torch.cuda.current_stream(idx)
-    return AUX_POOL.get(idx, int(st.cuda_stream))
-
-
 STATS_SLOTS = 16   # NAF_STATS_SLOTS of include/naf_hip.h: partial copies of every GroupNorm-sum buffer
 
 
@@ -444,51 +355,6 @@ def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_w
 
 
 # ------------------------------------------------------------------------------------------------
-class _AuxPool:
-    """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
-    library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
-    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
-    LIMIT = 16
-
-    def __init__(self):
-        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
-        self._lock = threading.Lock()
-
-    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
-        key = (threading.get_ident(), device_index, stream_handle)
-        with self._lock:
-            aux = self._by_key.pop(key, None)
-            if aux is None:
-                lib = _lib.load()
-                while len(self._by_key) >= self.LIMIT:
-                    old = self._by_key.pop(next(iter(self._by_key)))
-                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
-                aux = _lib.ForwardAux()
-                with torch.cuda.device(device_index):
-                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
-            self._by_key[key] = aux
-            return aux
-
-    def clear(self) -> None:
-        with self._lock:
-            lib = _lib.load()
-            for aux in self._by_key.values():
-                lib.naf_forward_aux_destroy(C.byref(aux))
-            self._by_key.clear()
-
-
-AUX_POOL = _AuxPool()
-
-
-def forward_aux(device, stream=None) -> "_lib.ForwardAux":
-    """The second-stream bundle ``ForwardPlan.run`` lends to the library for forwards issued by this thread on ``stream`` (default:
-    the current one) of ``device``.  Call it BEFORE a hipGraph capture on that stream so that nothing is created while capturing."""
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = stream if stream is not None else torch.cuda.current_stream(idx)
-    return AUX_POOL.get(idx, int(st.cuda_stream))
-
-
 def rope_tables(periods: torch.Tensor, Ho: int, Wo: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin tables [Ho, 2, P] and [Wo, 2, P] (fp32) for the module's `periods` buffer [P]."""
     _gpu(periods, "periods")
@@ -845,34 +711,51 @@ def xna_select(q, k_lr, v_lr, kernel_size, out_dtype=torch.bfloat16, return_logi
 class _AuxPool:
     """The ``naf_forward_aux`` objects (a second stream and the fork / join events) this host LENDS to ``naf_forward_ex``.  The
     library owns none (C ABI 0.4.0): one per (host thread, device, caller stream), so concurrent forwards never share fork / join
-    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recent are kept."""
+    events and a hipGraph capture pulls in a stream nothing else uses.  The sixteen most recently used are kept; a bundle that is
+    lent out at the moment (``lease``: inside a ``naf_forward_ex`` call of some thread) is never the one that is destroyed."""
     LIMIT = 16
 
     def __init__(self):
-        self._by_key: Dict[tuple, "_lib.ForwardAux"] = {}
+        self._by_key: Dict[tuple, list] = {}      # key -> [ForwardAux, leases outstanding]
         self._lock = threading.Lock()
 
-    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
+    def _entry(self, device_index: int, stream_handle: int) -> list:      # caller holds the lock
         key = (threading.get_ident(), device_index, stream_handle)
+        ent = self._by_key.pop(key, None)
+        if ent is None:
+            lib = _lib.load()
+            idle = [k for k, e in self._by_key.items() if e[1] == 0]
+            while len(self._by_key) >= self.LIMIT and idle:
+                old = self._by_key.pop(idle.pop(0))                         # least recently used idle one (dicts keep insertion order)
+                lib.naf_forward_aux_destroy(C.byref(old[0]))                # work already queued on a destroyed stream still completes
+            aux = _lib.ForwardAux()
+            with torch.cuda.device(device_index):
+                _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
+            ent = [aux, 0]
+        self._by_key[key] = ent
+        return ent
+
+    def get(self, device_index: int, stream_handle: int) -> "_lib.ForwardAux":
         with self._lock:
-            aux = self._by_key.pop(key, None)
-            if aux is None:
-                lib = _lib.load()
-                while len(self._by_key) >= self.LIMIT:
-                    old = self._by_key.pop(next(iter(self._by_key)))
-                    lib.naf_forward_aux_destroy(C.byref(old))     # queued work on a destroyed stream still completes
-                aux = _lib.ForwardAux()
-                with torch.cuda.device(device_index):
-                    _lib.check(lib.naf_forward_aux_create(C.byref(aux)), "naf_forward_aux_create")
-            self._by_key[key] = aux
-            return aux
+            return self._entry(device_index, stream_handle)[0]
+
+    @contextlib.contextmanager
+    def lease(self, device_index: int, stream_handle: int):
+        """The bundle of (this thread, device, stream) for the duration of one foreign call."""
+        with self._lock:
+            ent = self._entry(device_index, stream_handle)
+            ent[1] += 1
+        try:
+            yield ent[0]
+        finally:
+            with self._lock:
+                ent[1] -= 1
 
     def clear(self) -> None:
         with self._lock:
             lib = _lib.load()
-            for aux in self._by_key.values():
-                lib.naf_forward_aux_destroy(C.byref(aux))
-            self._by_key.clear()
+            for k in [k for k, e in self._by_key.items() if e[1] == 0]:
+                lib.naf_forward_aux_destroy(C.byref(self._by_key.pop(k)[0]))
 
 
 AUX_POOL = _AuxPool()
@@ -996,9 +879,12 @@ class ForwardPlan:
                                  dtype=torch.float32, device=dev)
         a.logits = logits.data_ptr() if logits is not None else None
         flags = (_lib.FWD_CONV0_EXACT if self.conv0_exact else 0) | {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)]
-        aux = None if self.streams == 1 else AUX_POOL.get(skey[0], skey[1])
         with torch.cuda.device(dev):
-            rc = self.lib.naf_forward_ex(C.byref(a), C.byref(aux) if aux is not None else None, flags, _stream(image))
+            if self.streams == 1:
+                rc = self.lib.naf_forward_ex(C.byref(a), None, flags, _stream(image))
+            else:
+                with AUX_POOL.lease(skey[0], skey[1]) as aux:
+                    rc = self.lib.naf_forward_ex(C.byref(a), C.byref(aux), flags, _stream(image))
         _lib.check(rc, "naf_forward_ex")
         out = out.permute(0, 3, 1, 2)
         return (out, logits) if return_logits else out
