@@ -773,6 +773,43 @@ def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_
         assert err <= tol * scale + 1e-5, f"{name}: max err {err:.3e} (ref max {scale:.3e})"   # dq is rounded to bf16
 
 
+def test_cell_backward_fuzz_against_table_driven_kernel(dev):
+    """Seeded random geometries of the MFMA cell backward -- every window 3 .. 13, every Dv, row-tile counts that are not multiples of the
+    four tiles of a round (dead query waves), one-row cells, several images and heads -- against the independent scalar table-driven
+    kernel (fp32 throughout) on the same bf16 inputs.  Windows up to 7 x 7 run the wave-specialised kernel (xna_bwd2_kernel.h: query
+    waves / key waves, double round buffers), the others the four-wave kernel."""
+    from naf_amd import ops
+    rng = np.random.RandomState(9753)
+    done = ragged = small = 0
+    for _ in range(400):
+        ksz = int(rng.choice([3, 5, 7, 7, 7, 9, 11, 13]))
+        h, w = int(rng.randint(ksz, ksz + 6)), int(rng.randint(ksz, ksz + 6))
+        dy, dx = int(rng.choice([1, 2, 3, 5, 6, 8, 16])), int(rng.choice([16, 16, 32, 48]))
+        Ho, Wo = h * dy, w * dx
+        if Ho * Wo > 160 * 400:
+            continue
+        B, heads = int(rng.choice([1, 2])), int(rng.choice([1, 2, 4]))
+        Dv = int(rng.choice([32, 64, 96, 128, 192, 256]))
+        q = torch.randn(B, heads, Ho, Wo, 64, device=dev).to(torch.bfloat16)
+        k = torch.randn(B, heads, h, w, 64, device=dev).to(torch.bfloat16)
+        v = torch.randn(B, h, w, heads, Dv, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        g = torch.randn(B, Ho, Wo, heads, Dv, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+        if ops.xna_backward_select(q, k, v, ksz) != "mfma":
+            continue
+        a = ops.xna_backward(q, k, v, g, ksz)
+        b = ops.xna_backward(q, k, v, g, ksz, path="generic")
+        for x, y, name in zip(a, b, ("dq", "dk", "dv")):
+            scale = float(y.float().abs().max())
+            err = float((x.float() - y.float()).abs().max())
+            assert bool(torch.isfinite(x.float()).all()) and err <= 2.5e-2 * scale + 1e-3, (name, B, heads, h, w, Ho, Wo, ksz, Dv, err, scale)
+        done += 1
+        ragged += int((dy * (dx // 16)) % 4 != 0)
+        small += int(ksz <= 7)
+        if done >= 60:
+            break
+    assert done >= 40 and ragged >= 10 and small >= 20, (done, ragged, small)
+
+
 @pytest.mark.parametrize("B,Cq,C,heads,size,ksz", [
     (1, 96, 3, 1, (12, 10), 5),        # narrower than one 16-query tile
     (1, 96, 3, 1, (40, 52), 15),       # the denoising call's shape class: one head, RGB values, 15x15 window, ragged last tile

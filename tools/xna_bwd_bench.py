@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from naf_amd import ops
 
-def timed(fn, n=10):
+def timed(fn, n=int(os.environ.get("BWD_BENCH_N", "10"))):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
