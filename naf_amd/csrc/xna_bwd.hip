@@ -53,6 +53,7 @@ int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
         return NAF_ERR_INVALID;
     }
     p.nblocks = (uint32_t)nb;
+    p.seg_len = 1; p.nseg = a->w;
     p.scale = scale;
     p.scale_log2e = scale * 1.4426950408889634f;
     for (int i = 0; i < 4; ++i) {

@@ -32,11 +32,10 @@
 template <int KS, int DV>
 struct XnaBwd2Geom {
     using G = XnaBwdGeom<KS, DV>;
+    static constexpr size_t kv_elems = (size_t)G::NSLOT * (G::KROW + G::VROW);  // bf16 per K + V window buffer
     static constexpr size_t ps_elems = (size_t)4 * G::MT * 64;                  // bf16x4 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
-    static constexpr size_t lds_bytes() {
-        return (size_t)G::NSLOT * (G::KROW + G::VROW) * 2 + 2 * (2 * ps_elems * 8) + 2 * (qg_elems * 2);
-    }
+    static constexpr size_t lds_bytes() { return 2 * kv_elems * 2 + 2 * (2 * ps_elems * 8) + 2 * (qg_elems * 2); }
     // K and V fragments of the whole window in registers: MT * (2 + Dv / 32) * 4 per lane
     static constexpr int frag_regs = G::MT * (2 + DV / 32) * 4;
 };
@@ -50,10 +49,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + NSLOT * KROW;
-    bf16x4_t* PS = reinterpret_cast<bf16x4_t*>(Vs + NSLOT * VROW);               // [2 buffers][P | dS][4 tiles][MT][64 lanes]
-    bf16_t* QG = reinterpret_cast<bf16_t*>(PS + 2 * 2 * G2::ps_elems);           // [2 buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
+    bf16_t* KV = reinterpret_cast<bf16_t*>(smem);                                // [2 window buffers][K: NSLOT x KROW | V: NSLOT x VROW]
+    bf16x4_t* PS = reinterpret_cast<bf16x4_t*>(KV + 2 * G2::kv_elems);           // [2 round buffers][P | dS][4 tiles][MT][64 lanes]
+    bf16_t* QG = reinterpret_cast<bf16_t*>(PS + 2 * 2 * G2::ps_elems);           // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,258 +61,331 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_[8];
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef NAF_BWD_TIMING2   // coarse: the query waves' rounds by round number + cell switch; the key waves' work and barrier wait by round number
+    unsigned long long tacc2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t2_ = __builtin_amdgcn_s_memtime();
+#endif
 
-    uint32_t L = blockIdx.x;
-    if ((p.nblocks % 128u) == 0u) { const uint32_t xcd = L & 7u, idx = L >> 3; L = ((idx / 16u) * 8u + xcd) * 16u + idx % 16u; }
-    const int head = L % p.heads;
-    L /= p.heads;
-    const int cx0 = L % p.w;
-    L /= p.w;
-    const int cy0 = L % p.h;
-    const int b = L / p.h;
-    const int y0 = min(max(cy0 - KS / 2, 0), p.h - KS), x0 = min(max(cx0 - KS / 2, 0), p.w - KS);
+    // A workgroup is resident and walks RUNS of cells: run = (batch, cell row, head, segment of seg_len consecutive cell columns), runs
+    // blockIdx.x, blockIdx.x + gridDim.x, ...  Inside a run the window moves one column at a time, and a key keeps its SLOT
+    // ((column mod KS) * KS + row) from cell to cell: only the column that enters is fetched, only the column that leaves is added to
+    // dK / dV in memory (1/KS of the per-cell atomics and window reads of the one-cell-at-a-time kernel).
+    const int nwg = (int)gridDim.x, first = (int)blockIdx.x;
+    const int nrun = (int)p.nblocks;
+    struct Cell { int run, pos, len, b, cy0, cx0, head, y0, x0; };
+    auto at = [&](int run, int pos) __attribute__((always_inline)) {
+        Cell c;
+        uint32_t L = (uint32_t)min(run, nrun - 1);
+        const int seg = L % p.nseg; L /= p.nseg;
+        c.head = L % p.heads;       L /= p.heads;
+        c.cy0 = L % p.h;
+        c.b = L / p.h;
+        c.run = run;
+        c.len = min(p.seg_len, p.w - seg * p.seg_len);
+        c.pos = pos;
+        c.cx0 = seg * p.seg_len + pos;
+        c.y0 = min(max(c.cy0 - KS / 2, 0), p.h - KS);
+        c.x0 = min(max(c.cx0 - KS / 2, 0), p.w - KS);
+        return c;
+    };
+    // the cell after c in this workgroup's walk (run >= nrun: there is none)
+    // (inside a run: one column to the right -- no divisions; every instruction of the walk is issued beside the MFMAs of the round in hand)
+    auto after = [&](const Cell& c) __attribute__((always_inline)) {
+        if (c.pos + 1 < c.len) {
+            Cell n = c;
+            n.pos = c.pos + 1;
+            n.cx0 = c.cx0 + 1;
+            n.x0 = min(max(n.cx0 - KS / 2, 0), p.w - KS);
+            return n;
+        }
+        return at(c.run + nwg, 0);
+    };
+    auto same_run = [&](const Cell& a, const Cell& c) __attribute__((always_inline)) { return a.run == c.run; };
 
     const int tpr = p.dx >> 4, ntile = p.dy * tpr;
     const int nround = (ntile + 3) >> 2;
-    const bf16_t* q_cell = p.q + b * p.qs[0] + head * p.qs[1] + (int64_t)(cy0 * p.dy) * p.qs[2] + (int64_t)(cx0 * p.dx) * p.qs[3];
-    const bf16_t* g_cell = p.dout + b * p.gs[0] + head * p.gs[1] + (int64_t)(cy0 * p.dy) * p.gs[2] + (int64_t)(cx0 * p.dx) * p.gs[3];
 
-    // fragments of tile tt (clamped): a lane's 16 query dims / Dv/4 gradient channels of its query
-    auto load_tile = [&](int tt, bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
-        const int tcc = min(tt, ntile - 1);
-        const int tyy = tcc / tpr, txx = (tcc - tyy * tpr) * 16;
-        const bf16_t* qp = q_cell + (int64_t)tyy * p.qs[2] + (int64_t)(txx + col) * p.qs[3] + grp * 8;
-        const bf16_t* gp = g_cell + (int64_t)tyy * p.gs[2] + (int64_t)(txx + col) * p.gs[3] + grp * 8;
-        qv[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-        qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-#pragma unroll
-        for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + ks * 32);
+    // 16-byte chunk i of window column x (rows y0 .. y0 + KS - 1; per row 8 chunks of K, then Dv/8 of V) -> global address, LDS offset
+    constexpr int VCH = DV / 8, RCH = 8 + VCH, CCH = KS * RCH;   // chunks per key, per column
+    auto col_chunk = [&](const Cell& c, int x, int i, int& off) __attribute__((always_inline)) -> const bf16_t* {
+        const int ry = i / RCH, ch = i - ry * RCH;
+        const int slot = (x % KS) * KS + ry;
+        const int64_t pix = (int64_t)(c.y0 + ry);
+        if (ch < 8) {
+            off = slot * KROW + ch * 8;
+            return p.k + c.b * p.ks[0] + c.head * p.ks[1] + pix * p.ks[2] + (int64_t)x * p.ks[3] + ch * 8;
+        }
+        off = NSLOT * KROW + slot * VROW + (ch - 8) * 8;
+        return p.v + c.b * p.vs[0] + c.head * p.vs[1] + pix * p.vs[2] + (int64_t)x * p.vs[3] + (ch - 8) * 8;
     };
-    bf16x8_t qf[2], gf[DKS];
-    if (query_wave) load_tile(wave, qf, gf);   // the first round's rows are on their way while the windows are staged
 
-    // ---- stage the K and V windows (all eight waves; loads of a batch issued before the first LDS write) ----
-    {
-        const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
-        const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1];
-        constexpr int VCH = DV / 8;
-        constexpr int KTOT = NSLOT * 8, VTOT = NSLOT * VCH;
-        constexpr int KIT = (KTOT + 511) / 512, VIT = (VTOT + 511) / 512;
-        constexpr int BATCH = 8;
-        auto chunk = [&](int j, int& off) __attribute__((always_inline)) -> const bf16_t* {
-            if (j < KIT) {
-                const int i = min(j * 512 + tid, KTOT - 1);
-                const int key = i >> 3, c = i & 7;
-                const int ry = key / KS, rx = key - ry * KS;
-                off = key * KROW + c * 8;
-                return kb + (int64_t)(y0 + ry) * p.ks[2] + (int64_t)(x0 + rx) * p.ks[3] + c * 8;
-            }
-            const int i = min((j - KIT) * 512 + tid, VTOT - 1);
-            const int key = i / VCH, c = i - key * VCH;
-            const int ry = key / KS, rx = key - ry * KS;
-            off = NSLOT * KROW + key * VROW + c * 8;
-            return vb + (int64_t)(y0 + ry) * p.vs[2] + (int64_t)(x0 + rx) * p.vs[3] + c * 8;
-        };
+    // fragments of the tile at row ty, 16-column block tx of the cell whose first query / gradient row is at qc / gc: a wave-uniform
+    // base and one 32-bit lane offset per tensor (global_load with a scalar base: no per-lane 64-bit address arithmetic in the rounds)
+    const uint32_t lane_q = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u, lane_g = (uint32_t)(col * (int)p.gs[3] + grp * 8) * 2u;
+    auto load_tile = [&](const bf16_t* qc, const bf16_t* gc, int ty_, int tx_, bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
+        const char* qp = reinterpret_cast<const char*>(qc + (int64_t)ty_ * p.qs[2] + (int64_t)(tx_ * 16) * p.qs[3]);
+        const char* gp = reinterpret_cast<const char*>(gc + (int64_t)ty_ * p.gs[2] + (int64_t)(tx_ * 16) * p.gs[3]);
+        qv[0] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q);
+        qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q + 64);
 #pragma unroll
-        for (int j0 = 0; j0 < KIT + VIT; j0 += BATCH) {
+        for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + lane_g + ks * 64);
+    };
+    // tile t = 4 r + wave of a cell, r = 0, 1, ...: row / block of this wave's tile in round 0, and the step from round to round
+    const int ty_first = min(wave, ntile - 1) / tpr, tx_first = min(wave, ntile - 1) % tpr;
+    const int ty_step = 4 / tpr, tx_step = 4 % tpr;
+    auto q_of = [&](const Cell& c) __attribute__((always_inline)) {
+        return p.q + c.b * p.qs[0] + c.head * p.qs[1] + (int64_t)(c.cy0 * p.dy) * p.qs[2] + (int64_t)(c.cx0 * p.dx) * p.qs[3];
+    };
+    auto g_of = [&](const Cell& c) __attribute__((always_inline)) {
+        return p.dout + c.b * p.gs[0] + c.head * p.gs[1] + (int64_t)(c.cy0 * p.dy) * p.gs[2] + (int64_t)(c.cx0 * p.dx) * p.gs[3];
+    };
+
+    const Cell c0 = at(first, 0);
+    bf16x8_t qf[2], gf[DKS];
+    if (query_wave) load_tile(q_of(c0), g_of(c0), ty_first, tx_first, qf, gf);   // the first round's rows are on their way while the windows are staged
+
+    // ---- the first cell's windows: all eight waves (loads of a batch issued before the first LDS write) ----
+    {
+        constexpr int TOT = KS * CCH, NIT = (TOT + 511) / 512, BATCH = 8;
+#pragma unroll
+        for (int j0 = 0; j0 < NIT; j0 += BATCH) {
             u32x4_t val[BATCH];
             int off[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (j0 + u < KIT + VIT) val[u] = *reinterpret_cast<const u32x4_t*>(chunk(j0 + u, off[u]));
+                if (j0 + u < NIT) {
+                    const int i = min((j0 + u) * 512 + tid, TOT - 1);
+                    val[u] = *reinterpret_cast<const u32x4_t*>(col_chunk(c0, c0.x0 + i / CCH, i % CCH, off[u]));
+                }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
-                if (j0 + u < KIT + VIT) *reinterpret_cast<u32x4_t*>(Ks + off[u]) = val[u];
+                if (j0 + u < NIT) *reinterpret_cast<u32x4_t*>(KV + off[u]) = val[u];     // clamped duplicates rewrite the last chunk
         }
     }
     __syncthreads();
 
     if (query_wave) {
         // =========================== query waves ===========================
-        bf16_t* dq_cell = p.dq + b * p.dqs[0] + head * p.dqs[1] + (int64_t)(cy0 * p.dy) * p.dqs[2] + (int64_t)(cx0 * p.dx) * p.dqs[3];
         auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
-        auto kt_of = [&](int blk) __attribute__((always_inline)) {
-            const int r = min(blk * 16 + grp * 4 + (col >> 2), NSLOT - 1);
-            return Ks + r * KROW + (col & 3) * 4;
-        };
-        // the windows as operand fragments, resident for the whole cell (row mt*16 + col, dims / channels grp*8 + 32 ks ..)
         bf16x8_t kfr[MT][2], vfr[MT][DKS];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
-            const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
-#pragma unroll
-            for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
-        }
-
+        Cell cur = c0;
+        int g = 0;   // rounds since the kernel started: round buffer g & 1
+        int kc = 0;  // cells since the kernel started: window buffer kc & 1
+        int ty_cur = ty_first, tx_cur = tx_first;   // this wave's tile of the round in hand
 #ifdef NAF_BWD_TIMING
-        tacc[0] = __builtin_amdgcn_s_memtime() - t_begin;   // window staging + fragments into registers
         constexpr int slot_[5] = {1, 2, 3, 4, 5};
 #endif
-        for (int r = 0; r < nround; ++r) {
-            BWD2_STAMP(0);
-            const int buf = r & 1;
-            bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
-            bf16x4_t* Sl = Pl + G2::ps_elems;
-            bf16_t* Qs = QG + buf * G2::qg_elems;
-            bf16_t* Gs = Qs + 4 * 16 * KROW;
-            const int t = 4 * r + wave;
-            const bool live = t < ntile;
-            const int tc = live ? t : ntile - 1;               // dead tiles compute on a real tile and contribute zeros
-            const int ty = tc / tpr, tx0 = (tc - ty * tpr) * 16;
-
-            // row-major LDS copies: the key waves' B operands (ds_read_tr) and this wave's own second pass
-            bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
-            bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
-            *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
-            *reinterpret_cast<bf16x8_t*>(qrow + 32) = qf[1];
-#pragma unroll
-            for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
-
-            // ---- pass 1, "swapped": S^T[key][q], dP^T[key][q] -- a lane owns one QUERY ----
-            f32x4_t sT[MT], gT[MT];
+        for (; cur.run < nrun; ++kc) {
+#ifdef NAF_BWD_TIMING
+            st_[6] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef NAF_BWD_TIMING2
+            const unsigned long long tcs_ = __builtin_amdgcn_s_memtime();
+#endif
+            const bf16_t* Ks = KV + (kc & 1) * G2::kv_elems;
+            const bf16_t* Vs = Ks + NSLOT * KROW;
+            auto kt_of = [&](int blk) __attribute__((always_inline)) {
+                const int r = min(blk * 16 + grp * 4 + (col >> 2), NSLOT - 1);
+                return Ks + r * KROW + (col & 3) * 4;
+            };
+            // the windows as operand fragments, resident for the whole cell (row = slot mt*16 + col, dims / channels grp*8 + 32 ks ..)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                sT[mt] = gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+                const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[mt][ks], qf[ks], sT[mt], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
 #pragma unroll
-                for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
+                for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
             }
-            // the global fragments are dead (their copies are in the LDS): request the next round's now
+            const Cell nxt = after(cur);
+            const Cell pre = nxt.run < nrun ? nxt : cur;         // whose first rows the last round requests (nobody's: harmless re-read)
+            const bf16_t* q_cell = q_of(cur);
+            const bf16_t* g_cell = g_of(cur);
+            const bf16_t* q_next = q_of(pre);
+            const bf16_t* g_next = g_of(pre);
+            bf16_t* dq_cell = p.dq + cur.b * p.dqs[0] + cur.head * p.dqs[1] + (int64_t)(cur.cy0 * p.dy) * p.dqs[2] + (int64_t)(cur.cx0 * p.dx) * p.dqs[3];
+#ifdef NAF_BWD_TIMING
+            tacc[0] += __builtin_amdgcn_s_memtime() - (kc == 0 ? t_begin : st_[6]);   // windows -> LDS (first cell) -> registers
+#endif
+
+#ifdef NAF_BWD_TIMING2
             __builtin_amdgcn_sched_barrier(0);
-            load_tile(t + 4, qf, gf);
-            __builtin_amdgcn_sched_barrier(0);
-            BWD2_STAMP(1);   // rows' arrival + LDS copies + pass-1 MFMAs
+            { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[4] += now_ - tcs_; t2_ = now_; }
+#endif
+            for (int r = 0; r < nround; ++r, ++g) {
+                BWD2_STAMP(0);
+                const int buf = g & 1;
+                bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
+                bf16x4_t* Sl = Pl + G2::ps_elems;
+                bf16_t* Qs = QG + buf * G2::qg_elems;
+                bf16_t* Gs = Qs + 4 * 16 * KROW;
+                const int t = 4 * r + wave;
+                const bool live = t < ntile;                       // dead tiles compute on the cell's last tile and contribute zeros
+                const int ty = ty_cur, tx0 = tx_cur * 16;
+                // where the tile of the next round is (clamped to the cell's last)
+                int ty_n = ty_cur + ty_step, tx_n = tx_cur + tx_step;
+                if (tx_n >= tpr) { tx_n -= tpr; ++ty_n; }
+                if (t + 4 >= ntile) { ty_n = p.dy - 1; tx_n = tpr - 1; }
 
-            float m = -INFINITY;
+                // row-major LDS copies: the key waves' B operands (ds_read_tr) and this wave's own second pass
+                bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
+                bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
+                *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
+                *reinterpret_cast<bf16x8_t*>(qrow + 32) = qf[1];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    if (mt * 16 + 15 >= NSLOT) sT[mt][rr] = (mt * 16 + grp * 4 + rr < NSLOT) ? sT[mt][rr] : -INFINITY;
-                    m = fmaxf(m, sT[mt][rr]);
-                }
-            m = naf_rows_max(m);
-            const float mc = m * p.scale_log2e;
-            float sum = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sT[mt][rr], p.scale_log2e, -mc));
-                    sT[mt][rr] = e;
-                    sum += e;
-                }
-            sum = naf_rows_sum(sum);
-            const float inv = __builtin_amdgcn_rcpf(sum);
-            float delta = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    sT[mt][rr] *= inv;                       // P^T
-                    delta = fmaf(sT[mt][rr], gT[mt][rr], delta);
-                }
-            delta = naf_rows_sum(delta);
-            bf16x8_t dsf[KST];
-#pragma unroll
-            for (int ks = 0; ks < KST; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int mt = 2 * ks + (j >> 2), rr = j & 3;
-                    dsf[ks][j] = (bf16_t)(p.scale * sT[mt][rr] * (gT[mt][rr] - delta));
-                }
+                for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
 
-            BWD2_STAMP(2);   // softmax, delta, dS^T
-            // ---- dQ^T[d][q] = K^T . dS^T ----
-            if (live) {
-                bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
-#pragma unroll
-                for (int ct = 0; ct < 4; ct += 2) {
-                    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < KST; ++ks) {
-                        bf16x8_t k0, k1;
-                        {
-                            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16));
-                            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16));
-                            k0[0] = lo[0]; k0[1] = lo[1]; k0[2] = lo[2]; k0[3] = lo[3];
-                            k0[4] = hi[0]; k0[5] = hi[1]; k0[6] = hi[2]; k0[7] = hi[3];
-                        }
-                        {
-                            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16 + 16));
-                            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16 + 16));
-                            k1[0] = lo[0]; k1[1] = lo[1]; k1[2] = lo[2]; k1[3] = lo[3];
-                            k1[4] = hi[0]; k1[5] = hi[1]; k1[6] = hi[2]; k1[7] = hi[3];
-                        }
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, dsf[ks], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, dsf[ks], a1, 0, 0, 0);
-                    }
-                    bf16x4_t ab, bb;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        ab[i] = (bf16_t)a0[i];
-                        bb[i] = (bf16_t)a1[i];
-                    }
-                    const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
-                    const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                    const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                    *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-                }
-            }
-
-            BWD2_STAMP(3);   // dQ
-            // ---- pass 2, "straight": S[q][key], dP[q][key] -- a lane owns one KEY: P and dS in the A-operand form of the
-            // contractions over queries.  The tile's rows come back from this wave's own LDS copy (the global fragments' registers
-            // already carry the next round's request). ----
-            {
-                // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout; they travel through the
-                // wave's own dS slots of this round's buffer, free until they are written below
-                float* stw = reinterpret_cast<float*>(Sl + (wave * MT) * 64);
-                if (grp == 0) {
-                    stw[col] = mc;
-                    stw[16 + col] = inv;
-                    stw[32 + col] = delta;
-                }
-                bf16x8_t q2[2], g2[DKS];
-                q2[0] = *reinterpret_cast<const bf16x8_t*>(qrow);
-                q2[1] = *reinterpret_cast<const bf16x8_t*>(qrow + 32);
-#pragma unroll
-                for (int ks = 0; ks < DKS; ++ks) g2[ks] = *reinterpret_cast<const bf16x8_t*>(grow + ks * 32);
-                const f32x4_t mcq = *reinterpret_cast<const f32x4_t*>(stw + grp * 4);
-                const f32x4_t invq = *reinterpret_cast<const f32x4_t*>(stw + 16 + grp * 4);
-                const f32x4_t dlq = *reinterpret_cast<const f32x4_t*>(stw + 32 + grp * 4);
-                asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq) : "memory");
+                // ---- pass 1, "swapped": S^T[key][q], dP^T[key][q] -- a lane owns one QUERY ----
+                f32x4_t sT[MT], gT[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    f32x4_t sS = {0.f, 0.f, 0.f, 0.f}, gS = {0.f, 0.f, 0.f, 0.f};
+                    sT[mt] = gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) sS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[ks], kfr[mt][ks], sS, 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[mt][ks], qf[ks], sT[mt], 0, 0, 0);
 #pragma unroll
-                    for (int ks = 0; ks < DKS; ++ks) gS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g2[ks], vfr[mt][ks], gS, 0, 0, 0);
-                    const bool kvalid = live && (mt * 16 + col < NSLOT);
-                    bf16x4_t pk, sk;
+                    for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
+                }
+                // the global fragments are dead (their copies are in the LDS): request the next round's -- the next cell's first -- now
+                __builtin_amdgcn_sched_barrier(0);
+                if (r + 1 < nround) load_tile(q_cell, g_cell, ty_n, tx_n, qf, gf);
+                else load_tile(q_next, g_next, ty_first, tx_first, qf, gf);
+                ty_cur = (r + 1 < nround) ? ty_n : ty_first;
+                tx_cur = (r + 1 < nround) ? tx_n : tx_first;
+                __builtin_amdgcn_sched_barrier(0);
+                BWD2_STAMP(1);   // rows' arrival + LDS copies + pass-1 MFMAs
+
+                float m = -INFINITY;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sS[rr], p.scale_log2e, -mcq[rr])) * invq[rr] : 0.f;
-                        pk[rr] = (bf16_t)pr;
-                        sk[rr] = (bf16_t)(p.scale * pr * (gS[rr] - dlq[rr]));
+                        if (mt * 16 + 15 >= NSLOT) sT[mt][rr] = (mt * 16 + grp * 4 + rr < NSLOT) ? sT[mt][rr] : -INFINITY;
+                        m = fmaxf(m, sT[mt][rr]);
                     }
-                    Pl[(wave * MT + mt) * 64 + lane] = pk;
-                    Sl[(wave * MT + mt) * 64 + lane] = sk;
+                m = naf_rows_max(m);
+                const float mc = m * p.scale_log2e;
+                float sum = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sT[mt][rr], p.scale_log2e, -mc));
+                        sT[mt][rr] = e;
+                        sum += e;
+                    }
+                sum = naf_rows_sum(sum);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                float delta = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        sT[mt][rr] *= inv;                       // P^T
+                        delta = fmaf(sT[mt][rr], gT[mt][rr], delta);
+                    }
+                delta = naf_rows_sum(delta);
+                bf16x8_t dsf[KST];
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int mt = 2 * ks + (j >> 2), rr = j & 3;
+                        dsf[ks][j] = (bf16_t)(p.scale * sT[mt][rr] * (gT[mt][rr] - delta));
+                    }
+
+                BWD2_STAMP(2);   // softmax, delta, dS^T
+                // ---- dQ^T[d][q] = K^T . dS^T ----
+                if (live) {
+                    bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct += 2) {
+                        f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KST; ++ks) {
+                            bf16x8_t k0, k1;
+                            {
+                                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16));
+                                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16));
+                                k0[0] = lo[0]; k0[1] = lo[1]; k0[2] = lo[2]; k0[3] = lo[3];
+                                k0[4] = hi[0]; k0[5] = hi[1]; k0[6] = hi[2]; k0[7] = hi[3];
+                            }
+                            {
+                                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2) + ct * 16 + 16));
+                                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(kt_of(ks * 2 + 1) + ct * 16 + 16));
+                                k1[0] = lo[0]; k1[1] = lo[1]; k1[2] = lo[2]; k1[3] = lo[3];
+                                k1[4] = hi[0]; k1[5] = hi[1]; k1[6] = hi[2]; k1[7] = hi[3];
+                            }
+                            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, dsf[ks], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, dsf[ks], a1, 0, 0, 0);
+                        }
+                        bf16x4_t ab, bb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ab[i] = (bf16_t)a0[i];
+                            bb[i] = (bf16_t)a1[i];
+                        }
+                        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                        *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    }
                 }
+
+                BWD2_STAMP(3);   // dQ
+                // ---- pass 2, "straight": S[q][key], dP[q][key] -- a lane owns one KEY: P and dS in the A-operand form of the
+                // contractions over queries.  The tile's rows come back from this wave's own LDS copy (the global fragments' registers
+                // already carry the next round's request). ----
+                {
+                    // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout; they travel through the
+                    // wave's own dS slots of this round's buffer, free until they are written below
+                    float* stw = reinterpret_cast<float*>(Sl + (wave * MT) * 64);
+                    if (grp == 0) {
+                        stw[col] = mc;
+                        stw[16 + col] = inv;
+                        stw[32 + col] = delta;
+                    }
+                    bf16x8_t q2[2], g2[DKS];
+                    q2[0] = *reinterpret_cast<const bf16x8_t*>(qrow);
+                    q2[1] = *reinterpret_cast<const bf16x8_t*>(qrow + 32);
+#pragma unroll
+                    for (int ks = 0; ks < DKS; ++ks) g2[ks] = *reinterpret_cast<const bf16x8_t*>(grow + ks * 32);
+                    const f32x4_t mcq = *reinterpret_cast<const f32x4_t*>(stw + grp * 4);
+                    const f32x4_t invq = *reinterpret_cast<const f32x4_t*>(stw + 16 + grp * 4);
+                    const f32x4_t dlq = *reinterpret_cast<const f32x4_t*>(stw + 32 + grp * 4);
+                    asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq) : "memory");
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4_t sS = {0.f, 0.f, 0.f, 0.f}, gS = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) sS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[ks], kfr[mt][ks], sS, 0, 0, 0);
+#pragma unroll
+                        for (int ks = 0; ks < DKS; ++ks) gS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g2[ks], vfr[mt][ks], gS, 0, 0, 0);
+                        const bool kvalid = live && (mt * 16 + col < NSLOT);
+                        bf16x4_t pk, sk;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sS[rr], p.scale_log2e, -mcq[rr])) * invq[rr] : 0.f;
+                            pk[rr] = (bf16_t)pr;
+                            sk[rr] = (bf16_t)(p.scale * pr * (gS[rr] - dlq[rr]));
+                        }
+                        Pl[(wave * MT + mt) * 64 + lane] = pk;
+                        Sl[(wave * MT + mt) * 64 + lane] = sk;
+                    }
+                }
+                BWD2_STAMP(4);   // pass 2: MFMAs, P / dS -> LDS
+                __syncthreads();   // this round's buffer is complete; the key waves have left the other one (and, by a cell's last
+                                   // round, have brought the other window buffer up to the next cell)
+                BWD2_STAMP(5);
+                BWD2_SUM(5);
+#ifdef NAF_BWD_TIMING2
+                { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[r & 3] += now_ - t2_; t2_ = now_; }
+#endif
             }
-            BWD2_STAMP(4);   // pass 2: MFMAs, P / dS -> LDS
-            __syncthreads();   // this round's buffer is complete; the key waves have left the other one
-            BWD2_STAMP(5);
-            BWD2_SUM(5);
+            cur = nxt;
         }
     } else {
         // =========================== key waves ===========================
-        const int wb = wave - 4;
+        const int wb = wave - 4, ktid = tid - 256;
         f32x4_t accV[MT][NVW], accK[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -322,92 +393,183 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
             for (int i = 0; i < NVW; ++i) accV[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-#ifdef NAF_BWD_TIMING
-        tacc[0] = __builtin_amdgcn_s_memtime() - t_begin;
-        constexpr int slot_[2] = {6, 5};
-        st_[0] = __builtin_amdgcn_s_memtime();
+        // add the sums of window column x of cell c to dK / dV in memory and clear them.  The column's KS keys are slots lo .. lo + KS - 1;
+        // acc[mt][rr] of lane group grp is slot mt*16 + 4 grp + rr: (mt, rr) pairs none of whose four slots is in the column are skipped
+        // by a scalar branch (at k = 7 four or five of the sixteen pairs take part)
+        const uint32_t lane_acc = (uint32_t)(wb * 16 + col);
+        auto flush_col = [&](const Cell& c, int x) __attribute__((always_inline)) {
+            const int lo = (x % KS) * KS;
+            const int64_t pix = (int64_t)c.y0 * p.w + x;
+            const uint32_t rowstep = (uint32_t)(p.w * p.heads);     // elements / 64 (dK), / Dv (dV) between window rows
+            float* dkp = p.dk + ((((int64_t)c.b * p.h) * p.w + pix) * p.heads + c.head) * 64;   // wave-uniform; the lane adds wb*16 + col
+            float* dvp = p.dv + ((((int64_t)c.b * p.h) * p.w + pix) * p.heads + c.head) * DV;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int d = mt * 16 + rr - lo;         // slot of lane group 0, relative to the column's first
+                    const bool any = (unsigned)d < (unsigned)KS || (unsigned)(d + 4) < (unsigned)KS || (unsigned)(d + 8) < (unsigned)KS || (unsigned)(d + 12) < (unsigned)KS;
+                    if (any) {
+                        const int ry = d + 4 * grp;
+#ifdef NAF_BWD_NO_ATOMICS   // experiments only: how much of the kernel is the atomic traffic
+                        if ((unsigned)ry < (unsigned)KS && p.scale > 1e30f) {
+#else
+                        if ((unsigned)ry < (unsigned)KS) {
 #endif
-        __syncthreads();   // round 0 is in its buffer
-#ifdef NAF_BWD_TIMING
-        tacc[5] += __builtin_amdgcn_s_memtime() - st_[0];
-#endif
-        for (int r = 0; r < nround; ++r) {
-            BWD2_STAMP(0);
-            const int buf = r & 1;
-            const bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
-            const bf16x4_t* Sl = Pl + G2::ps_elems;
-            const bf16_t* Qs = QG + buf * G2::qg_elems;
-            const bf16_t* Gs = Qs + 4 * 16 * KROW;
+                            atomicAdd(dkp + ((uint32_t)ry * rowstep * 64u + lane_acc), accK[mt][rr]);
+                            accK[mt][rr] = 0.f;
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                // B operands: queries 4*grp..+3 of tiles 2pr / 2pr+1 for column (16-wide tile nt, col)
-                auto tr_pair = [&](const bf16_t* base, int rowlen, int nt) __attribute__((always_inline)) {
-                    const bf16_t* a = base + ((2 * pr) * 16 + grp * 4 + (col >> 2)) * rowlen + (col & 3) * 4 + nt * 16;
-                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a);
-                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(a + 16 * rowlen));
-                    bf16x8_t o;
-                    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-                    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-                    return o;
-                };
-                const bf16x8_t bq = tr_pair(Qs, KROW, wb);
-                bf16x8_t bg[NVW];
-#pragma unroll
-                for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, NVT % 4 == 0 ? wb + 4 * i : min(wb + 4 * i, NVT - 1));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x4_t p0 = Pl[((2 * pr) * MT + mt) * 64 + lane], p1 = Pl[((2 * pr + 1) * MT + mt) * 64 + lane];
-                    const bf16x4_t s0 = Sl[((2 * pr) * MT + mt) * 64 + lane], s1 = Sl[((2 * pr + 1) * MT + mt) * 64 + lane];
-                    bf16x8_t pa, sa;
-                    pa[0] = p0[0]; pa[1] = p0[1]; pa[2] = p0[2]; pa[3] = p0[3];
-                    pa[4] = p1[0]; pa[5] = p1[1]; pa[6] = p1[2]; pa[7] = p1[3];
-                    sa[0] = s0[0]; sa[1] = s0[1]; sa[2] = s0[2]; sa[3] = s0[3];
-                    sa[4] = s1[0]; sa[5] = s1[1]; sa[6] = s1[2]; sa[7] = s1[3];
-                    accK[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, bq, accK[mt], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < NVW; ++i)
-                        if (NVT % 4 == 0 || wb + 4 * i < NVT) accV[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, bg[i], accV[mt][i], 0, 0, 0);
+                            for (int i = 0; i < NVW; ++i)
+                                if (NVT % 4 == 0 || wb + 4 * i < NVT) {
+                                    atomicAdd(dvp + ((uint32_t)ry * rowstep * (uint32_t)DV + lane_acc + i * 64), accV[mt][i][rr]);
+                                    accV[mt][i][rr] = 0.f;
+                                }
+                        }
+                    }
                 }
-            }
-            BWD2_STAMP(1);
-            if (r + 1 < nround) __syncthreads();   // the query waves have filled the other buffer; this one is free again
-            BWD2_STAMP(2);
-            BWD2_SUM(2);
-        }
-        BWD2_STAMP(0);
+        };
+        // The columns the next cell's window needs and its buffer does not hold travel through registers: requested in the query
+        // waves' second round of a cell, written in their third (fewer rounds per cell: in the last; the first is the step of the flush).
+        // Lane ktid < CCH owns 16-byte chunk ktid of EVERY column (row s_ry, chunk s_ch of the row's K or V part), so everything
+        // per lane is computed once and a column costs one 64-bit multiply-add and one load.
+        static_assert(CCH <= 256, "a window column must fit one pass of the key waves");
+        const int s_ry = ktid / RCH, s_ch = ktid - s_ry * RCH;
+        const bool s_on = ktid < CCH, s_isk = s_ch < 8;
+        const int64_t s_goff = s_isk ? (int64_t)s_ry * p.ks[2] + s_ch * 8 : (int64_t)s_ry * p.vs[2] + (s_ch - 8) * 8;
+        const int64_t s_xstr = s_isk ? p.ks[3] : p.vs[3];
+        const int s_loff = s_isk ? s_ry * KROW + s_ch * 8 : NSLOT * KROW + s_ry * VROW + (s_ch - 8) * 8;
+        const int s_lmul = s_isk ? KS * KROW : KS * VROW;
+        const bf16_t* s_base = nullptr;    // this lane's chunk at column 0 of the run in hand
+        int s_run = -1;
+        u32x4_t stage[KS];
+        int have0 = c0.x0, have1 = -4 * KS;    // first window column held by each buffer (of the run in hand; far away: nothing usable)
+        int st_xs = 0, st_n = 0;           // columns [st_xs, st_xs + st_n) are on their way
 
-        // ---- the cell's partial sums -> fp32 accumulators.  acc[mt][r] is key mt*16 + grp*4 + r, column col ----
-        float* dkb = p.dk + (((int64_t)b * p.h) * p.w * p.heads + head) * 64;
-        float* dvb = p.dv + (((int64_t)b * p.h) * p.w * p.heads + head) * DV;
+        Cell qc = c0;                  // where the query waves are at step g ...
+        int rq = 0, kq = 0;            // ... round rq of it, cell number kq of the walk
+        Cell kc = c0;                  // the cell the key waves work on at step g >= 1 ...
+        int rk = 0;                    // ... round rk of it
+#ifdef NAF_BWD_TIMING
+        constexpr int slot_[3] = {6, 7, 5};
+#endif
+        for (int g = 0;; ++g) {
+            BWD2_STAMP(0);
+            const bool more = qc.run < nrun;      // the query waves run a round in this step
+            if (g >= 1) {
+                const int buf = (g - 1) & 1;
+                const bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
+                const bf16x4_t* Sl = Pl + G2::ps_elems;
+                const bf16_t* Qs = QG + buf * G2::qg_elems;
+                const bf16_t* Gs = Qs + 4 * 16 * KROW;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+                for (int pr = 0; pr < 2; ++pr) {
+                    // B operands: queries 4*grp..+3 of tiles 2pr / 2pr+1 for column (16-wide tile nt, col)
+                    auto tr_pair = [&](const bf16_t* base, int rowlen, int nt) __attribute__((always_inline)) {
+                        const bf16_t* a = base + ((2 * pr) * 16 + grp * 4 + (col >> 2)) * rowlen + (col & 3) * 4 + nt * 16;
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a);
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(a + 16 * rowlen));
+                        bf16x8_t o;
+                        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+                        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+                        return o;
+                    };
+                    const bf16x8_t bq = tr_pair(Qs, KROW, wb);
+                    bf16x8_t bg[NVW];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int key = mt * 16 + grp * 4 + rr;
-                if (key < NSLOT) {
-                    const int ry = key / KS, rx = key - ry * KS;
-                    const int64_t cell = (int64_t)(y0 + ry) * p.w + (x0 + rx);
-                    atomicAdd(dkb + cell * p.heads * 64 + wb * 16 + col, accK[mt][rr]);
+                    for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, NVT % 4 == 0 ? wb + 4 * i : min(wb + 4 * i, NVT - 1));
 #pragma unroll
-                    for (int i = 0; i < NVW; ++i)
-                        if (NVT % 4 == 0 || wb + 4 * i < NVT) atomicAdd(dvb + cell * p.heads * DV + (wb + 4 * i) * 16 + col, accV[mt][i][rr]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16x4_t p0 = Pl[((2 * pr) * MT + mt) * 64 + lane], p1 = Pl[((2 * pr + 1) * MT + mt) * 64 + lane];
+                        const bf16x4_t s0 = Sl[((2 * pr) * MT + mt) * 64 + lane], s1 = Sl[((2 * pr + 1) * MT + mt) * 64 + lane];
+                        bf16x8_t pa, sa;
+                        pa[0] = p0[0]; pa[1] = p0[1]; pa[2] = p0[2]; pa[3] = p0[3];
+                        pa[4] = p1[0]; pa[5] = p1[1]; pa[6] = p1[2]; pa[7] = p1[3];
+                        sa[0] = s0[0]; sa[1] = s0[1]; sa[2] = s0[2]; sa[3] = s0[3];
+                        sa[4] = s1[0]; sa[5] = s1[1]; sa[6] = s1[2]; sa[7] = s1[3];
+                        accK[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, bq, accK[mt], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < NVW; ++i)
+                            if (NVT % 4 == 0 || wb + 4 * i < NVT) accV[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, bg[i], accV[mt][i], 0, 0, 0);
+                    }
+                }
+                BWD2_STAMP(1);
+                if (++rk == nround) {
+                    // the cell is complete: the columns its successor's window no longer holds (all of them at the end of a run) leave
+                    const Cell nk = after(kc);
+                    const int keep = same_run(nk, kc) ? nk.x0 : kc.x0 + KS;
+                    for (int x = kc.x0; x < keep; ++x) flush_col(kc, x);
+                    kc = nk;
+                    rk = 0;
+                }
+            } else {
+                BWD2_STAMP(1);
+            }
+            BWD2_STAMP(2);
+            if (!more) break;
+#ifdef NAF_BWD_TIMING2
+            const int rq_ = rq;
+#endif
+            {
+                const Cell nq = after(qc);
+                const bool stage_next = nq.run < nrun;
+                const int nb = (kq + 1) & 1;
+                if (stage_next && rq == min(1, nround - 1)) {
+                    // columns of nq's window that buffer nb does not hold
+                    const int old = same_run(nq, qc) ? (nb ? have1 : have0) : -4 * KS;
+                    st_n = min(KS, nq.x0 - old);
+                    st_xs = nq.x0 + KS - st_n;
+                    if (nq.run != s_run) {
+                        s_run = nq.run;
+                        const bf16_t* kb = p.k + nq.b * p.ks[0] + nq.head * p.ks[1] + (int64_t)nq.y0 * p.ks[2];
+                        const bf16_t* vb = p.v + nq.b * p.vs[0] + nq.head * p.vs[1] + (int64_t)nq.y0 * p.vs[2];
+                        s_base = (s_isk ? kb : vb) + s_goff;
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j)
+                        if (j < st_n && s_on) stage[j] = *reinterpret_cast<const u32x4_t*>(s_base + (int64_t)(st_xs + j) * s_xstr);
+                }
+                if (stage_next && rq == min(2, nround - 1)) {
+                    bf16_t* dst = KV + nb * G2::kv_elems + s_loff;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j)
+                        if (j < st_n && s_on) *reinterpret_cast<u32x4_t*>(dst + ((st_xs + j) % KS) * s_lmul) = stage[j];
+                    // (the other buffer holds a window of the previous run when nq opens a new one: nothing of it can be kept)
+                    const int other = same_run(nq, qc) ? (nb ? have0 : have1) : -4 * KS;
+                    have0 = nb ? other : nq.x0;
+                    have1 = nb ? nq.x0 : other;
+                }
+                if (++rq == nround) {
+                    rq = 0;
+                    ++kq;
+                    qc = nq;
                 }
             }
-#ifdef NAF_BWD_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        tacc[7] = __builtin_amdgcn_s_memtime() - st_[0];   // the atomics' issue
+#ifdef NAF_BWD_TIMING2
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long tw_ = __builtin_amdgcn_s_memtime();
 #endif
+            __syncthreads();
+#ifdef NAF_BWD_TIMING2
+            { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[rq_ & 3] += tw_ - t2_; tacc2[4 + (rq_ & 3)] += now_ - tw_; t2_ = now_; }
+#endif
+            BWD2_STAMP(3);
+            BWD2_SUM(3);
+        }
     }
 #ifdef NAF_BWD_TIMING
     if (lane == 0)
         for (int i = 0; i < 8; ++i) p.tim[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tacc[i];
+#endif
+#ifdef NAF_BWD_TIMING2
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) p.tim[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tacc2[i];
 #endif
 }
 
 // Windows whose fragments a query wave can hold beside its working set (hipcc 7.2: no scratch up to ~160 fragment registers)
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 7 && XnaBwd2Geom<KS, DV>::frag_regs <= 128 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
+    return KS <= 7 && XnaBwd2Geom<KS, DV>::frag_regs <= 128 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024 && KS * (8 + DV / 8) <= 256;
 }
 
 template <int KS, int DV>
@@ -422,7 +584,23 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
             naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
             return NAF_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(512), lds, s, p);
+        // runs of cells: whole cell rows when they fill the chip evenly, otherwise the segment length with the least estimated time
+        // (a run costs its cells plus ~1.5 cells of window staging and final flush)
+        const int ncu = naf_cu_count();
+        const int64_t rows = (int64_t)p.B * p.h * p.heads;
+        int best_len = p.w;
+        double best = 1e300;
+        for (int len = p.w; len >= 1; --len) {
+            const int64_t runs = rows * ((p.w + len - 1) / len);
+            const double cost = (double)((runs + ncu - 1) / ncu) * (len + 1.5);
+            if (cost < best * 0.999) { best = cost; best_len = len; }
+        }
+        XnaBwdParams q = p;
+        q.seg_len = best_len;
+        q.nseg = (p.w + best_len - 1) / best_len;
+        const int64_t runs = rows * q.nseg;
+        q.nblocks = (uint32_t)runs;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(runs < ncu ? runs : ncu)), dim3(512), lds, s, q);   // one resident workgroup per CU
         return naf_check_launch("xna_bwd2_kernel");
     }
 }

@@ -37,9 +37,10 @@ struct XnaBwdParams {
     float* dv;   // [B, h, w, heads, Dv]
     int32_t B, heads, Ho, Wo, h, w, dy, dx;
     uint32_t nblocks;
+    int32_t seg_len, nseg;   // xna_bwd2_kernel.h: cells per run, runs per cell row (nblocks = runs there)
     float scale, scale_log2e;
     int64_t qs[4], ks[4], vs[4], gs[4], dqs[4];  // {b, head, y, x} element strides (gs: dout)
-#ifdef NAF_BWD_TIMING
+#if defined(NAF_BWD_TIMING) || defined(NAF_BWD_TIMING2)
     unsigned long long* tim;   // tools/xna_bwd_probe.hip: [workgroup][wave][8] s_memtime sums per phase
 #endif
 };

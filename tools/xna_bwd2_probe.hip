@@ -31,34 +31,47 @@ int main(int argc, char** argv) {
     XnaBwdParams p;
     p.q = q; p.k = k; p.v = v; p.dout = g; p.dq = dq; p.dk = dk; p.dv = dv;
     p.B = 1; p.heads = heads; p.Ho = out; p.Wo = out; p.h = lr; p.w = lr; p.dy = out / lr; p.dx = out / lr;
-    p.nblocks = (uint32_t)(lr * lr * heads);
+    const int nseg = argc > 3 ? atoi(argv[3]) : 1;   // runs per cell row
+    p.seg_len = (lr + nseg - 1) / nseg; p.nseg = (lr + p.seg_len - 1) / p.seg_len;
+    p.nblocks = (uint32_t)(lr * heads * p.nseg);
+    const unsigned grid = p.nblocks < 256u ? p.nblocks : 256u;
     p.scale = 0.125f; p.scale_log2e = 0.125f * 1.4426950408889634f;
     const int64_t qs[4] = {(int64_t)nq, 64, (int64_t)out * heads * 64, (int64_t)heads * 64};
     const int64_t gs[4] = {(int64_t)ng, DV, (int64_t)out * heads * DV, (int64_t)heads * DV};
     const int64_t ks[4] = {(int64_t)nk, 64, (int64_t)lr * heads * 64, (int64_t)heads * 64};
     const int64_t vs[4] = {(int64_t)nv, DV, (int64_t)lr * heads * DV, (int64_t)heads * DV};
     for (int i = 0; i < 4; ++i) { p.qs[i] = qs[i]; p.dqs[i] = qs[i]; p.gs[i] = gs[i]; p.ks[i] = ks[i]; p.vs[i] = vs[i]; }
-    CK(hipMalloc(&tim, (size_t)p.nblocks * 8 * 8 * 8));
+#if defined(NAF_BWD_TIMING) || defined(NAF_BWD_TIMING2)
+    CK(hipMalloc(&tim, (size_t)grid * 8 * 8 * 8));
     p.tim = tim;
+#endif
     constexpr size_t lds = XnaBwd2Geom<KS, DV>::lds_bytes();
     auto kern = xna_bwd2_kernel<KS, DV>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(512), lds, 0, p);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(p.nblocks), dim3(512), lds, 0, p);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> t((size_t)p.nblocks * 8 * 8);
+    printf("xna_bwd2_kernel<%d, %d>  %dx%d -> %dx%d, %d runs of %d cells: %.4f ms per launch, LDS %zu B\n", KS, DV, lr, lr, out, out, (int)p.nblocks, p.seg_len, ms / 10, lds);
+#if !defined(NAF_BWD_TIMING) && !defined(NAF_BWD_TIMING2)
+    (void)tim; return 0;
+#else
+    std::vector<unsigned long long> t((size_t)grid * 8 * 8);
     CK(hipMemcpy(t.data(), tim, t.size() * 8, hipMemcpyDeviceToHost));
     double s[2][8] = {{0}}; double tot[2] = {0, 0};
     for (size_t i = 0; i < t.size(); ++i) { const int role = (int)((i >> 3) & 7) >= 4; s[role][i & 7] += (double)t[i]; tot[role] += (double)t[i]; }
-    const char* name[8] = {"prologue (windows -> LDS [-> registers])", "rows' arrival + LDS copies + pass-1 MFMAs", "softmax, delta, dS^T", "dQ (tr reads, MFMAs, stores)",
-                           "pass 2 (MFMAs, P / dS -> LDS)", "barrier", "dK / dV MFMAs of a round", "atomics (issue)"};
-    printf("xna_bwd2_kernel<%d, %d>  %dx%d -> %dx%d: %.4f ms per launch (with timers), LDS %zu B\n", KS, DV, lr, lr, out, out, ms / 10, lds);
+#ifdef NAF_BWD_TIMING2
+    const char* name[8] = {"q: round 0 of a cell / k: work beside the query waves' round 0", "round 1", "round 2", "round 3", "q: cell switch (fragments <- LDS) / k: barrier wait, round 0", "k: barrier wait, round 1", "k: barrier wait, round 2", "k: barrier wait, round 3"};
+#else
+    const char* name[8] = {"windows -> LDS (first cell) -> registers", "rows' arrival + LDS copies + pass-1 MFMAs", "softmax, delta, dS^T", "dQ (tr reads, MFMAs, stores)",
+                           "pass 2 (MFMAs, P / dS -> LDS)", "barrier (key waves: + window columns)", "dK / dV MFMAs", "leaving columns -> memory (atomics' issue)"};
+#endif
     for (int role = 0; role < 2; ++role) {
-        printf(" %s waves: %.0f ticks per wave\n", role ? "key" : "query", tot[role] / (p.nblocks * 4.0));
-        for (int i = 0; i < 8; ++i) if (s[role][i] > 0) printf("   %-46s %5.1f %%   (%.0f ticks per wave)\n", name[i], 100.0 * s[role][i] / tot[role], s[role][i] / (p.nblocks * 4.0));
+        printf(" %s waves: %.0f ticks per wave\n", role ? "key" : "query", tot[role] / (grid * 4.0));
+        for (int i = 0; i < 8; ++i) if (s[role][i] > 0) printf("   %-46s %5.1f %%   (%.0f ticks per wave)\n", name[i], 100.0 * s[role][i] / tot[role], s[role][i] / (grid * 4.0));
     }
     return 0;
+#endif
 }
