@@ -33,9 +33,10 @@ template <int KS, int DV>
 struct XnaBwd2Geom {
     using G = XnaBwdGeom<KS, DV>;
     static constexpr size_t kv_elems = (size_t)G::NSLOT * (G::KROW + G::VROW);  // bf16 per K + V window buffer
-    static constexpr size_t ps_elems = (size_t)4 * G::MT * 64;                  // bf16x4 per P (or dS) buffer of a round
+    static constexpr int PROW = G::KPAD + 8;                                    // bf16 per row of the P / dS matrices [query][slot]
+    static constexpr size_t ps_elems = (size_t)4 * 16 * PROW;                   // bf16 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
-    static constexpr size_t lds_bytes() { return 2 * kv_elems * 2 + 2 * (2 * ps_elems * 8) + 2 * (qg_elems * 2); }
+    static constexpr size_t lds_bytes() { return 2 * kv_elems * 2 + 2 * (2 * ps_elems * 2) + 2 * (qg_elems * 2); }
     // K and V fragments of the whole window in registers: MT * (2 + Dv / 32) * 4 per lane
     static constexpr int frag_regs = G::MT * (2 + DV / 32) * 4;
 };
@@ -45,13 +46,13 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     using G = XnaBwdGeom<KS, DV>;
     using G2 = XnaBwd2Geom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
-    constexpr int DKS = DV / 32;
+    constexpr int DKS = DV / 32, PROW = G2::PROW;
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* KV = reinterpret_cast<bf16_t*>(smem);                                // [2 window buffers][K: NSLOT x KROW | V: NSLOT x VROW]
-    bf16x4_t* PS = reinterpret_cast<bf16x4_t*>(KV + 2 * G2::kv_elems);           // [2 round buffers][P | dS][4 tiles][MT][64 lanes]
-    bf16_t* QG = reinterpret_cast<bf16_t*>(PS + 2 * 2 * G2::ps_elems);           // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
+    bf16_t* PS = KV + 2 * G2::kv_elems;                                          // [2 round buffers][P | dS][4 tiles x 16 queries][PROW]
+    bf16_t* QG = PS + 2 * 2 * G2::ps_elems;                                      // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             for (int r = 0; r < nround; ++r, ++g) {
                 BWD2_STAMP(0);
                 const int buf = g & 1;
-                bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
-                bf16x4_t* Sl = Pl + G2::ps_elems;
+                bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
+                bf16_t* Sq = Pq + G2::ps_elems;
                 bf16_t* Qs = QG + buf * G2::qg_elems;
                 bf16_t* Gs = Qs + 4 * 16 * KROW;
                 const int t = 4 * r + wave;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 if (tx_n >= tpr) { tx_n -= tpr; ++ty_n; }
                 if (t + 4 >= ntile) { ty_n = p.dy - 1; tx_n = tpr - 1; }
 
-                // row-major LDS copies: the key waves' B operands (ds_read_tr) and this wave's own second pass
+                // row-major LDS copies: the key waves' B operands (ds_read_tr)
                 bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
                 bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
                 *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
 
-                // ---- pass 1, "swapped": S^T[key][q], dP^T[key][q] -- a lane owns one QUERY ----
+                // ---- S^T[key][q] = K . Q^T, dP^T[key][q] = V . dO^T: a lane owns one QUERY (softmax statistics, delta and dS^T as the B
+                // operand of dQ^T without any exchange), the windows' fragments come from registers ----
                 f32x4_t sT[MT], gT[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 ty_cur = (r + 1 < nround) ? ty_n : ty_first;
                 tx_cur = (r + 1 < nround) ? tx_n : tx_first;
                 __builtin_amdgcn_sched_barrier(0);
-                BWD2_STAMP(1);   // rows' arrival + LDS copies + pass-1 MFMAs
+                BWD2_STAMP(1);   // rows' arrival + LDS copies + S / dP MFMAs
 
                 float m = -INFINITY;
 #pragma unroll
@@ -293,7 +295,26 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                         dsf[ks][j] = (bf16_t)(p.scale * sT[mt][rr] * (gT[mt][rr] - delta));
                     }
 
-                BWD2_STAMP(2);   // softmax, delta, dS^T
+                // P and dS for the key waves: row-major [query][slot] -- a lane holds four consecutive slots of ITS query per key tile, one
+                // 8-byte store each; the key waves read them back transposed (ds_read_tr) as the A operands of the contractions over queries.
+                // (Rounds 2-4 evaluated S and dP a second time with the operands swapped to get this layout out of the MFMA: 32 more
+                // MFMAs, 16 more exponentials and a statistics exchange per tile.)
+                {
+                    bf16_t* prow = Pq + (wave * 16 + col) * PROW + grp * 4;
+                    bf16_t* srow = Sq + (wave * 16 + col) * PROW + grp * 4;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        bf16x4_t pk, sk;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            pk[rr] = live ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
+                            sk[rr] = live ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
+                        }
+                        *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pk;
+                        *reinterpret_cast<bf16x4_t*>(srow + mt * 16) = sk;
+                    }
+                }
+                BWD2_STAMP(2);   // softmax, delta, dS^T, P / dS -> LDS
                 // ---- dQ^T[d][q] = K^T . dS^T ----
                 if (live) {
                     bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
@@ -332,47 +353,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 }
 
                 BWD2_STAMP(3);   // dQ
-                // ---- pass 2, "straight": S[q][key], dP[q][key] -- a lane owns one KEY: P and dS in the A-operand form of the
-                // contractions over queries.  The tile's rows come back from this wave's own LDS copy (the global fragments' registers
-                // already carry the next round's request). ----
-                {
-                    // statistics of query 4*grp + r live in lane (col = 4*grp + r) of the query-major layout; they travel through the
-                    // wave's own dS slots of this round's buffer, free until they are written below
-                    float* stw = reinterpret_cast<float*>(Sl + (wave * MT) * 64);
-                    if (grp == 0) {
-                        stw[col] = mc;
-                        stw[16 + col] = inv;
-                        stw[32 + col] = delta;
-                    }
-                    bf16x8_t q2[2], g2[DKS];
-                    q2[0] = *reinterpret_cast<const bf16x8_t*>(qrow);
-                    q2[1] = *reinterpret_cast<const bf16x8_t*>(qrow + 32);
-#pragma unroll
-                    for (int ks = 0; ks < DKS; ++ks) g2[ks] = *reinterpret_cast<const bf16x8_t*>(grow + ks * 32);
-                    const f32x4_t mcq = *reinterpret_cast<const f32x4_t*>(stw + grp * 4);
-                    const f32x4_t invq = *reinterpret_cast<const f32x4_t*>(stw + 16 + grp * 4);
-                    const f32x4_t dlq = *reinterpret_cast<const f32x4_t*>(stw + 32 + grp * 4);
-                    asm volatile("" ::"v"(mcq), "v"(invq), "v"(dlq) : "memory");
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4_t sS = {0.f, 0.f, 0.f, 0.f}, gS = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) sS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[ks], kfr[mt][ks], sS, 0, 0, 0);
-#pragma unroll
-                        for (int ks = 0; ks < DKS; ++ks) gS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g2[ks], vfr[mt][ks], gS, 0, 0, 0);
-                        const bool kvalid = live && (mt * 16 + col < NSLOT);
-                        bf16x4_t pk, sk;
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sS[rr], p.scale_log2e, -mcq[rr])) * invq[rr] : 0.f;
-                            pk[rr] = (bf16_t)pr;
-                            sk[rr] = (bf16_t)(p.scale * pr * (gS[rr] - dlq[rr]));
-                        }
-                        Pl[(wave * MT + mt) * 64 + lane] = pk;
-                        Sl[(wave * MT + mt) * 64 + lane] = sk;
-                    }
-                }
-                BWD2_STAMP(4);   // pass 2: MFMAs, P / dS -> LDS
+                BWD2_STAMP(4);
                 __syncthreads();   // this round's buffer is complete; the key waves have left the other one (and, by a cell's last
                                    // round, have brought the other window buffer up to the next cell)
                 BWD2_STAMP(5);
@@ -457,8 +438,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             const bool more = qc.run < nrun;      // the query waves run a round in this step
             if (g >= 1) {
                 const int buf = (g - 1) & 1;
-                const bf16x4_t* Pl = PS + buf * (2 * G2::ps_elems);
-                const bf16x4_t* Sl = Pl + G2::ps_elems;
+                const bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
+                const bf16_t* Sq = Pq + G2::ps_elems;
                 const bf16_t* Qs = QG + buf * G2::qg_elems;
                 const bf16_t* Gs = Qs + 4 * 16 * KROW;
 #pragma unroll
@@ -479,13 +460,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, NVT % 4 == 0 ? wb + 4 * i : min(wb + 4 * i, NVT - 1));
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const bf16x4_t p0 = Pl[((2 * pr) * MT + mt) * 64 + lane], p1 = Pl[((2 * pr + 1) * MT + mt) * 64 + lane];
-                        const bf16x4_t s0 = Sl[((2 * pr) * MT + mt) * 64 + lane], s1 = Sl[((2 * pr + 1) * MT + mt) * 64 + lane];
-                        bf16x8_t pa, sa;
-                        pa[0] = p0[0]; pa[1] = p0[1]; pa[2] = p0[2]; pa[3] = p0[3];
-                        pa[4] = p1[0]; pa[5] = p1[1]; pa[6] = p1[2]; pa[7] = p1[3];
-                        sa[0] = s0[0]; sa[1] = s0[1]; sa[2] = s0[2]; sa[3] = s0[3];
-                        sa[4] = s1[0]; sa[5] = s1[1]; sa[6] = s1[2]; sa[7] = s1[3];
+                        // A operands: slot mt*16 + col, queries 4*grp..+3 of the two tiles -- the transposed read of [query][slot]
+                        const bf16x8_t pa = tr_pair(Pq, PROW, mt), sa = tr_pair(Sq, PROW, mt);
                         accK[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, bq, accK[mt], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NVW; ++i)
