@@ -70,44 +70,32 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     // blockIdx.x, blockIdx.x + gridDim.x, ...  Inside a run the window moves one column at a time, and a key keeps its SLOT
     // ((column mod KS) * KS + row) from cell to cell: only the column that enters is fetched, only the column that leaves is added to
     // dK / dV in memory (1/KS of the per-cell atomics and window reads of the one-cell-at-a-time kernel).
+    // The walks below carry as little state as they can -- every scalar instruction of the bookkeeping is issued beside the MFMAs of
+    // the round in hand, and what does not fit the SGPRs is spilled into VGPR lanes: a run is decoded (divisions) when it is entered,
+    // inside a run everything moves by increments.
     const int nwg = (int)gridDim.x, first = (int)blockIdx.x;
     const int nrun = (int)p.nblocks;
-    struct Cell { int run, pos, len, b, cy0, cx0, head, y0, x0; };
-    auto at = [&](int run, int pos) __attribute__((always_inline)) {
-        Cell c;
+    struct Run { int b, cy0, head, y0, xs, len; };
+    auto decode = [&](int run) __attribute__((always_inline)) {
+        Run c;
         uint32_t L = (uint32_t)min(run, nrun - 1);
         const int seg = L % p.nseg; L /= p.nseg;
         c.head = L % p.heads;       L /= p.heads;
         c.cy0 = L % p.h;
         c.b = L / p.h;
-        c.run = run;
-        c.len = min(p.seg_len, p.w - seg * p.seg_len);
-        c.pos = pos;
-        c.cx0 = seg * p.seg_len + pos;
+        c.xs = seg * p.seg_len;
+        c.len = min(p.seg_len, p.w - c.xs);
         c.y0 = min(max(c.cy0 - KS / 2, 0), p.h - KS);
-        c.x0 = min(max(c.cx0 - KS / 2, 0), p.w - KS);
         return c;
     };
-    // the cell after c in this workgroup's walk (run >= nrun: there is none)
-    // (inside a run: one column to the right -- no divisions; every instruction of the walk is issued beside the MFMAs of the round in hand)
-    auto after = [&](const Cell& c) __attribute__((always_inline)) {
-        if (c.pos + 1 < c.len) {
-            Cell n = c;
-            n.pos = c.pos + 1;
-            n.cx0 = c.cx0 + 1;
-            n.x0 = min(max(n.cx0 - KS / 2, 0), p.w - KS);
-            return n;
-        }
-        return at(c.run + nwg, 0);
-    };
-    auto same_run = [&](const Cell& a, const Cell& c) __attribute__((always_inline)) { return a.run == c.run; };
+    auto x0_of = [&](int cx) __attribute__((always_inline)) { return min(max(cx - KS / 2, 0), p.w - KS); };
 
     const int tpr = p.dx >> 4, ntile = p.dy * tpr;
     const int nround = (ntile + 3) >> 2;
 
     // 16-byte chunk i of window column x (rows y0 .. y0 + KS - 1; per row 8 chunks of K, then Dv/8 of V) -> global address, LDS offset
     constexpr int VCH = DV / 8, RCH = 8 + VCH, CCH = KS * RCH;   // chunks per key, per column
-    auto col_chunk = [&](const Cell& c, int x, int i, int& off) __attribute__((always_inline)) -> const bf16_t* {
+    auto col_chunk = [&](const Run& c, int x, int i, int& off) __attribute__((always_inline)) -> const bf16_t* {
         const int ry = i / RCH, ch = i - ry * RCH;
         const int slot = (x % KS) * KS + ry;
         const int64_t pix = (int64_t)(c.y0 + ry);
@@ -119,34 +107,12 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         return p.v + c.b * p.vs[0] + c.head * p.vs[1] + pix * p.vs[2] + (int64_t)x * p.vs[3] + (ch - 8) * 8;
     };
 
-    // fragments of the tile at row ty, 16-column block tx of the cell whose first query / gradient row is at qc / gc: a wave-uniform
-    // base and one 32-bit lane offset per tensor (global_load with a scalar base: no per-lane 64-bit address arithmetic in the rounds)
-    const uint32_t lane_q = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u, lane_g = (uint32_t)(col * (int)p.gs[3] + grp * 8) * 2u;
-    auto load_tile = [&](const bf16_t* qc, const bf16_t* gc, int ty_, int tx_, bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
-        const char* qp = reinterpret_cast<const char*>(qc + (int64_t)ty_ * p.qs[2] + (int64_t)(tx_ * 16) * p.qs[3]);
-        const char* gp = reinterpret_cast<const char*>(gc + (int64_t)ty_ * p.gs[2] + (int64_t)(tx_ * 16) * p.gs[3]);
-        qv[0] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q);
-        qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q + 64);
-#pragma unroll
-        for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + lane_g + ks * 64);
-    };
-    // tile t = 4 r + wave of a cell, r = 0, 1, ...: row / block of this wave's tile in round 0, and the step from round to round
-    const int ty_first = min(wave, ntile - 1) / tpr, tx_first = min(wave, ntile - 1) % tpr;
-    const int ty_step = 4 / tpr, tx_step = 4 % tpr;
-    auto q_of = [&](const Cell& c) __attribute__((always_inline)) {
-        return p.q + c.b * p.qs[0] + c.head * p.qs[1] + (int64_t)(c.cy0 * p.dy) * p.qs[2] + (int64_t)(c.cx0 * p.dx) * p.qs[3];
-    };
-    auto g_of = [&](const Cell& c) __attribute__((always_inline)) {
-        return p.dout + c.b * p.gs[0] + c.head * p.gs[1] + (int64_t)(c.cy0 * p.dy) * p.gs[2] + (int64_t)(c.cx0 * p.dx) * p.gs[3];
-    };
-
-    const Cell c0 = at(first, 0);
-    bf16x8_t qf[2], gf[DKS];
-    if (query_wave) load_tile(q_of(c0), g_of(c0), ty_first, tx_first, qf, gf);   // the first round's rows are on their way while the windows are staged
+    const Run r0 = decode(first);
 
     // ---- the first cell's windows: all eight waves (loads of a batch issued before the first LDS write) ----
-    {
+    auto stage_first = [&]() __attribute__((always_inline)) {
         constexpr int TOT = KS * CCH, NIT = (TOT + 511) / 512, BATCH = 8;
+        const int x0 = x0_of(r0.xs);
 #pragma unroll
         for (int j0 = 0; j0 < NIT; j0 += BATCH) {
             u32x4_t val[BATCH];
@@ -155,27 +121,80 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             for (int u = 0; u < BATCH; ++u)
                 if (j0 + u < NIT) {
                     const int i = min((j0 + u) * 512 + tid, TOT - 1);
-                    val[u] = *reinterpret_cast<const u32x4_t*>(col_chunk(c0, c0.x0 + i / CCH, i % CCH, off[u]));
+                    val[u] = *reinterpret_cast<const u32x4_t*>(col_chunk(r0, x0 + i / CCH, i % CCH, off[u]));
                 }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u)
                 if (j0 + u < NIT) *reinterpret_cast<u32x4_t*>(KV + off[u]) = val[u];     // clamped duplicates rewrite the last chunk
         }
-    }
-    __syncthreads();
+    };
 
     if (query_wave) {
         // =========================== query waves ===========================
+        // Rows of a tile: a wave-uniform base and one 32-bit lane offset per tensor.  ONE set of row fragments, re-requested for the
+        // next round as soon as the S / dP MFMAs have consumed it.  (Two sets, each requested two rounds ahead, were built and measured:
+        // beside the resident window fragments they do not fit the 256 registers -- the K fragments and the last two V key tiles then
+        // have to come from the LDS per round, hipcc chains those reads one by one in front of their MFMAs, and the kernel is 5 %
+        // slower, 0.78 against 0.74 ms at G1: profiles/r05_bwd2_phases.txt.)
+        const uint32_t lane_q = (uint32_t)(col * (int)p.qs[3] + grp * 8) * 2u, lane_g = (uint32_t)(col * (int)p.gs[3] + grp * 8) * 2u;
+        // tile t = 4 r + wave of a cell, r = 0, 1, ...: row / 16-column block of this wave's tile in round 0, the step from round to round
+        const int ty_first = min(wave, ntile - 1) / tpr, tx_first = min(wave, ntile - 1) % tpr;
+        const int ty_step = 4 / tpr, tx_step = 4 % tpr;
+        auto q_of = [&](const Run& c) __attribute__((always_inline)) {
+            return p.q + c.b * p.qs[0] + c.head * p.qs[1] + (int64_t)(c.cy0 * p.dy) * p.qs[2] + (int64_t)(c.xs * p.dx) * p.qs[3];
+        };
+        auto g_of = [&](const Run& c) __attribute__((always_inline)) {
+            return p.dout + c.b * p.gs[0] + c.head * p.gs[1] + (int64_t)(c.cy0 * p.dy) * p.gs[2] + (int64_t)(c.xs * p.dx) * p.gs[3];
+        };
+        auto dq_of = [&](const Run& c) __attribute__((always_inline)) {
+            return p.dq + c.b * p.dqs[0] + c.head * p.dqs[1] + (int64_t)(c.cy0 * p.dy) * p.dqs[2] + (int64_t)(c.xs * p.dx) * p.dqs[3];
+        };
+        // the walker: the round that is requested next (one ahead of the round in hand)
+        int a_run = first, a_pos = 0, a_len = r0.len, a_r = 0, a_ty = ty_first, a_tx = tx_first;
+        const bf16_t* a_q = q_of(r0);
+        const bf16_t* a_g = g_of(r0);
+        bf16x8_t qf[2], gf[DKS];
+        auto request = [&](bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
+            const char* qp = reinterpret_cast<const char*>(a_q + (int64_t)a_ty * p.qs[2] + (int64_t)(a_tx * 16) * p.qs[3]);
+            const char* gp = reinterpret_cast<const char*>(a_g + (int64_t)a_ty * p.gs[2] + (int64_t)(a_tx * 16) * p.gs[3]);
+            qv[0] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q);
+            qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q + 64);
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + lane_g + ks * 64);
+            // one round on (past the last cell the walker stays on the last tile: harmless re-reads)
+            if (a_r + 1 < nround) {
+                ++a_r;
+                a_ty += ty_step; a_tx += tx_step;
+                if (a_tx >= tpr) { a_tx -= tpr; ++a_ty; }
+                if (4 * a_r + wave >= ntile) { a_ty = p.dy - 1; a_tx = tpr - 1; }
+            } else if (a_pos + 1 < a_len) {
+                ++a_pos;
+                a_q += (int64_t)p.dx * p.qs[3];
+                a_g += (int64_t)p.dx * p.gs[3];
+                a_r = 0; a_ty = ty_first; a_tx = tx_first;
+            } else if (a_run + nwg < nrun) {
+                a_run += nwg;
+                const Run c = decode(a_run);
+                a_pos = 0; a_len = c.len;
+                a_q = q_of(c); a_g = g_of(c);
+                a_r = 0; a_ty = ty_first; a_tx = tx_first;
+            }
+        };
+        request(qf, gf);      // the first round's rows are on their way while the windows are staged
+        stage_first();
+        __syncthreads();
+
         auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
-        bf16x8_t kfr[MT][2], vfr[MT][DKS];
-        Cell cur = c0;
-        int g = 0;   // rounds since the kernel started: round buffer g & 1
+        bf16x8_t kfr[MT][2], vfr[MT][DKS];   // the windows as operand fragments, resident for the whole cell
+        int c_run = first, c_pos = 0, c_len = r0.len;
+        bf16_t* dq_cell = dq_of(r0);
+        int g = 0;   // rounds since the kernel started: round buffer g & 1, row set g & 1
         int kc = 0;  // cells since the kernel started: window buffer kc & 1
         int ty_cur = ty_first, tx_cur = tx_first;   // this wave's tile of the round in hand
 #ifdef NAF_BWD_TIMING
         constexpr int slot_[5] = {1, 2, 3, 4, 5};
 #endif
-        for (; cur.run < nrun; ++kc) {
+        for (; c_run < nrun; ++kc) {
 #ifdef NAF_BWD_TIMING
             st_[6] = __builtin_amdgcn_s_memtime();
 #endif
@@ -188,7 +207,6 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const int r = min(blk * 16 + grp * 4 + (col >> 2), NSLOT - 1);
                 return Ks + r * KROW + (col & 3) * 4;
             };
-            // the windows as operand fragments, resident for the whole cell (row = slot mt*16 + col, dims / channels grp*8 + 32 ks ..)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
@@ -198,17 +216,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
             }
-            const Cell nxt = after(cur);
-            const Cell pre = nxt.run < nrun ? nxt : cur;         // whose first rows the last round requests (nobody's: harmless re-read)
-            const bf16_t* q_cell = q_of(cur);
-            const bf16_t* g_cell = g_of(cur);
-            const bf16_t* q_next = q_of(pre);
-            const bf16_t* g_next = g_of(pre);
-            bf16_t* dq_cell = p.dq + cur.b * p.dqs[0] + cur.head * p.dqs[1] + (int64_t)(cur.cy0 * p.dy) * p.dqs[2] + (int64_t)(cur.cx0 * p.dx) * p.dqs[3];
 #ifdef NAF_BWD_TIMING
             tacc[0] += __builtin_amdgcn_s_memtime() - (kc == 0 ? t_begin : st_[6]);   // windows -> LDS (first cell) -> registers
 #endif
-
 #ifdef NAF_BWD_TIMING2
             __builtin_amdgcn_sched_barrier(0);
             { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[4] += now_ - tcs_; t2_ = now_; }
@@ -223,12 +233,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const int t = 4 * r + wave;
                 const bool live = t < ntile;                       // dead tiles compute on the cell's last tile and contribute zeros
                 const int ty = ty_cur, tx0 = tx_cur * 16;
-                // where the tile of the next round is (clamped to the cell's last)
-                int ty_n = ty_cur + ty_step, tx_n = tx_cur + tx_step;
-                if (tx_n >= tpr) { tx_n -= tpr; ++ty_n; }
-                if (t + 4 >= ntile) { ty_n = p.dy - 1; tx_n = tpr - 1; }
 
-                // row-major LDS copies: the key waves' B operands (ds_read_tr)
+                // row-major LDS copies of the rows: the key waves' B operands
                 bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
                 bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
                 *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
@@ -237,22 +243,23 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
 
                 // ---- S^T[key][q] = K . Q^T, dP^T[key][q] = V . dO^T: a lane owns one QUERY (softmax statistics, delta and dS^T as the B
-                // operand of dQ^T without any exchange), the windows' fragments come from registers ----
+                // operand of dQ^T without any exchange) ----
                 f32x4_t sT[MT], gT[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    sT[mt] = gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    sT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[mt][ks], qf[ks], sT[mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
                 }
-                // the global fragments are dead (their copies are in the LDS): request the next round's -- the next cell's first -- now
+                // the fragments are dead (the rows are in the LDS): the next round's -- the next cell's first -- are requested now
                 __builtin_amdgcn_sched_barrier(0);
-                if (r + 1 < nround) load_tile(q_cell, g_cell, ty_n, tx_n, qf, gf);
-                else load_tile(q_next, g_next, ty_first, tx_first, qf, gf);
-                ty_cur = (r + 1 < nround) ? ty_n : ty_first;
-                tx_cur = (r + 1 < nround) ? tx_n : tx_first;
+                request(qf, gf);
                 __builtin_amdgcn_sched_barrier(0);
                 BWD2_STAMP(1);   // rows' arrival + LDS copies + S / dP MFMAs
 
@@ -297,8 +304,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 
                 // P and dS for the key waves: row-major [query][slot] -- a lane holds four consecutive slots of ITS query per key tile, one
                 // 8-byte store each; the key waves read them back transposed (ds_read_tr) as the A operands of the contractions over queries.
-                // (Rounds 2-4 evaluated S and dP a second time with the operands swapped to get this layout out of the MFMA: 32 more
-                // MFMAs, 16 more exponentials and a statistics exchange per tile.)
+                // (The four-wave kernel evaluated S and dP a second time with the operands swapped to get that layout out of the MFMA: 32
+                // more MFMAs, 16 more exponentials and a statistics exchange per tile.)
                 {
                     bf16_t* prow = Pq + (wave * 16 + col) * PROW + grp * 4;
                     bf16_t* srow = Sq + (wave * 16 + col) * PROW + grp * 4;
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     }
                 }
                 BWD2_STAMP(2);   // softmax, delta, dS^T, P / dS -> LDS
-                // ---- dQ^T[d][q] = K^T . dS^T ----
+                // ---- dQ^T[d][q] = K^T . dS^T : lane (q, grp) gets 4 consecutive d per 16-d tile; pairs -> 16-byte stores ----
                 if (live) {
                     bf16_t* dqp = dq_cell + (int64_t)ty * p.dqs[2] + (int64_t)(tx0 + col) * p.dqs[3];
 #pragma unroll
@@ -346,13 +353,20 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                             bb[i] = (bf16_t)a1[i];
                         }
                         const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
-                        const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
-                        const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                        *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                        const auto r0_ = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                        const auto r1_ = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                        *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0_[0], r1_[0], r0_[1], r1_[1]};
                     }
                 }
-
                 BWD2_STAMP(3);   // dQ
+                // this wave's tile of the next round of the cell
+                if (r + 1 < nround) {
+                    ty_cur += ty_step; tx_cur += tx_step;
+                    if (tx_cur >= tpr) { tx_cur -= tpr; ++ty_cur; }
+                    if (t + 4 >= ntile) { ty_cur = p.dy - 1; tx_cur = tpr - 1; }
+                } else {
+                    ty_cur = ty_first; tx_cur = tx_first;
+                }
                 BWD2_STAMP(4);
                 __syncthreads();   // this round's buffer is complete; the key waves have left the other one (and, by a cell's last
                                    // round, have brought the other window buffer up to the next cell)
@@ -362,10 +376,23 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[r & 3] += now_ - t2_; t2_ = now_; }
 #endif
             }
-            cur = nxt;
+            // the next cell
+            if (c_pos + 1 < c_len) {
+                ++c_pos;
+                dq_cell += (int64_t)p.dx * p.dqs[3];
+            } else {
+                c_run += nwg;
+                if (c_run < nrun) {
+                    const Run c = decode(c_run);
+                    c_pos = 0; c_len = c.len;
+                    dq_cell = dq_of(c);
+                }
+            }
         }
     } else {
         // =========================== key waves ===========================
+        stage_first();
+        __syncthreads();
         const int wb = wave - 4, ktid = tid - 256;
         f32x4_t accV[MT][NVW], accK[MT];
 #pragma unroll
@@ -374,23 +401,17 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
             for (int i = 0; i < NVW; ++i) accV[mt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        // add the sums of window column x of cell c to dK / dV in memory and clear them.  The column's KS keys are slots lo .. lo + KS - 1;
-        // acc[mt][rr] of lane group grp is slot mt*16 + 4 grp + rr: (mt, rr) pairs none of whose four slots is in the column are skipped
-        // by a scalar branch (at k = 7 four or five of the sixteen pairs take part)
+        // Add the sums of one window column to dK / dV in memory and clear them.  The column's KS keys are slots lo .. lo + KS - 1; acc[mt][rr] of lane group grp is slot mt*16 + 4 grp + rr: (mt, rr) pairs none of whose four slots is in the column are
+        // skipped by a scalar branch (at k = 7 four or five of the sixteen pairs take part).  dkp / dvp: the column's first key, wave-uniform.
         const uint32_t lane_acc = (uint32_t)(wb * 16 + col);
-        auto flush_col = [&](const Cell& c, int x) __attribute__((always_inline)) {
-            const int lo = (x % KS) * KS;
-            const int64_t pix = (int64_t)c.y0 * p.w + x;
-            const uint32_t rowstep = (uint32_t)(p.w * p.heads);     // elements / 64 (dK), / Dv (dV) between window rows
-            float* dkp = p.dk + ((((int64_t)c.b * p.h) * p.w + pix) * p.heads + c.head) * 64;   // wave-uniform; the lane adds wb*16 + col
-            float* dvp = p.dv + ((((int64_t)c.b * p.h) * p.w + pix) * p.heads + c.head) * DV;
+        const uint32_t rowstep = (uint32_t)(p.w * p.heads);     // elements / 64 (dK), / Dv (dV) between window rows
+        auto flush_col = [&](float* dkp, float* dvp, int lo) __attribute__((always_inline)) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int d = mt * 16 + rr - lo;         // slot of lane group 0, relative to the column's first
-                    const bool any = (unsigned)d < (unsigned)KS || (unsigned)(d + 4) < (unsigned)KS || (unsigned)(d + 8) < (unsigned)KS || (unsigned)(d + 12) < (unsigned)KS;
-                    if (any) {
+                    if ((unsigned)d < (unsigned)KS || (unsigned)(d + 4) < (unsigned)KS || (unsigned)(d + 8) < (unsigned)KS || (unsigned)(d + 12) < (unsigned)KS) {
                         const int ry = d + 4 * grp;
 #ifdef NAF_BWD_NO_ATOMICS   // experiments only: how much of the kernel is the atomic traffic
                         if ((unsigned)ry < (unsigned)KS && p.scale > 1e30f) {
@@ -420,22 +441,27 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         const int64_t s_xstr = s_isk ? p.ks[3] : p.vs[3];
         const int s_loff = s_isk ? s_ry * KROW + s_ch * 8 : NSLOT * KROW + s_ry * VROW + (s_ch - 8) * 8;
         const int s_lmul = s_isk ? KS * KROW : KS * VROW;
-        const bf16_t* s_base = nullptr;    // this lane's chunk at column 0 of the run in hand
-        int s_run = -1;
         u32x4_t stage[KS];
-        int have0 = c0.x0, have1 = -4 * KS;    // first window column held by each buffer (of the run in hand; far away: nothing usable)
-        int st_xs = 0, st_n = 0;           // columns [st_xs, st_xs + st_n) are on their way
+        int have0 = x0_of(r0.xs), have1 = -4 * KS;   // first window column held by each buffer (of the run in hand; far away: nothing usable)
+        int st_xs = 0, st_n = 0;                     // columns [st_xs, st_xs + st_n) are on their way
 
-        Cell qc = c0;                  // where the query waves are at step g ...
-        int rq = 0, kq = 0;            // ... round rq of it, cell number kq of the walk
-        Cell kc = c0;                  // the cell the key waves work on at step g >= 1 ...
-        int rk = 0;                    // ... round rk of it
+        // where the query waves are at step g: round q_r of cell q_pos of run q_run (window column q_cx), cell number q_k of the walk
+        int q_run = first, q_pos = 0, q_len = r0.len, q_cx = r0.xs, q_r = 0, q_k = 0;
+        // the run the NEXT cell of the query waves lies in (its chunk base per lane): changes when the query waves enter a run's last cell
+        const bf16_t* s_base = (s_isk ? p.k + r0.b * p.ks[0] + r0.head * p.ks[1] + (int64_t)r0.y0 * p.ks[2]
+                                      : p.v + r0.b * p.vs[0] + r0.head * p.vs[1] + (int64_t)r0.y0 * p.vs[2]) + s_goff;
+        // the cell the key waves work on at step g >= 1: round k_r of cell k_pos of run k_run, window [k_x0, k_x0 + KS); its run's first key
+        int k_run = first, k_pos = 0, k_len = r0.len, k_cx = r0.xs, k_x0 = x0_of(r0.xs), k_r = 0;
+        auto dk_of = [&](const Run& c) __attribute__((always_inline)) { return p.dk + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * 64; };
+        auto dv_of = [&](const Run& c) __attribute__((always_inline)) { return p.dv + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * DV; };
+        float* dk_run = dk_of(r0);     // key (y0, column 0) of the run, this head
+        float* dv_run = dv_of(r0);
 #ifdef NAF_BWD_TIMING
         constexpr int slot_[3] = {6, 7, 5};
 #endif
         for (int g = 0;; ++g) {
             BWD2_STAMP(0);
-            const bool more = qc.run < nrun;      // the query waves run a round in this step
+            const bool more = q_run < nrun;      // the query waves run a round in this step
             if (g >= 1) {
                 const int buf = (g - 1) & 1;
                 const bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
@@ -444,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const bf16_t* Gs = Qs + 4 * 16 * KROW;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    // B operands: queries 4*grp..+3 of tiles 2pr / 2pr+1 for column (16-wide tile nt, col)
+                    // operands of a contraction over the 32 queries of tiles 2pr / 2pr+1: queries 4*grp..+3 of each, 16-wide column tile nt
                     auto tr_pair = [&](const bf16_t* base, int rowlen, int nt) __attribute__((always_inline)) {
                         const bf16_t* a = base + ((2 * pr) * 16 + grp * 4 + (col >> 2)) * rowlen + (col & 3) * 4 + nt * 16;
                         const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a);
@@ -469,13 +495,23 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     }
                 }
                 BWD2_STAMP(1);
-                if (++rk == nround) {
-                    // the cell is complete: the columns its successor's window no longer holds (all of them at the end of a run) leave
-                    const Cell nk = after(kc);
-                    const int keep = same_run(nk, kc) ? nk.x0 : kc.x0 + KS;
-                    for (int x = kc.x0; x < keep; ++x) flush_col(kc, x);
-                    kc = nk;
-                    rk = 0;
+                if (++k_r == nround) {
+                    // the cell is complete: the column its successor's window no longer holds (all of them at the end of a run) leaves
+                    k_r = 0;
+                    if (k_pos + 1 < k_len) {
+                        ++k_pos; ++k_cx;
+                        const int nx0 = x0_of(k_cx);
+                        if (nx0 > k_x0) flush_col(dk_run + (int64_t)k_x0 * p.heads * 64, dv_run + (int64_t)k_x0 * p.heads * DV, (k_x0 % KS) * KS);
+                        k_x0 = nx0;
+                    } else {
+                        for (int x = k_x0; x < k_x0 + KS; ++x) flush_col(dk_run + (int64_t)x * p.heads * 64, dv_run + (int64_t)x * p.heads * DV, (x % KS) * KS);
+                        k_run += nwg;
+                        if (k_run < nrun) {
+                            const Run c = decode(k_run);
+                            k_pos = 0; k_len = c.len; k_cx = c.xs; k_x0 = x0_of(c.xs);
+                            dk_run = dk_of(c); dv_run = dv_of(c);
+                        }
+                    }
                 }
             } else {
                 BWD2_STAMP(1);
@@ -483,41 +519,49 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             BWD2_STAMP(2);
             if (!more) break;
 #ifdef NAF_BWD_TIMING2
-            const int rq_ = rq;
+            const int rq_ = q_r;
 #endif
             {
-                const Cell nq = after(qc);
-                const bool stage_next = nq.run < nrun;
-                const int nb = (kq + 1) & 1;
-                if (stage_next && rq == min(1, nround - 1)) {
-                    // columns of nq's window that buffer nb does not hold
-                    const int old = same_run(nq, qc) ? (nb ? have1 : have0) : -4 * KS;
-                    st_n = min(KS, nq.x0 - old);
-                    st_xs = nq.x0 + KS - st_n;
-                    if (nq.run != s_run) {
-                        s_run = nq.run;
-                        const bf16_t* kb = p.k + nq.b * p.ks[0] + nq.head * p.ks[1] + (int64_t)nq.y0 * p.ks[2];
-                        const bf16_t* vb = p.v + nq.b * p.vs[0] + nq.head * p.vs[1] + (int64_t)nq.y0 * p.vs[2];
-                        s_base = (s_isk ? kb : vb) + s_goff;
+                // the query waves' next cell: the next column of the run, or the first cell of this workgroup's next run
+                const bool last_of_run = q_pos + 1 == q_len;
+                const bool stage_next = !last_of_run || q_run + nwg < nrun;
+                const int nb = (q_k + 1) & 1;
+                if (stage_next && q_r == min(1, nround - 1)) {
+                    int nx0;
+                    if (last_of_run) {
+                        const Run c = decode(q_run + nwg);
+                        nx0 = x0_of(c.xs);
+                        s_base = (s_isk ? p.k + c.b * p.ks[0] + c.head * p.ks[1] + (int64_t)c.y0 * p.ks[2]
+                                        : p.v + c.b * p.vs[0] + c.head * p.vs[1] + (int64_t)c.y0 * p.vs[2]) + s_goff;
+                        have0 = have1 = -4 * KS;        // nothing of another run's windows can be kept
+                    } else {
+                        nx0 = x0_of(q_cx + 1);
                     }
+                    // columns of the next window that buffer nb does not hold
+                    st_n = min(KS, nx0 - (nb ? have1 : have0));
+                    st_xs = nx0 + KS - st_n;
+                    if (nb) have1 = nx0; else have0 = nx0;
 #pragma unroll
                     for (int j = 0; j < KS; ++j)
                         if (j < st_n && s_on) stage[j] = *reinterpret_cast<const u32x4_t*>(s_base + (int64_t)(st_xs + j) * s_xstr);
                 }
-                if (stage_next && rq == min(2, nround - 1)) {
+                if (stage_next && q_r == min(2, nround - 1)) {
                     bf16_t* dst = KV + nb * G2::kv_elems + s_loff;
 #pragma unroll
                     for (int j = 0; j < KS; ++j)
                         if (j < st_n && s_on) *reinterpret_cast<u32x4_t*>(dst + ((st_xs + j) % KS) * s_lmul) = stage[j];
-                    // (the other buffer holds a window of the previous run when nq opens a new one: nothing of it can be kept)
-                    const int other = same_run(nq, qc) ? (nb ? have0 : have1) : -4 * KS;
-                    have0 = nb ? other : nq.x0;
-                    have1 = nb ? nq.x0 : other;
                 }
-                if (++rq == nround) {
-                    rq = 0;
-                    ++kq;
-                    qc = nq;
+                if (++q_r == nround) {
+                    q_r = 0;
+                    ++q_k;
+                    if (!last_of_run) { ++q_pos; ++q_cx; }
+                    else {
+                        q_run += nwg;
+                        if (q_run < nrun) {
+                            const Run c = decode(q_run);
+                            q_pos = 0; q_len = c.len; q_cx = c.xs;
+                        }
+                    }
                 }
             }
 #ifdef NAF_BWD_TIMING2
@@ -545,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 // Windows whose fragments a query wave can hold beside its working set (hipcc 7.2: no scratch up to ~160 fragment registers)
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 7 && XnaBwd2Geom<KS, DV>::frag_regs <= 128 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024 && KS * (8 + DV / 8) <= 256;
+    return KS <= 9 && XnaBwd2Geom<KS, DV>::frag_regs <= 128 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024 && KS * (8 + DV / 8) <= 256;
 }
 
 template <int KS, int DV>
