@@ -36,9 +36,14 @@ struct XnaBwd2Geom {
     static constexpr int PROW = G::KPAD + 8;                                    // bf16 per row of the P / dS matrices [query][slot]
     static constexpr size_t ps_elems = (size_t)4 * 16 * PROW;                   // bf16 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
-    static constexpr size_t lds_bytes() { return 2 * kv_elems * 2 + 2 * (2 * ps_elems * 2) + 2 * (qg_elems * 2); }
-    // K and V fragments of the whole window in registers: MT * (2 + Dv / 32) * 4 per lane
-    static constexpr int frag_regs = G::MT * (2 + DV / 32) * 4;
+    static constexpr size_t round_bytes = 2 * (2 * ps_elems * 2) + 2 * (qg_elems * 2);
+    // Two window buffers (the key waves bring the other one up to the next cell while this one is in use) where the LDS has room;
+    // one otherwise: the entering column is then written between two barriers at the cell change (the widest shapes: Dv = 256 at k = 7)
+    static constexpr int kv_bufs = (2 * kv_elems * 2 + round_bytes <= 160 * 1024) ? 2 : 1;
+    static constexpr size_t lds_bytes() { return kv_bufs * kv_elems * 2 + round_bytes; }
+    // K and V fragments of the whole window in registers: MT * (2 + Dv / 32) * 4 per lane; beyond 128 the K fragments come from the LDS per round
+    static constexpr int frag_regs = G::MT * (2 + DV / 32) * 4, v_frag_regs = G::MT * (DV / 32) * 4;
+    static constexpr bool k_resident = frag_regs <= 128;
 };
 
 template <int KS, int DV>
@@ -47,11 +52,12 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     using G2 = XnaBwd2Geom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32, PROW = G2::PROW;
+    constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident;
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* KV = reinterpret_cast<bf16_t*>(smem);                                // [2 window buffers][K: NSLOT x KROW | V: NSLOT x VROW]
-    bf16_t* PS = KV + 2 * G2::kv_elems;                                          // [2 round buffers][P | dS][4 tiles x 16 queries][PROW]
+    bf16_t* PS = KV + G2::kv_bufs * G2::kv_elems;                                          // [2 round buffers][P | dS][4 tiles x 16 queries][PROW]
     bf16_t* QG = PS + 2 * 2 * G2::ps_elems;                                      // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         __syncthreads();
 
         auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
-        bf16x8_t kfr[MT][2], vfr[MT][DKS];   // the windows as operand fragments, resident for the whole cell
+        // the windows as operand fragments, resident for the whole cell (at the widest shapes only V: the K fragments, a fifth of the
+        // S / dP MFMAs there, are then read at the top of every round)
+        bf16x8_t kfr[MT][2], vfr[MT][DKS];
         int c_run = first, c_pos = 0, c_len = r0.len;
         bf16_t* dq_cell = dq_of(r0);
         int g = 0;   // rounds since the kernel started: round buffer g & 1, row set g & 1
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #ifdef NAF_BWD_TIMING2
             const unsigned long long tcs_ = __builtin_amdgcn_s_memtime();
 #endif
-            const bf16_t* Ks = KV + (kc & 1) * G2::kv_elems;
+            const bf16_t* Ks = KV + (KV2 ? (kc & 1) : 0) * G2::kv_elems;
             const bf16_t* Vs = Ks + NSLOT * KROW;
             auto kt_of = [&](int blk) __attribute__((always_inline)) {
                 const int r = min(blk * 16 + grp * 4 + (col >> 2), NSLOT - 1);
@@ -211,8 +219,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
                 const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+                if constexpr (KRES) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                    for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                }
 #pragma unroll
                 for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
             }
@@ -234,6 +244,14 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const bool live = t < ntile;                       // dead tiles compute on the cell's last tile and contribute zeros
                 const int ty = ty_cur, tx0 = tx_cur * 16;
 
+                if constexpr (!KRES) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                    }
+                }
                 // row-major LDS copies of the rows: the key waves' B operands
                 bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
                 bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
@@ -388,6 +406,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     dq_cell = dq_of(c);
                 }
             }
+            if constexpr (!KV2) {
+                if (c_run < nrun) __syncthreads();   // the key waves have written the entering column(s) into the one window buffer
+            }
         }
     } else {
         // =========================== key waves ===========================
@@ -434,22 +455,39 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         // waves' second round of a cell, written in their third (fewer rounds per cell: in the last; the first is the step of the flush).
         // Lane ktid < CCH owns 16-byte chunk ktid of EVERY column (row s_ry, chunk s_ch of the row's K or V part), so everything
         // per lane is computed once and a column costs one 64-bit multiply-add and one load.
-        static_assert(CCH <= 256, "a window column must fit one pass of the key waves");
-        const int s_ry = ktid / RCH, s_ch = ktid - s_ry * RCH;
-        const bool s_on = ktid < CCH, s_isk = s_ch < 8;
-        const int64_t s_goff = s_isk ? (int64_t)s_ry * p.ks[2] + s_ch * 8 : (int64_t)s_ry * p.vs[2] + (s_ch - 8) * 8;
-        const int64_t s_xstr = s_isk ? p.ks[3] : p.vs[3];
-        const int s_loff = s_isk ? s_ry * KROW + s_ch * 8 : NSLOT * KROW + s_ry * VROW + (s_ch - 8) * 8;
-        const int s_lmul = s_isk ? KS * KROW : KS * VROW;
-        u32x4_t stage[KS];
+        // (columns of more than 256 chunks -- Dv = 256 at k = 7, 9 -- take two passes: chunk ktid and chunk 256 + ktid)
+        static_assert(CCH <= 512, "a window column must fit two passes of the key waves");
+        constexpr int NP = (CCH + 255) / 256;
+        bool s_on[NP];
+        int64_t s_xstr[NP];
+        int s_loff[NP], s_lmul[NP];
+        const bf16_t* s_base[NP];      // this lane's chunk(s) at column 0 of the run the query waves' NEXT cell lies in
+        auto s_base_of = [&](const Run& c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int ch_all = min(u * 256 + ktid, CCH - 1);
+                const int ry = ch_all / RCH, ch = ch_all - ry * RCH;
+                s_base[u] = ch < 8 ? p.k + c.b * p.ks[0] + c.head * p.ks[1] + (int64_t)(c.y0 + ry) * p.ks[2] + ch * 8
+                                   : p.v + c.b * p.vs[0] + c.head * p.vs[1] + (int64_t)(c.y0 + ry) * p.vs[2] + (ch - 8) * 8;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int ch_all = min(u * 256 + ktid, CCH - 1);
+            const int ry = ch_all / RCH, ch = ch_all - ry * RCH;
+            const bool isk = ch < 8;
+            s_on[u] = u * 256 + ktid < CCH;
+            s_xstr[u] = isk ? p.ks[3] : p.vs[3];
+            s_loff[u] = isk ? ry * KROW + ch * 8 : NSLOT * KROW + ry * VROW + (ch - 8) * 8;
+            s_lmul[u] = isk ? KS * KROW : KS * VROW;
+        }
+        s_base_of(r0);
+        u32x4_t stage[NP][KS];
         int have0 = x0_of(r0.xs), have1 = -4 * KS;   // first window column held by each buffer (of the run in hand; far away: nothing usable)
         int st_xs = 0, st_n = 0;                     // columns [st_xs, st_xs + st_n) are on their way
 
         // where the query waves are at step g: round q_r of cell q_pos of run q_run (window column q_cx), cell number q_k of the walk
         int q_run = first, q_pos = 0, q_len = r0.len, q_cx = r0.xs, q_r = 0, q_k = 0;
-        // the run the NEXT cell of the query waves lies in (its chunk base per lane): changes when the query waves enter a run's last cell
-        const bf16_t* s_base = (s_isk ? p.k + r0.b * p.ks[0] + r0.head * p.ks[1] + (int64_t)r0.y0 * p.ks[2]
-                                      : p.v + r0.b * p.vs[0] + r0.head * p.vs[1] + (int64_t)r0.y0 * p.vs[2]) + s_goff;
         // the cell the key waves work on at step g >= 1: round k_r of cell k_pos of run k_run, window [k_x0, k_x0 + KS); its run's first key
         int k_run = first, k_pos = 0, k_len = r0.len, k_cx = r0.xs, k_x0 = x0_of(r0.xs), k_r = 0;
         auto dk_of = [&](const Run& c) __attribute__((always_inline)) { return p.dk + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * 64; };
@@ -521,18 +559,18 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #ifdef NAF_BWD_TIMING2
             const int rq_ = q_r;
 #endif
+            bool wrapped = false, stage_next = false;
             {
                 // the query waves' next cell: the next column of the run, or the first cell of this workgroup's next run
                 const bool last_of_run = q_pos + 1 == q_len;
-                const bool stage_next = !last_of_run || q_run + nwg < nrun;
-                const int nb = (q_k + 1) & 1;
+                stage_next = !last_of_run || q_run + nwg < nrun;
+                const int nb = KV2 ? (q_k + 1) & 1 : 0;
                 if (stage_next && q_r == min(1, nround - 1)) {
                     int nx0;
                     if (last_of_run) {
                         const Run c = decode(q_run + nwg);
                         nx0 = x0_of(c.xs);
-                        s_base = (s_isk ? p.k + c.b * p.ks[0] + c.head * p.ks[1] + (int64_t)c.y0 * p.ks[2]
-                                        : p.v + c.b * p.vs[0] + c.head * p.vs[1] + (int64_t)c.y0 * p.vs[2]) + s_goff;
+                        s_base_of(c);
                         have0 = have1 = -4 * KS;        // nothing of another run's windows can be kept
                     } else {
                         nx0 = x0_of(q_cx + 1);
@@ -542,15 +580,20 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     st_xs = nx0 + KS - st_n;
                     if (nb) have1 = nx0; else have0 = nx0;
 #pragma unroll
-                    for (int j = 0; j < KS; ++j)
-                        if (j < st_n && s_on) stage[j] = *reinterpret_cast<const u32x4_t*>(s_base + (int64_t)(st_xs + j) * s_xstr);
-                }
-                if (stage_next && q_r == min(2, nround - 1)) {
-                    bf16_t* dst = KV + nb * G2::kv_elems + s_loff;
+                    for (int u = 0; u < NP; ++u)
 #pragma unroll
-                    for (int j = 0; j < KS; ++j)
-                        if (j < st_n && s_on) *reinterpret_cast<u32x4_t*>(dst + ((st_xs + j) % KS) * s_lmul) = stage[j];
+                        for (int j = 0; j < KS; ++j)
+                            if (j < st_n && s_on[u]) stage[u][j] = *reinterpret_cast<const u32x4_t*>(s_base[u] + (int64_t)(st_xs + j) * s_xstr[u]);
                 }
+                if (KV2 && stage_next && q_r == min(2, nround - 1)) {
+                    bf16_t* dst = KV + nb * G2::kv_elems;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+#pragma unroll
+                        for (int j = 0; j < KS; ++j)
+                            if (j < st_n && s_on[u]) *reinterpret_cast<u32x4_t*>(dst + s_loff[u] + ((st_xs + j) % KS) * s_lmul[u]) = stage[u][j];
+                }
+                wrapped = q_r + 1 == nround;
                 if (++q_r == nround) {
                     q_r = 0;
                     ++q_k;
@@ -569,6 +612,17 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             const unsigned long long tw_ = __builtin_amdgcn_s_memtime();
 #endif
             __syncthreads();
+            if constexpr (!KV2) {
+                if (wrapped && stage_next) {
+                    // one window buffer: the query waves are between their cell's last round and the next cell's fragments
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+#pragma unroll
+                        for (int j = 0; j < KS; ++j)
+                            if (j < st_n && s_on[u]) *reinterpret_cast<u32x4_t*>(KV + s_loff[u] + ((st_xs + j) % KS) * s_lmul[u]) = stage[u][j];
+                    __syncthreads();
+                }
+            }
 #ifdef NAF_BWD_TIMING2
             { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc2[rq_ & 3] += tw_ - t2_; tacc2[4 + (rq_ & 3)] += now_ - tw_; t2_ = now_; }
 #endif
@@ -586,10 +640,11 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #endif
 }
 
-// Windows whose fragments a query wave can hold beside its working set (hipcc 7.2: no scratch up to ~160 fragment registers)
+// Windows whose V fragments a query wave can hold beside its working set (hipcc 7.2: k = 7 with Dv = 256 -- 128 registers of V fragments --
+// spills 50 registers) and whose buffers fit the LDS; everything else stays with the four-wave kernel
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 9 && XnaBwd2Geom<KS, DV>::frag_regs <= 128 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024 && KS * (8 + DV / 8) <= 256;
+    return KS <= 9 && XnaBwd2Geom<KS, DV>::v_frag_regs <= 96 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
 }
 
 template <int KS, int DV>

@@ -726,6 +726,8 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (2, 128, (5, 6), (40, 96), 3),         # Dv = 32, d = (8, 16): 8 tiles per cell, non-square grid
     (1, 768, (7, 7), (7, 112), 7),         # Dv = 192, dy = 1: one tile per cell (three dead waves per round), k = h = w
     (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
+    (1, 512, (10, 11), (160, 176), 9),     # Dv = 128, 9x9: eight-wave kernel with ONE window buffer and K fragments from the LDS
+    (2, 768, (9, 12), (144, 192), 7),      # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
     (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): one workgroup per CU
     (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow)
 ])
