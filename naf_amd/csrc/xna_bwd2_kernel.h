@@ -451,6 +451,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     }
                 }
         };
+        // (Built, measured, removed: moving the leaving column's sums to a second register set and adding them to memory over the next two
+        // steps.  hipcc joins the accumulators' paths with dozens of v_mov behind s_waitcnt vmcnt(0) -- behind the atomics in flight -- or,
+        // with the moves written branch-free, spills 62 registers: profiles/r05_bwd2_phases.txt.)
         // The columns the next cell's window needs and its buffer does not hold travel through registers: requested in the query
         // waves' second round of a cell, written in their third (fewer rounds per cell: in the last; the first is the step of the flush).
         // Lane ktid < CCH owns 16-byte chunk ktid of EVERY column (row s_ry, chunk s_ch of the row's K or V part), so everything
@@ -482,9 +485,23 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             s_lmul[u] = isk ? KS * KROW : KS * VROW;
         }
         s_base_of(r0);
-        u32x4_t stage[NP][KS];
+        u32x4_t stage[NP];             // the one column of the common case (a run's first two cells fetch whole windows: synchronously, below)
         int have0 = x0_of(r0.xs), have1 = -4 * KS;   // first window column held by each buffer (of the run in hand; far away: nothing usable)
         int st_xs = 0, st_n = 0;                     // columns [st_xs, st_xs + st_n) are on their way
+        int ld_x = x0_of(r0.xs);                     // the column every step loads (see the loop)
+        // columns [st_xs, st_xs + st_n) -> window buffer dst: the first from the registers, further ones (a run's first two cells) fetched here and now
+        auto write_cols = [&](bf16_t* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u)
+                if (st_n > 0 && s_on[u]) *reinterpret_cast<u32x4_t*>(dst + s_loff[u] + (st_xs % KS) * s_lmul[u]) = stage[u];
+            for (int j = 1; j < st_n; ++j) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const u32x4_t val = *reinterpret_cast<const u32x4_t*>(s_base[u] + (int64_t)(st_xs + j) * s_xstr[u]);
+                    if (s_on[u]) *reinterpret_cast<u32x4_t*>(dst + s_loff[u] + ((st_xs + j) % KS) * s_lmul[u]) = val;
+                }
+            }
+        };
 
         // where the query waves are at step g: round q_r of cell q_pos of run q_run (window column q_cx), cell number q_k of the walk
         int q_run = first, q_pos = 0, q_len = r0.len, q_cx = r0.xs, q_r = 0, q_k = 0;
@@ -500,6 +517,37 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         for (int g = 0;; ++g) {
             BWD2_STAMP(0);
             const bool more = q_run < nrun;      // the query waves run a round in this step
+            // The query waves' next cell: the next column of the run, or the first cell of this workgroup's next run.  Its window's new
+            // columns are requested at the TOP of one step of the cell and written at the bottom of the SAME step, the dK / dV MFMAs in
+            // between (two window buffers: the step of the query waves' second round -- the first is the step of the flush; one buffer:
+            // the cell's last step, written behind its barrier).  Request and write in different steps cost a vmcnt(0) in front of
+            // every load (hipcc cannot count a load across the loop's back edge), and vmcnt(0) waits for the flush's atomics too:
+            // +1.9 k cycles in that step, profiles/r05_bwd2_phases.txt.
+            const bool last_of_run = q_pos + 1 == q_len;
+            const bool stage_next = more && (!last_of_run || q_run + nwg < nrun);
+            const int nb = KV2 ? (q_k + 1) & 1 : 0;
+            const bool stage_now = stage_next && q_r == (KV2 ? min(1, nround - 1) : nround - 1);
+            if (stage_now) {
+                int nx0;
+                if (last_of_run) {
+                    const Run c = decode(q_run + nwg);
+                    nx0 = x0_of(c.xs);
+                    s_base_of(c);
+                    have0 = have1 = -4 * KS;        // nothing of another run's windows can be kept
+                } else {
+                    nx0 = x0_of(q_cx + 1);
+                }
+                // columns of the next window that buffer nb does not hold
+                st_n = min(KS, nx0 - (nb ? have1 : have0));
+                st_xs = nx0 + KS - st_n;
+                if (nb) have1 = nx0; else have0 = nx0;
+                if (st_n > 0) ld_x = st_xs;     // (st_n == 0: the window does not move -- st_xs is one past it, possibly past the tensor)
+            }
+            // The one column of the common case is loaded in EVERY step, needed or not (column ld_x: the last one staged): a load under a
+            // condition draws an s_waitcnt vmcnt(0) in front of it (hipcc cannot count a conditional load's register across the loop's back
+            // edge), and vmcnt(0) also waits for the atomics of the flush, a step earlier.  (Lanes past the column's chunks re-read its last.)
+#pragma unroll
+            for (int u = 0; u < NP; ++u) stage[u] = *reinterpret_cast<const u32x4_t*>(s_base[u] + (int64_t)ld_x * s_xstr[u]);
             if (g >= 1) {
                 const int buf = (g - 1) & 1;
                 const bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
@@ -532,7 +580,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                             if (NVT % 4 == 0 || wb + 4 * i < NVT) accV[mt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, bg[i], accV[mt][i], 0, 0, 0);
                     }
                 }
-                BWD2_STAMP(1);
+            }
+            BWD2_STAMP(1);
+            if (g >= 1) {
                 if (++k_r == nround) {
                     // the cell is complete: the column its successor's window no longer holds (all of them at the end of a run) leaves
                     k_r = 0;
@@ -551,49 +601,17 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                         }
                     }
                 }
-            } else {
-                BWD2_STAMP(1);
             }
             BWD2_STAMP(2);
             if (!more) break;
 #ifdef NAF_BWD_TIMING2
             const int rq_ = q_r;
 #endif
-            bool wrapped = false, stage_next = false;
+            const bool wrapped = q_r + 1 == nround;
             {
-                // the query waves' next cell: the next column of the run, or the first cell of this workgroup's next run
-                const bool last_of_run = q_pos + 1 == q_len;
-                stage_next = !last_of_run || q_run + nwg < nrun;
-                const int nb = KV2 ? (q_k + 1) & 1 : 0;
-                if (stage_next && q_r == min(1, nround - 1)) {
-                    int nx0;
-                    if (last_of_run) {
-                        const Run c = decode(q_run + nwg);
-                        nx0 = x0_of(c.xs);
-                        s_base_of(c);
-                        have0 = have1 = -4 * KS;        // nothing of another run's windows can be kept
-                    } else {
-                        nx0 = x0_of(q_cx + 1);
-                    }
-                    // columns of the next window that buffer nb does not hold
-                    st_n = min(KS, nx0 - (nb ? have1 : have0));
-                    st_xs = nx0 + KS - st_n;
-                    if (nb) have1 = nx0; else have0 = nx0;
-#pragma unroll
-                    for (int u = 0; u < NP; ++u)
-#pragma unroll
-                        for (int j = 0; j < KS; ++j)
-                            if (j < st_n && s_on[u]) stage[u][j] = *reinterpret_cast<const u32x4_t*>(s_base[u] + (int64_t)(st_xs + j) * s_xstr[u]);
-                }
-                if (KV2 && stage_next && q_r == min(2, nround - 1)) {
-                    bf16_t* dst = KV + nb * G2::kv_elems;
-#pragma unroll
-                    for (int u = 0; u < NP; ++u)
-#pragma unroll
-                        for (int j = 0; j < KS; ++j)
-                            if (j < st_n && s_on[u]) *reinterpret_cast<u32x4_t*>(dst + s_loff[u] + ((st_xs + j) % KS) * s_lmul[u]) = stage[u][j];
-                }
-                wrapped = q_r + 1 == nround;
+                // (at the bottom of the step: same-lease A/B against writing right behind the MFMAs, 0.726 / 0.670 against 0.773 / 0.718 ms
+                // at G1 / k = 9: profiles/r05_bwd2_phases.txt)
+                if (KV2 && stage_now) write_cols(KV + nb * G2::kv_elems);
                 if (++q_r == nround) {
                     q_r = 0;
                     ++q_k;
@@ -615,11 +633,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             if constexpr (!KV2) {
                 if (wrapped && stage_next) {
                     // one window buffer: the query waves are between their cell's last round and the next cell's fragments
-#pragma unroll
-                    for (int u = 0; u < NP; ++u)
-#pragma unroll
-                        for (int j = 0; j < KS; ++j)
-                            if (j < st_n && s_on[u]) *reinterpret_cast<u32x4_t*>(KV + s_loff[u] + ((st_xs + j) % KS) * s_lmul[u]) = stage[u][j];
+                    write_cols(KV);
                     __syncthreads();
                 }
             }

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, GPU call 27: wave-specialised backward, final form -- probes, backward parity, interleaved A/B against the four-wave kernel
+export TMPDIR=/tmp
+O=gpurun_out/r05_run27; mkdir -p $O
+(tools/bin/bwd2_plain; tools/bin/bwd2_t2; tools/bin/xna_bwd2_probe; tools/bin/bwd2_plain_k9; tools/bin/bwd2_t2_k9; tools/bin/bwd2_plain_k9_128; tools/bin/bwd2_plain 512 32 2; tools/bin/xna_bwd_probe) 2>&1 | tee $O/probe.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "backward or bwd or autograd or train" 2>&1 | tail -5 | tee $O/pytest.txt
+for r in 1 2 3; do
+  echo "== eight waves (product)"; BWD_BENCH_N=30 timeout 300 python tools/xna_bwd_bench.py
+  echo "== four waves (NAF_BWD_V1=1)"; NAF_HIP_KNOBS=1 NAF_BWD_V1=1 BWD_BENCH_N=30 timeout 300 python tools/xna_bwd_bench.py
+done 2>&1 | grep -v amdgpu.ids | tee $O/ab.txt
