@@ -1,7 +1,7 @@
 // Cross-scale neighbourhood attention BACKWARD, wave-specialised cell kernel (gfx950 / CDNA4), round 5.
 //
-// Same mathematics and the same operand tricks as xna_bwd_kernel.h (which this kernel replaces for the windows whose K / V
-// fragments fit the register file: k <= 7); what changes is WHO does what and WHEN ("change the round
+// Same mathematics and the same operand tricks as xna_bwd_kernel.h (which this kernel replaces for windows up to 9 x 9 whose
+// buffers fit the LDS); what changes is WHO does what and WHEN ("change the round
 // structure").  The four-wave kernel ran every wave through [S / dP MFMAs behind 32 LDS fragment reads, softmax, dQ, P / dS -> LDS |
 // barrier | dK / dV MFMAs | barrier]: all eight waves of a CU in the same phase at the same time, 1.7 k cycles of MFMAs in a
 // 10 k-cycle round (profiles/r02_xna_bwd_phase.txt).  Here one workgroup = EIGHT waves = one (batch, cell, head), and the waves have roles:
@@ -44,6 +44,9 @@ struct XnaBwd2Geom {
     // K and V fragments of the whole window in registers: MT * (2 + Dv / 32) * 4 per lane; beyond 128 the K fragments come from the LDS per round
     static constexpr int frag_regs = G::MT * (2 + DV / 32) * 4, v_frag_regs = G::MT * (DV / 32) * 4;
     static constexpr bool k_resident = frag_regs <= 128;
+    // V fragments of the first v_res_mt key tiles stay in registers (at most 96 registers of them); the other key tiles' come from
+    // the LDS in every round, one tile's worth (Dv / 8 registers) at a time in front of its dP MFMAs (Dv = 256 at k = 7: three of four resident)
+    static constexpr int v_res_mt = (96 / ((DV / 32) * 4)) < G::MT ? (96 / ((DV / 32) * 4)) : G::MT;
 };
 
 template <int KS, int DV>
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32, PROW = G2::PROW;
     constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident;
+    constexpr int VRES = G2::v_res_mt;
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
         // the windows as operand fragments, resident for the whole cell (at the widest shapes only V: the K fragments, a fifth of the
         // S / dP MFMAs there, are then read at the top of every round)
-        bf16x8_t kfr[MT][2], vfr[MT][DKS];
+        bf16x8_t kfr[MT][2], vfr[VRES][DKS];
         int c_run = first, c_pos = 0, c_len = r0.len;
         bf16_t* dq_cell = dq_of(r0);
         int g = 0;   // rounds since the kernel started: round buffer g & 1, row set g & 1
@@ -223,8 +227,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
                 }
+                if (mt < VRES) {
 #pragma unroll
-                for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+                    for (int ks = 0; ks < DKS; ++ks) vfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+                }
             }
 #ifdef NAF_BWD_TIMING
             tacc[0] += __builtin_amdgcn_s_memtime() - (kc == 0 ? t_begin : st_[6]);   // windows -> LDS (first cell) -> registers
@@ -272,8 +278,18 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (mt < VRES) {
 #pragma unroll
-                    for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
+                        for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
+                    } else {
+                        // a key tile whose V fragments are not resident: all of its reads, then its MFMAs
+                        const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+                        bf16x8_t vt[DKS];
+#pragma unroll
+                        for (int ks = 0; ks < DKS; ++ks) vt[ks] = *reinterpret_cast<const bf16x8_t*>(vr + ks * 32);
+#pragma unroll
+                        for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[ks], gf[ks], gT[mt], 0, 0, 0);
+                    }
                 }
                 // the fragments are dead (the rows are in the LDS): the next round's -- the next cell's first -- are requested now
                 __builtin_amdgcn_sched_barrier(0);
@@ -654,11 +670,12 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #endif
 }
 
-// Windows whose V fragments a query wave can hold beside its working set (hipcc 7.2: k = 7 with Dv = 256 -- 128 registers of V fragments --
-// spills 50 registers) and whose buffers fit the LDS; everything else stays with the four-wave kernel
+// Windows up to 9 x 9 whose buffers fit the LDS (9 x 9 stops at Dv = 128: 167 KB at Dv = 192); everything else stays with the four-wave
+// kernel.  Where the whole window's V fragments do not fit beside a query wave's working set (7 x 7 at Dv = 256: 128 registers of them, hipcc 7.2
+// spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 9 && XnaBwd2Geom<KS, DV>::v_frag_regs <= 96 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
+    return KS <= 9 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
 }
 
 template <int KS, int DV>

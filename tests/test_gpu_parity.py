@@ -728,6 +728,7 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
     (1, 512, (10, 11), (160, 176), 9),     # Dv = 128, 9x9: eight-wave kernel with ONE window buffer and K fragments from the LDS
     (2, 768, (9, 12), (144, 192), 7),      # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
+    (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
     (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): one workgroup per CU
     (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow)
 ])
