@@ -46,7 +46,10 @@ struct XnaBwd2Geom {
     static constexpr bool k_resident = frag_regs <= 128;
     // V fragments of the first v_res_mt key tiles stay in registers (at most 96 registers of them); the other key tiles' come from
     // the LDS in every round, one tile's worth (Dv / 8 registers) at a time in front of its dP MFMAs (Dv = 256 at k = 7: three of four resident)
-    static constexpr int v_res_mt = (96 / ((DV / 32) * 4)) < G::MT ? (96 / ((DV / 32) * 4)) : G::MT;
+#ifndef NAF_BWD2_VREGS   // A/B builds only (tools/build_variant.py): the register budget of the resident V fragments
+#define NAF_BWD2_VREGS 96
+#endif
+    static constexpr int v_res_mt = (NAF_BWD2_VREGS / ((DV / 32) * 4)) < G::MT ? (NAF_BWD2_VREGS / ((DV / 32) * 4)) : G::MT;
 };
 
 template <int KS, int DV>

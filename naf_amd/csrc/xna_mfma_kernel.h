@@ -279,6 +279,54 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     // ALL loads of a batch are issued (clamped chunk index, no branch) before the first LDS write: a load behind a
     // per-chunk `if` is followed by its own s_waitcnt vmcnt(0) -- seven dependent L2 round trips (9 us of a 21 us
     // workgroup at k = 7, profiles/r02_xna_phase_timing.txt) instead of one.
+#ifdef NAF_XNA_GLDS
+    // A/B build only (tools/build_variant.py -DNAF_XNA_GLDS=1; VERDICT r04 item 1 asked for LDS-DMA).  Measured 0.5-3 % SLOWER than the register
+    // path below at G1 / G3 / G4 (profiles/r05_negative_results.txt section 5) -- a measurement switch, not the product.  The windows and the cell's RoPE
+    // tables go global -> LDS without passing through registers (global_load_lds_dwordx4: 1 KB per wave instruction, destination =
+    // wave-uniform base + 16 lane, so a lane's SOURCE is whatever its 16 bytes of the padded row layout hold; pad chunks are masked off).
+    // The first queries are requested behind the DMAs and stay in flight across the barrier (loads return in order: vmcnt(2 TPW)).
+    {
+        const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
+        const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
+        constexpr int KCH = KROW / 8, VCHP = VROW / 8;            // 16-byte chunks per padded row
+        constexpr int KT = NSLOT * KCH, TOT = KT + NSLOT * VCHP;  // Ks and Vs are contiguous
+        constexpr int NIT = (TOT + NT - 1) / NT;
+        static_assert(KROW % 8 == 0 && VROW % 8 == 0, "padded rows are whole 16-byte chunks");
+        const bool rope_lds = STG && CB == 1 && p.rope_lds && p.tab_y != nullptr && p.dy <= XNA_ROPE_ROWS && p.dx <= 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c0 = it * NT + wave * 64;     // wave-uniform
+            const int c = c0 + lane;
+            // branch-free: a wave's 64 chunks may straddle the K | V border
+            const bool isk = c < KT;
+            const int c2 = isk ? c : c - KT;
+            const int kraw = isk ? c2 / KCH : c2 / VCHP;
+            const int cc = c2 - kraw * (isk ? KCH : VCHP);
+            const int key = min(kraw, NSLOT - 1);
+            const int ry = key / WS, rx = key - ry * WS;
+            const int yy = min(y0 + ry, p.h - 1), xx = min(x0 + rx, p.w - 1);
+            const bool on = cc < (isk ? 8 : VCH) && c < TOT;
+            const bf16_t* src = (isk ? kb : vb) + (int64_t)yy * (isk ? p.ks[2] : p.vs[2]) + (int64_t)xx * (isk ? p.ks[3] : p.vs[3]) + cc * 8;
+            if (c0 < TOT && on)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (NAF_LDS void*)(Ks + c0 * 8), 16, 0, 0);
+        }
+        if (rope_lds) {
+            // row tables: thread t < 8 dy owns 16 bytes at Ty + 4 t floats (waves 0, 1); column tables (eight-wave workgroups): waves 2, 3
+            if (wave < 2 && tid < p.dy * 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.tab_y + (int64_t)(cy0 * p.dy + (tid >> 3)) * 32 + (tid & 7) * 4),
+                                                 (NAF_LDS void*)(Ty + wave * 256), 16, 0, 0);
+            if (TXL && wave >= 2 && wave < 4 && tid < 128 + p.dx * 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.tab_x + (int64_t)(cx0 * p.dx + ((tid - 128) >> 3)) * 32 + (tid & 7) * 4),
+                                                 (NAF_LDS void*)(Tx + (wave - 2) * 256), 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q_AFTER_WINDOW) load_first_queries();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool rope = p.tab_y != nullptr;
+    if constexpr (TPW == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+#else
     {
         const bf16_t* kb = p.k + b * p.ks[0] + head * p.ks[1];
         const bf16_t* vb = p.v + b * p.vs[0] + head * p.vs[1] + chunk * DVT;
@@ -334,6 +382,7 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     }
     const bool rope = p.tab_y != nullptr;   // rotate-on-load (host guarantees the FAST path then)
     __syncthreads();
+#endif
     XNA_TSTAMP(ts_staged)
 
     // key slots >= NSLOT are not stored: clamp their row to the last real key (their logits are masked, P = 0)
