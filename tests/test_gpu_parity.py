@@ -813,6 +813,37 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     assert done >= 40 and ragged >= 10 and small >= 20, (done, ragged, small)
 
 
+@pytest.mark.parametrize("B,heads,lr,d,Dv,ksz", [
+    (2, 4, (40, 40), (16, 16), 192, 7),     # G1's instantiation, 320 cell rows x heads: segments of ~10 cells, five runs per workgroup
+    (3, 2, (44, 46), (4, 16), 256, 7),      # BASELINE's G2 / G3 width: one window buffer, a V key tile from the LDS, columns staged in two passes
+    (2, 4, (36, 50), (8, 16), 96, 9),       # 9 x 9 (the reference's default window), two window buffers
+    (2, 4, (34, 38), (6, 32), 128, 9),      # 9 x 9 at Dv = 128: one window buffer, K fragments from the LDS; three rounds per cell
+])
+def test_cell_backward_walks_several_runs_per_workgroup(dev, B, heads, lr, d, Dv, ksz):
+    """The wave-specialised backward launches one resident workgroup per CU and lets it walk runs of cells (xna_bwd2_kernel.h); every other
+    backward case in this file has fewer runs than the chip has CUs, i.e. ONE run per workgroup -- as have G1, G2 and a G3 image.  Here
+    B x h x heads exceeds 256, so workgroups leave a run (flush of the whole window, windows of another cell row / head / image staged
+    from scratch, walker and key-wave bookkeeping re-decoded) several times.  Checked against the independent table-driven scalar kernel
+    (fp32 throughout) on the same bf16 inputs."""
+    from naf_amd import ops
+    h, w = lr
+    Ho, Wo = h * d[0], w * d[1]
+    assert B * h * heads > 256
+    gen = torch.Generator(device=dev).manual_seed(4242 + Dv + ksz)
+    q = torch.randn(B, heads, Ho, Wo, 64, device=dev, generator=gen).to(torch.bfloat16)
+    k = torch.randn(B, heads, h, w, 64, device=dev, generator=gen).to(torch.bfloat16)
+    v = torch.randn(B, h, w, heads, Dv, device=dev, generator=gen).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    g = torch.randn(B, Ho, Wo, heads, Dv, device=dev, generator=gen).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    assert ops.xna_backward_select(q, k, v, ksz) == "mfma"
+    a = ops.xna_backward(q, k, v, g, ksz)
+    b = ops.xna_backward(q, k, v, g, ksz, path="generic")
+    for x, y, name in zip(a, b, ("dq", "dk", "dv")):
+        scale = float(y.float().abs().max())
+        err = (x.float() - y.float()).abs()
+        assert bool(torch.isfinite(x.float()).all()), name
+        assert float(err.max()) <= 2.5e-2 * scale + 1e-3 and float(err.mean()) <= 3e-3 * scale + 1e-4, (name, float(err.max()), float(err.mean()), scale)
+
+
 @pytest.mark.parametrize("B,Cq,C,heads,size,ksz", [
     (1, 96, 3, 1, (12, 10), 5),        # narrower than one 16-query tile
     (1, 96, 3, 1, (40, 52), 15),       # the denoising call's shape class: one head, RGB values, 15x15 window, ragged last tile
