@@ -489,6 +489,32 @@ def test_attention_G3_whole_batch_of_64_in_one_launch(dev):
         assert float((ones[b].float() - 0.5).abs().max()) <= 4e-3
 
 
+@pytest.mark.parametrize("name,C,lr,out,ksz", [
+    ("G1", 768, 64, 1024, 7),          # xna_bwd2_kernel<7, 192>: 256 runs of 64 cells, one per CU
+    ("G2-k7", 1024, 32, 512, 7),       # xna_bwd2_kernel<7, 256>: one window buffer, a V key tile from the LDS per round
+    ("G2-k11", 1024, 32, 512, 11),     # four-wave kernel, one workgroup per CU
+])
+def test_attention_backward_at_benched_sizes_against_the_scalar_kernel(dev, name, C, lr, out, ksz):
+    """The attention backward at BASELINE's sizes (the oracle's autograd would take minutes there): the matrix-core cell kernels against the
+    independent table-driven scalar kernel (fp32 throughout, one wave per query) on the same bf16 inputs, every element of dq / dk / dv."""
+    from naf_amd import ops
+    heads = 4
+    gen = torch.Generator(device=dev).manual_seed(8800 + C + ksz)
+    q = torch.randn(1, heads, out, out, 64, device=dev, generator=gen).to(torch.bfloat16)
+    k = torch.randn(1, heads, lr, lr, 64, device=dev, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, lr, lr, heads, C // heads, device=dev, generator=gen).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    g = torch.randn(1, out, out, heads, C // heads, device=dev, generator=gen).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
+    assert ops.xna_backward_select(q, k, v, ksz) == "mfma"
+    a = ops.xna_backward(q, k, v, g, ksz)
+    b = ops.xna_backward(q, k, v, g, ksz, path="generic")
+    for x, y, nm in zip(a, b, ("dq", "dk", "dv")):
+        scale = float(y.float().abs().max())
+        err = (x.float() - y.float()).abs()
+        assert bool(torch.isfinite(x.float()).all()), (name, nm)
+        # dk / dv add up 256 queries x k^2 windows of bf16-rounded P / dS per key: the cell-fuzz tolerance
+        assert float(err.max()) <= 2.5e-2 * scale + 1e-3 and float(err.mean()) <= 3e-3 * scale + 1e-4, (name, nm, float(err.max()), float(err.mean()), scale)
+
+
 def test_edge_inputs_empty_batch_dtypes_and_strides(dev):
     """Edge cases at the operator boundary: an empty batch (empty tensors in, empty tensors out, as through the reference's torch
     ops), fp16 / fp64 features (computed through the bf16 / fp32 contract, returned in the caller's dtype), a non-contiguous
