@@ -33,7 +33,10 @@ template <int KS, int DV>
 struct XnaBwd2Geom {
     using G = XnaBwdGeom<KS, DV>;
     static constexpr size_t kv_elems = (size_t)G::NSLOT * (G::KROW + G::VROW);  // bf16 per K + V window buffer
-    static constexpr int PROW = G::KPAD + 8;                                    // bf16 per row of the P / dS matrices [query][slot]
+    // bf16 per row of the P / dS matrices [query][slot].  9 x 9: the sixth key tile holds ONE real slot (80), so a row keeps 88 slots and the
+    // tile's transposed reads of columns 88 .. 95 run into the next row (finite or not, that data only reaches the accumulators of pad slots,
+    // which are never added to memory; the query waves do not write those columns) -- 8 KB less, which is what lets Dv = 192 (C = 768) fit
+    static constexpr int PROW = (KS == 9) ? 88 : G::KPAD + 8;
     static constexpr size_t ps_elems = (size_t)4 * 16 * PROW;                   // bf16 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
     static constexpr size_t round_bytes = 2 * (2 * ps_elems * 2) + 2 * (qg_elems * 2);
@@ -49,7 +52,9 @@ struct XnaBwd2Geom {
 #ifndef NAF_BWD2_VREGS   // A/B builds only (tools/build_variant.py): the register budget of the resident V fragments
 #define NAF_BWD2_VREGS 96
 #endif
-    static constexpr int v_res_mt = (NAF_BWD2_VREGS / ((DV / 32) * 4)) < G::MT ? (NAF_BWD2_VREGS / ((DV / 32) * 4)) : G::MT;
+    // (9 x 9 at Dv = 192: six key tiles of sT / gT and the K fragments streamed beside them -- three resident V tiles, 96 spilled 18 registers)
+    static constexpr int v_budget = (KS == 9 && DV >= 192) ? (NAF_BWD2_VREGS < 72 ? NAF_BWD2_VREGS : 72) : NAF_BWD2_VREGS;
+    static constexpr int v_res_mt = (v_budget / ((DV / 32) * 4)) < G::MT ? (v_budget / ((DV / 32) * 4)) : G::MT;
 };
 
 template <int KS, int DV>
@@ -354,8 +359,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                             pk[rr] = live ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
                             sk[rr] = live ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
                         }
-                        *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pk;
-                        *reinterpret_cast<bf16x4_t*>(srow + mt * 16) = sk;
+                        if (mt * 16 + 16 <= PROW || mt * 16 + grp * 4 + 4 <= PROW) {     // (9 x 9: the last tile's columns past the row pitch are not stored)
+                            *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pk;
+                            *reinterpret_cast<bf16x4_t*>(srow + mt * 16) = sk;
+                        }
                     }
                 }
                 BWD2_STAMP(2);   // softmax, delta, dS^T, P / dS -> LDS
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #endif
 }
 
-// Windows up to 9 x 9 whose buffers fit the LDS (9 x 9 stops at Dv = 128: 167 KB at Dv = 192); everything else stays with the four-wave
+// Windows up to 9 x 9 whose buffers fit the LDS (9 x 9 stops at Dv = 192: 185 KB at Dv = 256); everything else stays with the four-wave
 // kernel.  Where the whole window's V fragments do not fit beside a query wave's working set (7 x 7 at Dv = 256: 128 registers of them, hipcc 7.2
 // spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>
