@@ -39,7 +39,12 @@ struct XnaBwd2Geom {
     static constexpr int PROW = (KS == 9) ? 88 : G::KPAD + 8;
     static constexpr size_t ps_elems = (size_t)4 * 16 * PROW;                   // bf16 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
-    static constexpr size_t round_bytes = 2 * (2 * ps_elems * 2) + 2 * (qg_elems * 2);
+    // Round buffers: Q / dO always double; P / dS double where the LDS has room, SINGLE otherwise (9 x 9 at Dv = 256, C = 1024 at the reference's
+    // default window: 185.5 -> 163.0 KB).  With one P / dS buffer a round has two barriers: the query waves keep P and dS in registers across
+    // their dQ, cross the first barrier (the key waves have finished the previous round's matrices), write, cross the second.
+    static constexpr size_t qg_bytes = 2 * (qg_elems * 2);
+    static constexpr int ps_bufs = (kv_elems * 2 + 2 * (2 * ps_elems * 2) + qg_bytes <= 160 * 1024) ? 2 : 1;
+    static constexpr size_t round_bytes = ps_bufs * (2 * ps_elems * 2) + qg_bytes;
     // Two window buffers (the key waves bring the other one up to the next cell while this one is in use) where the LDS has room;
     // one otherwise: the entering column is then written between two barriers at the cell change (the widest shapes: Dv = 256 at k = 7)
     static constexpr int kv_bufs = (2 * kv_elems * 2 + round_bytes <= 160 * 1024) ? 2 : 1;
@@ -53,7 +58,8 @@ struct XnaBwd2Geom {
 #define NAF_BWD2_VREGS 96
 #endif
     // (9 x 9 at Dv = 192: six key tiles of sT / gT and the K fragments streamed beside them -- three resident V tiles, 96 spilled 18 registers)
-    static constexpr int v_budget = (KS == 9 && DV >= 192) ? (NAF_BWD2_VREGS < 72 ? NAF_BWD2_VREGS : 72) : NAF_BWD2_VREGS;
+    static constexpr int v_budget = (KS == 9 && DV >= 256) ? 0
+                                  : (KS == 9 && DV >= 192) ? (NAF_BWD2_VREGS < 72 ? NAF_BWD2_VREGS : 72) : NAF_BWD2_VREGS;
     static constexpr int v_res_mt = (v_budget / ((DV / 32) * 4)) < G::MT ? (v_budget / ((DV / 32) * 4)) : G::MT;
 };
 
@@ -63,14 +69,15 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     using G2 = XnaBwd2Geom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32, PROW = G2::PROW;
-    constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident;
+    constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident, PS2 = G2::ps_bufs == 2;
+    constexpr bool KTILE = !KRES && KS == 9 && DV >= 256;   // K fragments one key tile at a time (elsewhere: all of the window's at the top of a round, or resident)
     constexpr int VRES = G2::v_res_mt;
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* KV = reinterpret_cast<bf16_t*>(smem);                                // [2 window buffers][K: NSLOT x KROW | V: NSLOT x VROW]
     bf16_t* PS = KV + G2::kv_bufs * G2::kv_elems;                                          // [2 round buffers][P | dS][4 tiles x 16 queries][PROW]
-    bf16_t* QG = PS + 2 * 2 * G2::ps_elems;                                      // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
+    bf16_t* QG = PS + G2::ps_bufs * 2 * G2::ps_elems;                                      // [2 round buffers][Q: 4 x 16 x KROW | dO: 4 x 16 x VROW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         auto krow = [&](int mt) __attribute__((always_inline)) { return min(mt * 16 + col, NSLOT - 1); };
         // the windows as operand fragments, resident for the whole cell (at the widest shapes only V: the K fragments, a fifth of the
         // S / dP MFMAs there, are then read at the top of every round)
-        bf16x8_t kfr[MT][2], vfr[VRES][DKS];
+        bf16x8_t kfr[KTILE ? 1 : MT][2], vfr[VRES > 0 ? VRES : 1][DKS];
         int c_run = first, c_pos = 0, c_len = r0.len;
         bf16_t* dq_cell = dq_of(r0);
         int g = 0;   // rounds since the kernel started: round buffer g & 1, row set g & 1
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             for (int r = 0; r < nround; ++r, ++g) {
                 BWD2_STAMP(0);
                 const int buf = g & 1;
-                bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
+                bf16_t* Pq = PS + (PS2 ? buf : 0) * (2 * G2::ps_elems);
                 bf16_t* Sq = Pq + G2::ps_elems;
                 bf16_t* Qs = QG + buf * G2::qg_elems;
                 bf16_t* Gs = Qs + 4 * 16 * KROW;
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const bool live = t < ntile;                       // dead tiles compute on the cell's last tile and contribute zeros
                 const int ty = ty_cur, tx0 = tx_cur * 16;
 
-                if constexpr (!KRES) {
+                if constexpr (!KRES && !KTILE) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
@@ -280,8 +287,13 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     sT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (KTILE) {     // the widest shape: a key tile's two K fragments, then its MFMAs
+                        const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[mt][ks], qf[ks], sT[mt], 0, 0, 0);
+                        for (int ks = 0; ks < 2; ++ks) kfr[0][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[KTILE ? 0 : mt][ks], qf[ks], sT[mt], 0, 0, 0);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -348,23 +360,26 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 // 8-byte store each; the key waves read them back transposed (ds_read_tr) as the A operands of the contractions over queries.
                 // (The four-wave kernel evaluated S and dP a second time with the operands swapped to get that layout out of the MFMA: 32
                 // more MFMAs, 16 more exponentials and a statistics exchange per tile.)
-                {
+                bf16x4_t pkv[MT];        // P in its stored form (with one P / dS buffer it waits in registers for the first barrier; sT is dead from here)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) pkv[mt][rr] = live ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
+                auto write_ps = [&]() __attribute__((always_inline)) {
                     bf16_t* prow = Pq + (wave * 16 + col) * PROW + grp * 4;
                     bf16_t* srow = Sq + (wave * 16 + col) * PROW + grp * 4;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        bf16x4_t pk, sk;
+                        bf16x4_t sk;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            pk[rr] = live ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
-                            sk[rr] = live ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
-                        }
+                        for (int rr = 0; rr < 4; ++rr) sk[rr] = live ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
                         if (mt * 16 + 16 <= PROW || mt * 16 + grp * 4 + 4 <= PROW) {     // (9 x 9: the last tile's columns past the row pitch are not stored)
-                            *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pk;
+                            *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pkv[mt];
                             *reinterpret_cast<bf16x4_t*>(srow + mt * 16) = sk;
                         }
                     }
-                }
+                };
+                if constexpr (PS2) write_ps();
                 BWD2_STAMP(2);   // softmax, delta, dS^T, P / dS -> LDS
                 // ---- dQ^T[d][q] = K^T . dS^T : lane (q, grp) gets 4 consecutive d per 16-d tile; pairs -> 16-byte stores ----
                 if (live) {
@@ -412,6 +427,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     ty_cur = ty_first; tx_cur = tx_first;
                 }
                 BWD2_STAMP(4);
+                if constexpr (!PS2) {
+                    __syncthreads();   // one P / dS buffer: the key waves have finished the previous round's matrices
+                    write_ps();
+                }
                 __syncthreads();   // this round's buffer is complete; the key waves have left the other one (and, by a cell's last
                                    // round, have brought the other window buffer up to the next cell)
                 BWD2_STAMP(5);
@@ -441,6 +460,12 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         stage_first();
         __syncthreads();
         const int wb = wave - 4, ktid = tid - 256;
+        // transposed reads of the round buffers: this lane's byte offset in a [query][.] matrix of each row length, the buffers' LDS addresses
+        const uint32_t ln_p = (uint32_t)(((grp * 4 + (col >> 2)) * PROW + (col & 3) * 4) * 2);
+        const uint32_t ln_q = (uint32_t)(((grp * 4 + (col >> 2)) * KROW + (col & 3) * 4) * 2);
+        const uint32_t ln_g = (uint32_t)(((grp * 4 + (col >> 2)) * VROW + (col & 3) * 4) * 2);
+        const uint32_t lds_ps = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((NAF_LDS bf16_t*)PS));
+        const uint32_t lds_qg = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((NAF_LDS bf16_t*)QG));
         f32x4_t accV[MT][NVW], accK[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -452,7 +477,13 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         // skipped by a scalar branch (at k = 7 four or five of the sixteen pairs take part).  dkp / dvp: the column's first key, wave-uniform.
         const uint32_t lane_acc = (uint32_t)(wb * 16 + col);
         const uint32_t rowstep = (uint32_t)(p.w * p.heads);     // elements / 64 (dK), / Dv (dV) between window rows
+        // The atomics are written as asm in the saddr form -- wave-uniform base, ONE 32-bit lane offset, immediates: from atomicAdd(ptr + index)
+        // hipcc forms a 64-bit VGPR address per atomic and hoists the lane-invariant part of every (tile, register) pair's out of the loop
+        // (up to 24 pairs x two tensors at 9 x 9: 158 registers spilled at Dv = 256, 16 at Dv = 192).
+        const uint32_t fl_lane = lane_acc * 4u, fl_stepk = rowstep * 256u, fl_stepv = rowstep * (uint32_t)DV * 4u;
         auto flush_col = [&](float* dkp, float* dvp, int lo) __attribute__((always_inline)) {
+            uint32_t la = fl_lane;
+            asm volatile("" : "+v"(la));      // a lane constant the loop keeps in ONE register
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -465,14 +496,17 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #else
                         if ((unsigned)ry < (unsigned)KS) {
 #endif
-                            atomicAdd(dkp + ((uint32_t)ry * rowstep * 64u + lane_acc), accK[mt][rr]);
-                            accK[mt][rr] = 0.f;
+                            const uint32_t ok = (uint32_t)ry * fl_stepk + la, ov = (uint32_t)ry * fl_stepv + la;
+                            asm volatile("global_atomic_add_f32 %0, %1, %2" ::"v"(ok), "v"(accK[mt][rr]), "s"(dkp) : "memory");
 #pragma unroll
                             for (int i = 0; i < NVW; ++i)
-                                if (NVT % 4 == 0 || wb + 4 * i < NVT) {
-                                    atomicAdd(dvp + ((uint32_t)ry * rowstep * (uint32_t)DV + lane_acc + i * 64), accV[mt][i][rr]);
-                                    accV[mt][i][rr] = 0.f;
-                                }
+                                if (NVT % 4 == 0 || wb + 4 * i < NVT)
+                                    asm volatile("global_atomic_add_f32 %0, %1, %2 offset:%3" ::"v"(ov), "v"(accV[mt][i][rr]), "s"(dvp), "i"(i * 256) : "memory");
+                        }
+                        if ((unsigned)ry < (unsigned)KS) {
+                            accK[mt][rr] = 0.f;
+#pragma unroll
+                            for (int i = 0; i < NVW; ++i) accV[mt][i][rr] = 0.f;
                         }
                     }
                 }
@@ -576,30 +610,36 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             for (int u = 0; u < NP; ++u) stage[u] = *reinterpret_cast<const u32x4_t*>(s_base[u] + (int64_t)ld_x * s_xstr[u]);
             if (g >= 1) {
                 const int buf = (g - 1) & 1;
-                const bf16_t* Pq = PS + buf * (2 * G2::ps_elems);
-                const bf16_t* Sq = Pq + G2::ps_elems;
-                const bf16_t* Qs = QG + buf * G2::qg_elems;
-                const bf16_t* Gs = Qs + 4 * 16 * KROW;
+                // Every transposed read below is (one opaque lane register per matrix type + a wave-uniform base) + an immediate: written out as
+                // pointers, hipcc materialises each of the ~50 addresses in its own register and hoists them out of the loop (164 registers
+                // spilled at 9 x 9 with Dv = 256, 18 at Dv = 192)
+                uint32_t ap = ln_p + (lds_ps + (uint32_t)((PS2 ? buf : 0) * (2 * G2::ps_elems * 2)));
+                uint32_t aq = ln_q + (lds_qg + (uint32_t)(buf * (G2::qg_elems * 2)) + (uint32_t)wb * 32u);
+                uint32_t ag = ln_g + (lds_qg + (uint32_t)(buf * (G2::qg_elems * 2)) + (uint32_t)(4 * 16 * KROW * 2) + (uint32_t)wb * 32u);
+                asm volatile("" : "+v"(ap), "+v"(aq), "+v"(ag));
+                // operands of a contraction over the 32 queries of tiles 2pr / 2pr+1: queries 4*grp..+3 of each (rows +16 * rowlen: the second tile)
+                auto tr2 = [&](uint32_t addr, int rowlen) __attribute__((always_inline)) {
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(uintptr_t)addr);
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(uintptr_t)(addr + (uint32_t)(16 * rowlen * 2)));
+                    bf16x8_t o;
+                    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+                    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+                    return o;
+                };
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    // operands of a contraction over the 32 queries of tiles 2pr / 2pr+1: queries 4*grp..+3 of each, 16-wide column tile nt
-                    auto tr_pair = [&](const bf16_t* base, int rowlen, int nt) __attribute__((always_inline)) {
-                        const bf16_t* a = base + ((2 * pr) * 16 + grp * 4 + (col >> 2)) * rowlen + (col & 3) * 4 + nt * 16;
-                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a);
-                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(a + 16 * rowlen));
-                        bf16x8_t o;
-                        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-                        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-                        return o;
-                    };
-                    const bf16x8_t bq = tr_pair(Qs, KROW, wb);
+                    const bf16x8_t bq = tr2(aq + (uint32_t)(pr * 32 * KROW * 2), KROW);
                     bf16x8_t bg[NVW];
 #pragma unroll
-                    for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, NVT % 4 == 0 ? wb + 4 * i : min(wb + 4 * i, NVT - 1));
+                    for (int i = 0; i < NVW; ++i) {
+                        if constexpr (NVT % 4 == 0) bg[i] = tr2(ag + (uint32_t)(pr * 32 * VROW * 2 + i * 128), VROW);
+                        else bg[i] = tr2(ag + (uint32_t)(pr * 32 * VROW * 2) + (uint32_t)(min(wb + 4 * i, NVT - 1) - wb) * 32u, VROW);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         // A operands: slot mt*16 + col, queries 4*grp..+3 of the two tiles -- the transposed read of [query][slot]
-                        const bf16x8_t pa = tr_pair(Pq, PROW, mt), sa = tr_pair(Sq, PROW, mt);
+                        const bf16x8_t pa = tr2(ap + (uint32_t)(pr * 32 * PROW * 2 + mt * 32), PROW);
+                        const bf16x8_t sa = tr2(ap + (uint32_t)(G2::ps_elems * 2 + pr * 32 * PROW * 2 + mt * 32), PROW);
                         accK[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, bq, accK[mt], 0, 0, 0);
 #pragma unroll
                         for (int i = 0; i < NVW; ++i)
@@ -608,6 +648,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 }
             }
             BWD2_STAMP(1);
+            if constexpr (!PS2) {
+                if (more) __syncthreads();   // one P / dS buffer: the matrices of round g - 1 are consumed, the query waves may write round g's
+            }
             if (g >= 1) {
                 if (++k_r == nround) {
                     // the cell is complete: the column its successor's window no longer holds (all of them at the end of a run) leaves
@@ -680,7 +723,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #endif
 }
 
-// Windows up to 9 x 9 whose buffers fit the LDS (9 x 9 stops at Dv = 192: 185 KB at Dv = 256); everything else stays with the four-wave
+// Windows up to 9 x 9 whose buffers fit the LDS (all of them since the single P / dS buffer mode); everything else stays with the four-wave
 // kernel.  Where the whole window's V fragments do not fit beside a query wave's working set (7 x 7 at Dv = 256: 128 registers of them, hipcc 7.2
 // spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>

@@ -728,6 +728,7 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
     (1, 512, (10, 11), (160, 176), 9),     # Dv = 128, 9x9: eight-wave kernel with ONE window buffer and K fragments from the LDS
     (1, 768, (10, 12), (160, 192), 9),     # Dv = 192, 9x9 (ViT-B features at the reference's default window): 88-slot P / dS rows, three resident V key tiles
+    (1, 1024, (10, 11), (160, 176), 9),    # Dv = 256, 9x9 (DINOv3-L features at the reference's default window): ONE P / dS buffer, two barriers per round, no resident V tile
     (2, 768, (9, 12), (144, 192), 7),      # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
     (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
     (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): one workgroup per CU
@@ -820,6 +821,7 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     (2, 4, (36, 50), (8, 16), 96, 9),       # 9 x 9 (the reference's default window), two window buffers
     (2, 4, (34, 38), (6, 32), 128, 9),      # 9 x 9 at Dv = 128: one window buffer, K fragments from the LDS; three rounds per cell
     (2, 4, (33, 40), (4, 16), 192, 9),      # 9 x 9 at Dv = 192 (C = 768): 88-slot P / dS rows, columns staged in two passes
+    (2, 4, (35, 37), (2, 32), 256, 9),      # 9 x 9 at Dv = 256 (C = 1024): one P / dS buffer (two barriers per round) AND one window buffer
 ])
 def test_cell_backward_walks_several_runs_per_workgroup(dev, B, heads, lr, d, Dv, ksz):
     """The wave-specialised backward launches one resident workgroup per CU and lets it walk runs of cells (xna_bwd2_kernel.h); every other
