@@ -420,8 +420,10 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  *   dk_lr  device float [B, h, w, heads, Dq] dense, dv_lr device float [B, h, w, heads, Dv] dense: the caller
  *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
  *   idx_y, idx_x   optional device int32 tables from naf_axis_index_table, required by the table-driven path.
- * Two kernels, like the forward: the MFMA cell kernel (what the MFMA forward serves with ky = kx <= 9, Wo/w a
- * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}) and a table-driven one for everything else (any ratio,
+ * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 13, Wo/w a
+ * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 on the wave-specialised eight-wave
+ * kernel at every Dv, 11 x 11 and 13 x 13 -- the latter up to Dv = 128 -- on the four-wave kernel), the row-streaming
+ * matrix-core kernel below, and a table-driven one for everything else (any ratio,
  * head dims, rectangular windows; one wave per query, atomics per key).  naf_xna_bwd_supported returns which
  * (NAF_XNA_MFMA / NAF_XNA_GENERIC) so that the caller knows whether to build the tables.  scale <= 0 selects Dq^-0.5. */
 typedef struct naf_xna_bwd_args {
