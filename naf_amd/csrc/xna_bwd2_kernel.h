@@ -483,7 +483,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         const uint32_t fl_lane = lane_acc * 4u, fl_stepk = rowstep * 256u, fl_stepv = rowstep * (uint32_t)DV * 4u;
         auto flush_col = [&](float* dkp, float* dvp, int lo) __attribute__((always_inline)) {
             uint32_t la = fl_lane;
-            asm volatile("" : "+v"(la));      // a lane constant the loop keeps in ONE register
+            // (the asm atomics read accumulator registers the step's last MFMAs wrote: hipcc's hazard recogniser does not look into asm operands,
+            // so the wait states an MFMA result needs before a VMEM read are spelled out -- the branches in between cover them many times over,
+            // this costs 32 idle issue slots per column and removes the assumption)
+            asm volatile("s_nop 15\n\ts_nop 15\n" : "+v"(la));      // ... and a lane constant the loop keeps in ONE register
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
