@@ -421,8 +421,8 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
  *   idx_y, idx_x   optional device int32 tables from naf_axis_index_table, required by the table-driven path.
  * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 13, Wo/w a
- * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 on the wave-specialised eight-wave
- * kernel at every Dv, 11 x 11 and 13 x 13 -- the latter up to Dv = 128 -- on the four-wave kernel), the row-streaming
+ * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 at every Dv and 11 x 11 up to Dv = 128 on
+ * the wave-specialised eight-wave kernel, the rest of 11 x 11 and 13 x 13 -- up to Dv = 128 -- on the four-wave kernel), the row-streaming
  * matrix-core kernel below, and a table-driven one for everything else (any ratio,
  * head dims, rectangular windows; one wave per query, atomics per key).  naf_xna_bwd_supported returns which
  * (NAF_XNA_MFMA / NAF_XNA_GENERIC) so that the caller knows whether to build the tables.  scale <= 0 selects Dq^-0.5. */

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32, PROW = G2::PROW;
     constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident, PS2 = G2::ps_bufs == 2;
-    constexpr bool KTILE = !KRES && KS == 9 && DV >= 256;   // K fragments one key tile at a time (elsewhere: all of the window's at the top of a round, or resident)
+    constexpr bool KTILE = !KRES && ((KS == 9 && DV >= 256) || KS >= 11);   // K fragments one key tile at a time (elsewhere: all of the window's at the top of a round, or resident)
     constexpr int VRES = G2::v_res_mt;
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
 
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 // spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 9 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
+    return KS <= 11 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
 }
 
 template <int KS, int DV>

@@ -727,11 +727,13 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 768, (7, 7), (7, 112), 7),         # Dv = 192, dy = 1: one tile per cell (three dead waves per round), k = h = w
     (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
     (1, 512, (10, 11), (160, 176), 9),     # Dv = 128, 9x9: eight-wave kernel with ONE window buffer and K fragments from the LDS
-    (1, 768, (10, 12), (160, 192), 9),     # Dv = 192, 9x9 (ViT-B features at the reference's default window): 88-slot P / dS rows, three resident V key tiles
-    (1, 1024, (10, 11), (160, 176), 9),    # Dv = 256, 9x9 (DINOv3-L features at the reference's default window): ONE P / dS buffer, two barriers per round, no resident V tile
+    (1, 768, (10, 12), (80, 192), 9),      # Dv = 192, 9x9 (ViT-B features at the reference's default window): 88-slot P / dS rows, three resident V key tiles
+    (1, 1024, (10, 11), (80, 176), 9),     # Dv = 256, 9x9 (DINOv3-L features at the reference's default window): ONE P / dS buffer, two barriers per round, no resident V tile
     (2, 768, (9, 12), (144, 192), 7),      # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
     (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
-    (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): one workgroup per CU
+    (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
+    (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
+    (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): four-wave kernel, one workgroup per CU
     (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow)
 ])
 def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
@@ -822,6 +824,7 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     (2, 4, (34, 38), (6, 32), 128, 9),      # 9 x 9 at Dv = 128: one window buffer, K fragments from the LDS; three rounds per cell
     (2, 4, (33, 40), (4, 16), 192, 9),      # 9 x 9 at Dv = 192 (C = 768): 88-slot P / dS rows, columns staged in two passes
     (2, 4, (35, 37), (2, 32), 256, 9),      # 9 x 9 at Dv = 256 (C = 1024): one P / dS buffer (two barriers per round) AND one window buffer
+    (2, 4, (33, 35), (4, 16), 128, 11),     # 11 x 11 at Dv = 128: the widest the eight-wave kernel takes at that window
 ])
 def test_cell_backward_walks_several_runs_per_workgroup(dev, B, heads, lr, d, Dv, ksz):
     """The wave-specialised backward launches one resident workgroup per CU and lets it walk runs of cells (xna_bwd2_kernel.h); every other
