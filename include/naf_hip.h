@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 400 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 401 /* major*10000 + minor*100 + patch */
 /* Binary compatibility: the argument structs carry no size field, so a host must be BUILT against the header of the library it
  * loads whenever the minor version differs (compare naf_version() / 100 with NAF_HIP_VERSION / 100 at start-up, as
  * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
@@ -47,7 +47,9 @@ extern "C" {
  * built against a 0.2.x / 0.3.x header fails to resolve them at load time instead of overrunning its [B][8][2] buffers, and
  * naf_abi_check(NAF_HIP_VERSION) lets a host compare the header it was compiled with against the library it loaded in one call.
  * 0.4.0 also appends `flags` to naf_stem_conv0_args and adds naf_forward_ex / naf_forward_aux (caller-owned second stream);
- * naf_forward itself is unchanged in signature and now runs on the caller's stream only. */
+ * naf_forward itself is unchanged in signature and now runs on the caller's stream only.
+ * 0.4.1 (binary compatible with 0.4.0): naf_xna_bwd_args.reserved -- documented as 0 -- becomes `path` (0 = NAF_XNA_AUTO: the
+ * behaviour of 0.4.0), and the cell backward takes 13 x 13 windows at every Dv and 15 x 15 windows (channel chunks). */
 #define naf_stem_conv0_fwd naf_stem_conv0_fwd_s16
 #define naf_stem_conv_fwd naf_stem_conv_fwd_s16
 #define naf_stem_conv_keys_fwd naf_stem_conv_keys_fwd_s16
@@ -420,12 +422,14 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  *   dk_lr  device float [B, h, w, heads, Dq] dense, dv_lr device float [B, h, w, heads, Dv] dense: the caller
  *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
  *   idx_y, idx_x   optional device int32 tables from naf_axis_index_table, required by the table-driven path.
- * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 13, Wo/w a
+ * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 15, Wo/w a
  * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 at every Dv and 11 x 11 up to Dv = 128 on
- * the wave-specialised eight-wave kernel, the rest of 11 x 11 and 13 x 13 -- up to Dv = 128 -- on the four-wave kernel), the row-streaming
- * matrix-core kernel below, and a table-driven one for everything else (any ratio,
+ * the wave-specialised eight-wave kernel, the rest of 11 x 11 on the four-wave kernel, 13 x 13 and 15 x 15 on the four-wave kernel in
+ * CHANNEL CHUNKS of at most 128 / 64 value channels per launch -- the softmax does not depend on V, dV splits by channel and dQ / dK are
+ * sums over channels, so each launch is a complete backward for its slice and later launches add their dQ to the earlier ones'), the
+ * row-streaming matrix-core kernel below, and a table-driven one for everything else (any ratio,
  * head dims, rectangular windows; one wave per query, atomics per key).  naf_xna_bwd_supported returns which
- * (NAF_XNA_MFMA / NAF_XNA_GENERIC) so that the caller knows whether to build the tables.  scale <= 0 selects Dq^-0.5. */
+ * (NAF_XNA_MFMA / NAF_XNA_ROWS / NAF_XNA_GENERIC) so that the caller knows whether to build the tables.  scale <= 0 selects Dq^-0.5. */
 typedef struct naf_xna_bwd_args {
     const void* q;
     const void* k_lr;
@@ -438,7 +442,8 @@ typedef struct naf_xna_bwd_args {
     const int32_t* idx_x;
     int32_t B, heads, Ho, Wo, h, w, Dq, Dv, ky, kx;
     float scale;
-    int32_t reserved;
+    int32_t path;            /* 0.4.1 (was `reserved`, 0): NAF_XNA_AUTO, or insist on NAF_XNA_MFMA / NAF_XNA_ROWS / NAF_XNA_GENERIC -- GENERIC
+                                runs the table-driven scalar kernel on ANY shape (the independent reference of the parity tests) */
     int64_t q_stride[4];
     int64_t k_stride[4];
     int64_t v_stride[4];

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported before the HIP library is dlopen'e
 # NAF_HIP_LIB lets an experiment point at an alternative build of the SAME library (A/B kernel variants)
 LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
-HEADER_VERSION = 400          # NAF_HIP_VERSION of the include/naf_hip.h these ctypes mirrors were written against
+HEADER_VERSION = 401          # NAF_HIP_VERSION of the include/naf_hip.h these ctypes mirrors were written against
 NAF_BF16, NAF_F32 = 0, 1
 XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION, XNA_ROWS = 0, 1, 2, 3, 4
 
@@ -119,7 +119,7 @@ class XnaBwdArgs(C.Structure):
         ("dk_lr", C.c_void_p), ("dv_lr", C.c_void_p), ("idx_y", C.c_void_p), ("idx_x", C.c_void_p),
         ("B", C.c_int32), ("heads", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("h", C.c_int32),
         ("w", C.c_int32), ("Dq", C.c_int32), ("Dv", C.c_int32), ("ky", C.c_int32), ("kx", C.c_int32),
-        ("scale", C.c_float), ("reserved", C.c_int32),
+        ("scale", C.c_float), ("path", C.c_int32),
         ("q_stride", I64x4), ("k_stride", I64x4), ("v_stride", I64x4), ("dout_stride", I64x4), ("dq_stride", I64x4),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]

@@ -349,15 +349,39 @@ static int xna_bwd_validate(const naf_xna_bwd_args* a) {
     return NAF_OK;
 }
 
+// Which kernel serves the request under a->path (0.4.1: the field that was `reserved`; 0 = NAF_XNA_AUTO as before): AUTO takes the cell
+// kernel, else the row-streaming one, else the table-driven one; NAF_XNA_MFMA / NAF_XNA_ROWS insist on theirs (NAF_ERR_UNSUPPORTED where it
+// does not apply); NAF_XNA_GENERIC is the table-driven scalar kernel for ANY shape -- the independent reference of the parity tests.
+static int xna_bwd_pick(const naf_xna_bwd_args* a) {
+    switch (a->path) {
+        case NAF_XNA_AUTO:
+            if (naf_xna_bwd_eligible(a)) return NAF_XNA_MFMA;
+            return naf_xna_rows_bwd_eligible(a) ? NAF_XNA_ROWS : NAF_XNA_GENERIC;
+        case NAF_XNA_MFMA:
+            if (naf_xna_bwd_eligible(a)) return NAF_XNA_MFMA;
+            naf_set_error("naf_xna_bwd: path NAF_XNA_MFMA asked for a shape the cell kernels do not serve (k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
+                          a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
+            return -NAF_ERR_UNSUPPORTED;
+        case NAF_XNA_ROWS:
+            if (naf_xna_rows_bwd_eligible(a)) return NAF_XNA_ROWS;
+            naf_set_error("naf_xna_bwd: path NAF_XNA_ROWS asked for a shape the row-streaming kernel does not serve (k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
+                          a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
+            return -NAF_ERR_UNSUPPORTED;
+        case NAF_XNA_GENERIC:
+            return NAF_XNA_GENERIC;
+    }
+    naf_set_error("naf_xna_bwd: path %d (NAF_XNA_AUTO, NAF_XNA_MFMA, NAF_XNA_ROWS or NAF_XNA_GENERIC)", a->path);
+    return -NAF_ERR_INVALID;
+}
+
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a) {
     const int rc = xna_bwd_validate(a);
     if (rc != NAF_OK) return -rc;
-    if (naf_xna_bwd_eligible(a)) return NAF_XNA_MFMA;
-    return naf_xna_rows_bwd_eligible(a) ? NAF_XNA_ROWS : NAF_XNA_GENERIC;
+    return xna_bwd_pick(a);
 }
 
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a) {
-    if (a == nullptr || xna_bwd_validate(a) != NAF_OK || naf_xna_bwd_eligible(a) || !naf_xna_rows_bwd_eligible(a)) return 0;
+    if (a == nullptr || xna_bwd_validate(a) != NAF_OK || xna_bwd_pick(a) != NAF_XNA_ROWS) return 0;
     return naf_xna_rows_bwd_workspace(a);
 }
 
@@ -365,13 +389,18 @@ int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream) {
     const int rc = xna_bwd_validate(a);
     if (rc != NAF_OK) return rc;
     const float scale = a->scale > 0.f ? a->scale : 1.0f / sqrtf((float)a->Dq);
-    if (naf_xna_bwd_eligible(a)) return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
+    const int sel = xna_bwd_pick(a);
+    if (sel < 0) return -sel;
+    if (sel == NAF_XNA_MFMA) return naf_launch_xna_bwd(a, scale, static_cast<hipStream_t>(stream));
     // the denoising call's shapes: matrix cores when the caller brought the tables and the statistics workspace
     // a workspace pointer that is not 16-byte aligned cannot be one this library asked for (a host built against a 0.1.0 header
     // leaves stack garbage in the field): refuse it instead of writing the per-query statistics through it
     NAF_REQUIRE(a->workspace == nullptr || al16(a->workspace), "naf_xna_bwd: workspace must be 16-byte aligned");
-    if (naf_xna_rows_bwd_eligible(a) && a->idx_y && a->idx_x && a->workspace && (size_t)a->workspace_bytes >= naf_xna_rows_bwd_workspace(a))
-        return naf_launch_xna_rows_bwd(a, scale, static_cast<hipStream_t>(stream));
+    if (sel == NAF_XNA_ROWS) {
+        if (a->idx_y && a->idx_x && a->workspace && (size_t)a->workspace_bytes >= naf_xna_rows_bwd_workspace(a))
+            return naf_launch_xna_rows_bwd(a, scale, static_cast<hipStream_t>(stream));
+        NAF_REQUIRE(a->path == NAF_XNA_AUTO, "naf_xna_bwd: path NAF_XNA_ROWS needs idx_y / idx_x and a workspace of naf_xna_bwd_workspace_bytes()");
+    }
     return naf_launch_xna_generic_bwd(a, scale, static_cast<hipStream_t>(stream));
 }
 

@@ -2,18 +2,30 @@
 #include "xna_bwd_kernel.h"
 
 #define NAF_DECL(K) int naf_xna_bwd_launch_k##K(const XnaBwdParams& p, int Dv, hipStream_t s);
-NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13)
+NAF_DECL(3) NAF_DECL(5) NAF_DECL(7) NAF_DECL(9) NAF_DECL(11) NAF_DECL(13) NAF_DECL(15)
 #undef NAF_DECL
 
 static bool bwd_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-// 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..13, Dq = 64, integer
+// Value channels per launch.  A window whose K / V tiles, round buffers or accumulators do not fit at the full Dv is served in CHANNEL CHUNKS:
+// the softmax depends on q and k only, dV splits by channel, and dQ / dK are sums over channels of V -- so the backward for a slice of V
+// (and of dO) is a complete backward, and the slices' dQ / dK add up (XnaBwdParams::dq_accum; dK through the atomics).  13 x 13: chunks of
+// up to 128 channels (Dv 192 = 128 + 64, 256 = 128 + 128); 15 x 15 (BASELINE configs[2]'s largest window): chunks of up to 64 -- 225 keys x
+// (64 + 64) accumulators and the two-sweep S / dP of xna_bwd_kernel.h are what one wave per SIMD holds without scratch.  0 = whole Dv.
+static int bwd_chunk_limit(int ks) { return ks >= 15 ? 64 : ks >= 13 ? 128 : 0; }
+static int bwd_next_chunk(int ks, int left) {
+    const int lim = bwd_chunk_limit(ks);
+    if (lim == 0 || left <= lim) return left;
+    return lim;
+}
+
+// 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..15, Dq = 64, integer
 // ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0), Dv in {32, 64, 96, 128, 192, 256} and K/V windows + round buffers
-// within 160 KB of LDS (all Dv up to k = 11; k = 13: Dv <= 128).
+// within 160 KB of LDS (all Dv up to k = 11 in one launch; k = 13 and 15 in channel chunks, above).
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->ky != a->kx) return 0;
     const int ks = a->ky;
-    if (ks < 3 || ks > 13 || (ks & 1) == 0) return 0;   // 15: hipcc 7.2 crashes in 'AMDGPU Rewrite AGPR-Copy-MFMA' on that instantiation
+    if (ks < 3 || ks > 15 || (ks & 1) == 0) return 0;
     if (a->Dq != 64) return 0;
     if (a->h < ks || a->w < ks) return 0;
     if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
@@ -22,7 +34,7 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
         case 32: case 64: case 96: case 128: case 192: case 256: break;
         default: return 0;
     }
-    if (xna_bwd_lds_for(ks, a->Dv) > 160 * 1024) return 0;   // k = 13 with Dv > 128: windows exceed the LDS
+    if (xna_bwd_lds_for(ks, bwd_next_chunk(ks, a->Dv)) > 160 * 1024) return 0;
     if (!bwd_aligned(a->q) || !bwd_aligned(a->k_lr) || !bwd_aligned(a->v_lr) || !bwd_aligned(a->dout) || !bwd_aligned(a->dq)) return 0;
     for (int i = 0; i < 4; ++i)
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->dout_stride[i] % 8 || a->dq_stride[i] % 8) return 0;
@@ -32,7 +44,7 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     if (!naf_xna_bwd_eligible(a)) {
         naf_set_error(
-            "naf_xna_bwd: needs square odd kernel 3..13 (windows within the LDS), Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
+            "naf_xna_bwd: needs square odd kernel 3..15, Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
             "Dv in {32,64,96,128,192,256} and 16-byte aligned tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
             a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;
@@ -60,13 +72,27 @@ int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
         p.qs[i] = a->q_stride[i]; p.ks[i] = a->k_stride[i]; p.vs[i] = a->v_stride[i];
         p.gs[i] = a->dout_stride[i]; p.dqs[i] = a->dq_stride[i];
     }
-    switch (a->ky) {
-        case 3: return naf_xna_bwd_launch_k3(p, a->Dv, s);
-        case 5: return naf_xna_bwd_launch_k5(p, a->Dv, s);
-        case 7: return naf_xna_bwd_launch_k7(p, a->Dv, s);
-        case 9: return naf_xna_bwd_launch_k9(p, a->Dv, s);
-        case 11: return naf_xna_bwd_launch_k11(p, a->Dv, s);
-        case 13: return naf_xna_bwd_launch_k13(p, a->Dv, s);
+    p.dv_pitch = a->Dv;
+    p.dq_accum = 0;
+    // channel chunks (one launch where the whole Dv fits): v, dout and dv move to the chunk's first channel of every head
+    for (int c0 = 0; c0 < a->Dv;) {
+        const int dvc = bwd_next_chunk(a->ky, a->Dv - c0);
+        p.v = static_cast<const bf16_t*>(a->v_lr) + c0;
+        p.dout = static_cast<const bf16_t*>(a->dout) + c0;
+        p.dv = a->dv_lr + c0;
+        p.dq_accum = c0 > 0;
+        int rc = NAF_ERR_UNSUPPORTED;
+        switch (a->ky) {
+            case 3: rc = naf_xna_bwd_launch_k3(p, dvc, s); break;
+            case 5: rc = naf_xna_bwd_launch_k5(p, dvc, s); break;
+            case 7: rc = naf_xna_bwd_launch_k7(p, dvc, s); break;
+            case 9: rc = naf_xna_bwd_launch_k9(p, dvc, s); break;
+            case 11: rc = naf_xna_bwd_launch_k11(p, dvc, s); break;
+            case 13: rc = naf_xna_bwd_launch_k13(p, dvc, s); break;
+            case 15: rc = naf_xna_bwd_launch_k15(p, dvc, s); break;
+        }
+        if (rc != NAF_OK) return rc;
+        c0 += dvc;
     }
-    return NAF_ERR_UNSUPPORTED;
+    return NAF_OK;
 }

@@ -40,6 +40,11 @@ struct XnaBwdParams {
     int32_t seg_len, nseg;   // xna_bwd2_kernel.h: cells per run, runs per cell row (nblocks = runs there)
     float scale, scale_log2e;
     int64_t qs[4], ks[4], vs[4], gs[4], dqs[4];  // {b, head, y, x} element strides (gs: dout)
+    // Channel chunks (xna_bwd.hip, windows whose K / V tiles + accumulators exceed the LDS / the register file at the full Dv): a launch
+    // works on DV of the head's dv_pitch value channels (v, dout, dv point at its first one) -- the softmax does not depend on the
+    // chunk and dQ, dK are sums over chunks, so every launch is a complete backward for its slice of V; launches after the first ADD
+    // their dQ to what is there (dq_accum), dK accumulates through the atomics as it does across cells.
+    int32_t dv_pitch, dq_accum;
 #if defined(NAF_BWD_TIMING) || defined(NAF_BWD_TIMING2)
     unsigned long long* tim;   // tools/xna_bwd_probe.hip: [workgroup][wave][8] s_memtime sums per phase
 #endif
@@ -76,6 +81,13 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32;   // 32-channel k-steps of the dP contraction
     static_assert(DV % 32 == 0, "Dv must be a multiple of 32");
+    // 15 x 15 (16 key tiles): S / dP in both operand orders at once are 256 registers beside 128 of accumulators (hipcc 7.2 spilled 233).
+    // Sweeps over the key tiles instead, with only S^T (lane = query) held: dP^T is evaluated tile by tile where it is consumed -- once for
+    // delta, once for dS^T -- and S, dP with a lane per key tile by tile in front of the P / dS hand-over; K / V fragments come from the
+    // LDS each time and the wave's own Q / dO fragments from their row-major copies (the registers they came in carry the next round's
+    // by then).  64 result registers live instead of 256; three dP evaluations instead of two (2 MFMAs per tile at a 64-channel chunk).
+    constexpr bool kTwoSweep = KS >= 15;
+    constexpr int MTS = kTwoSweep ? 1 : MT;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
@@ -205,7 +217,8 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
         }
 
         // S^T, dP^T (lane = query) and S, dP (lane = key) from the same fragments
-        f32x4_t sT[MT], gT[MT], sS[MT], gS[MT];
+        f32x4_t sT[MT], gT[MTS], sS[MTS], gS[MTS];
+        bf16x8_t qf2[2], gf2[DKS];   // kTwoSweep: the tile's fragments again, from the LDS copies
         // Only where it pays and fits: 9x9 at C = 384 0.935 -> 0.86 ms (round 4, interleaved); 7x7 windows measure the same with and without
         // (G1 0.97-1.00 vs 0.96-0.97 ms: their four key tiles leave little to pipeline), the widest shapes spill with the second set.
         constexpr bool kPrefetch = (KS == 9 && DV <= 128) || KS == 11 || (KS == 13 && DV <= 96);
@@ -241,6 +254,21 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (kTwoSweep) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                sT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    sT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(kr + ks * 32), qf[ks], sT[mt], 0, 0, 0);
+            }
+            const bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
+            qf2[0] = *reinterpret_cast<const bf16x8_t*>(qrow);
+            qf2[1] = *reinterpret_cast<const bf16x8_t*>(qrow + 32);
+            const bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
+#pragma unroll
+            for (int ks = 0; ks < DKS; ++ks) gf2[ks] = *reinterpret_cast<const bf16x8_t*>(grow + ks * 32);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -294,24 +322,38 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             }
         sum = naf_rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
+        // dP^T of key tile mt (lane = query): held from the MFMAs above, or evaluated here (kTwoSweep)
+        auto gT_of = [&](int mt) __attribute__((always_inline)) -> f32x4_t {
+            if constexpr (kTwoSweep) {
+                f32x4_t g = {0.f, 0.f, 0.f, 0.f};
+                const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+#pragma unroll
+                for (int ks = 0; ks < DKS; ++ks)
+                    g = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(vr + ks * 32), gf2[ks], g, 0, 0, 0);
+                return g;
+            } else {
+                return gT[mt];
+            }
+        };
         float delta = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4_t g = gT_of(mt);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sT[mt][r] *= inv;                       // P^T
-                delta = fmaf(sT[mt][r], gT[mt][r], delta);
+                delta = fmaf(sT[mt][r], g[r], delta);
             }
+        }
         delta = naf_rows_sum(delta);
         // dS^T = scale * P (dP - delta), packed as the B operand of dQ^T = K^T . dS^T  (k order as the forward's P)
         bf16x8_t dsf[KST];
 #pragma unroll
-        for (int ks = 0; ks < KST; ++ks)
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4_t g = gT_of(mt);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int mt = 2 * ks + (j >> 2), r = j & 3;
-                dsf[ks][j] = (bf16_t)(p.scale * sT[mt][r] * (gT[mt][r] - delta));
-            }
+            for (int r = 0; r < 4; ++r) dsf[mt >> 1][(mt & 1) * 4 + r] = (bf16_t)(p.scale * sT[mt][r] * (g[r] - delta));
+        }
 
         BWD_T(2);   // softmax, delta, dS^T
         // ---- dQ^T[d][q] = K^T . dS^T : lane (q, grp) gets 4 consecutive d per 16-d tile; pairs -> 16-byte stores ----
@@ -337,6 +379,15 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                     }
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, dsf[ks], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, dsf[ks], a1, 0, 0, 0);
+                }
+                if (p.dq_accum) {   // a later channel chunk: add what the earlier launches wrote (this lane's d = ct*16 + grp*4 .. +3, and + 16)
+                    const bf16x4_t o0 = *reinterpret_cast<const bf16x4_t*>(dqp + ct * 16 + grp * 4);
+                    const bf16x4_t o1 = *reinterpret_cast<const bf16x4_t*>(dqp + ct * 16 + 16 + grp * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a0[i] += (float)o0[i];
+                        a1[i] += (float)o1[i];
+                    }
                 }
                 bf16x4_t ab, bb;
 #pragma unroll
@@ -372,12 +423,27 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool kvalid = live && (mt * 16 + col < NSLOT);
+                f32x4_t sSm, gSm;
+                if constexpr (kTwoSweep) {
+                    sSm = gSm = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        sSm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2[ks], *reinterpret_cast<const bf16x8_t*>(kr + ks * 32), sSm, 0, 0, 0);
+                    const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
+#pragma unroll
+                    for (int ks = 0; ks < DKS; ++ks)
+                        gSm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf2[ks], *reinterpret_cast<const bf16x8_t*>(vr + ks * 32), gSm, 0, 0, 0);
+                } else {
+                    sSm = sS[mt];
+                    gSm = gS[mt];
+                }
                 bf16x4_t pk, sk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sS[mt][r], p.scale_log2e, -mcq[r])) * invq[r] : 0.f;
+                    const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(sSm[r], p.scale_log2e, -mcq[r])) * invq[r] : 0.f;
                     pk[r] = (bf16_t)pr;
-                    sk[r] = (bf16_t)(p.scale * pr * (gS[mt][r] - dlq[r]));
+                    sk[r] = (bf16_t)(p.scale * pr * (gSm[r] - dlq[r]));
                 }
                 Pl[(wave * MT + mt) * 64 + lane] = pk;
                 Sl[(wave * MT + mt) * 64 + lane] = sk;
@@ -404,10 +470,15 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
             bf16x8_t bg[NVW];
 #pragma unroll
             for (int i = 0; i < NVW; ++i) bg[i] = tr_pair(Gs, VROW, min(wave + 4 * i, NVT - 1));
+            // kTwoSweep: the P / dS buffers lie beyond the 64 KB a ds_read's immediate reaches from address 0; left alone hipcc forms one
+            // address register per read (128 of them), hoists them out of the round loop and parks them in AGPRs.  One laundered base each.
+            NAF_LDS const bf16x4_t* plp = (NAF_LDS const bf16x4_t*)(Pl + lane);
+            NAF_LDS const bf16x4_t* slp = (NAF_LDS const bf16x4_t*)(Sl + lane);
+            if constexpr (kTwoSweep) asm volatile("" : "+v"(plp), "+v"(slp));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bf16x4_t p0 = Pl[((2 * pr) * MT + mt) * 64 + lane], p1 = Pl[((2 * pr + 1) * MT + mt) * 64 + lane];
-                const bf16x4_t s0 = Sl[((2 * pr) * MT + mt) * 64 + lane], s1 = Sl[((2 * pr + 1) * MT + mt) * 64 + lane];
+                const bf16x4_t p0 = plp[((2 * pr) * MT + mt) * 64], p1 = plp[((2 * pr + 1) * MT + mt) * 64];
+                const bf16x4_t s0 = slp[((2 * pr) * MT + mt) * 64], s1 = slp[((2 * pr + 1) * MT + mt) * 64];
                 bf16x8_t pa, sa;
                 pa[0] = p0[0]; pa[1] = p0[1]; pa[2] = p0[2]; pa[3] = p0[3];
                 pa[4] = p1[0]; pa[5] = p1[1]; pa[6] = p1[2]; pa[7] = p1[3];
@@ -434,7 +505,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
 
     // ---- the cell's partial sums -> fp32 accumulators.  acc[mt][r] is key mt*16 + grp*4 + r, column col ----
     float* dkb = p.dk + (((int64_t)b * p.h) * p.w * p.heads + head) * 64;
-    float* dvb = p.dv + (((int64_t)b * p.h) * p.w * p.heads + head) * DV;
+    float* dvb = p.dv + (((int64_t)b * p.h) * p.w * p.heads + head) * p.dv_pitch;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -450,7 +521,7 @@ __global__ __launch_bounds__(256, (KS >= 11 ? 1 : 2)) void xna_bwd_kernel(const 
                 atomicAdd(dkb + cell * p.heads * 64 + wave * 16 + col, accK[mt][r]);
 #pragma unroll
                 for (int i = 0; i < NVW; ++i)
-                    if (wave + 4 * i < NVT) atomicAdd(dvb + cell * p.heads * DV + (wave + 4 * i) * 16 + col, accV[mt][i][r]);
+                    if (wave + 4 * i < NVT) atomicAdd(dvb + cell * p.heads * p.dv_pitch + (wave + 4 * i) * 16 + col, accV[mt][i][r]);
             }
         }
 }

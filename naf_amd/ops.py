@@ -542,6 +542,9 @@ def _fill_xna_bwd(q, k, v, dout, dq, dk, dv, ky, kx, scale) -> XnaBwdArgs:
     return a
 
 
+_BWD_PATHS = {"auto": _lib.XNA_AUTO, "mfma": _lib.XNA_MFMA, "rows": _lib.XNA_ROWS, "generic": _lib.XNA_GENERIC}
+
+
 def xna_backward_supported(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> bool:
     """True when ``xna_backward`` runs the MFMA cell kernel for these shapes (otherwise: the table-driven one)."""
     lib = _lib.load()
@@ -574,8 +577,10 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
                  scale: Optional[float] = None, path: str = "auto"):
     """Gradients of ``xna_forward`` w.r.t. q, k_lr, v_lr given ``dout`` (5-D [B, heads, Ho, Wo, Dv], any strides with
     Dv contiguous; cast to bf16).  Returns (dq bf16 [B,heads,Ho,Wo,Dq] view of a channels-last buffer,
-    dk_lr fp32 [B,heads,h,w,Dq] view, dv_lr fp32 [B,heads,h,w,Dv] view).  ``path="generic"`` withholds the workspace of the
-    row-streaming kernel, so that shapes it would serve run the table-driven kernel (A/B and tests)."""
+    dk_lr fp32 [B,heads,h,w,Dq] view, dv_lr fp32 [B,heads,h,w,Dv] view).  ``path`` (naf_xna_bwd_args.path): "auto", or insist on "mfma"
+    (cell kernels), "rows" (row-streaming matrix-core kernel) or "generic" -- the table-driven scalar kernel, which serves EVERY shape and
+    is the independent reference of the parity tests (until 0.4.1 "generic" only withheld the row-streaming kernel's workspace: shapes the
+    cell kernels take ran the cell kernel again, and the tests that compared the two compared it with itself)."""
     for t, n in ((q, "q"), (k_lr, "k_lr"), (v_lr, "v_lr")):
         _gpu(t, n)
         if t.dtype != torch.bfloat16 or t.dim() != 5 or t.stride(4) != 1:
@@ -592,7 +597,10 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
     dq = torch.empty((B, Ho, Wo, heads, Dq), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2, 4)
     dk = torch.zeros((B, h, w, heads, Dq), dtype=torch.float32, device=dev)
     dv = torch.zeros((B, h, w, heads, Dv), dtype=torch.float32, device=dev)
+    if path not in _BWD_PATHS:
+        raise ValueError(f"xna_backward: path must be one of {sorted(_BWD_PATHS)}, got {path!r}")
     a = _fill_xna_bwd(q, k_lr, v_lr, dout, dq, dk, dv, ky, kx, scale)
+    a.path = _BWD_PATHS[path]
     sel = lib.naf_xna_bwd_supported(C.byref(a))
     if sel < 0:
         _lib.check(-sel, "naf_xna_bwd_supported")
@@ -600,9 +608,7 @@ def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: 
         iy = device_index_table(Ho, h, ky, dev)
         ix = device_index_table(Wo, w, kx, dev)
         a.idx_y, a.idx_x = iy.data_ptr(), ix.data_ptr()
-    if path not in ("auto", "generic"):
-        raise ValueError(f"xna_backward: path must be 'auto' or 'generic', got {path!r}")
-    if sel == _lib.XNA_ROWS and path == "auto":    # matrix-core backward of the denoising shapes: per-query softmax statistics live in a workspace
+    if sel == _lib.XNA_ROWS:    # matrix-core backward of the denoising shapes: per-query softmax statistics live in a workspace
         ws = torch.empty(int(lib.naf_xna_bwd_workspace_bytes(C.byref(a))), dtype=torch.uint8, device=dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev), _Timed("xna_bwd"):

@@ -734,7 +734,10 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
     (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
     (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): four-wave kernel, one workgroup per CU
-    (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow)
+    (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow in one launch)
+    (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 128 + 64 (dQ of the second launch adds to the first's)
+    (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 64 + 64, the swept S / dP form
+    (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 64 + 32, one-row cells (three dead waves per round), two images
 ])
 def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
     """naf_xna_bwd vs autograd through the oracle's forward, same bf16-rounded q, k, v and output gradient."""
@@ -781,15 +784,15 @@ def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_
 
 
 def test_cell_backward_fuzz_against_table_driven_kernel(dev):
-    """Seeded random geometries of the MFMA cell backward -- every window 3 .. 13, every Dv, row-tile counts that are not multiples of the
+    """Seeded random geometries of the MFMA cell backward -- every window 3 .. 15, every Dv (13 x 13 and 15 x 15 in channel chunks), row-tile counts that are not multiples of the
     four tiles of a round (dead query waves), one-row cells, several images and heads -- against the independent scalar table-driven
     kernel (fp32 throughout) on the same bf16 inputs.  Windows up to 7 x 7 run the wave-specialised kernel (xna_bwd2_kernel.h: query
     waves / key waves, double round buffers), the others the four-wave kernel."""
     from naf_amd import ops
     rng = np.random.RandomState(9753)
-    done = ragged = small = 0
+    done = ragged = small = chunked = 0
     for _ in range(400):
-        ksz = int(rng.choice([3, 5, 7, 7, 7, 9, 11, 13]))
+        ksz = int(rng.choice([3, 5, 7, 7, 7, 9, 11, 13, 15, 15]))
         h, w = int(rng.randint(ksz, ksz + 6)), int(rng.randint(ksz, ksz + 6))
         dy, dx = int(rng.choice([1, 2, 3, 5, 6, 8, 16])), int(rng.choice([16, 16, 32, 48]))
         Ho, Wo = h * dy, w * dx
@@ -812,9 +815,10 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
         done += 1
         ragged += int((dy * (dx // 16)) % 4 != 0)
         small += int(ksz <= 7)
-        if done >= 60:
+        chunked += int((ksz == 13 and Dv > 128) or (ksz == 15 and Dv > 64))
+        if done >= 70:
             break
-    assert done >= 40 and ragged >= 10 and small >= 20, (done, ragged, small)
+    assert done >= 40 and ragged >= 10 and small >= 20 and chunked >= 5, (done, ragged, small, chunked)
 
 
 @pytest.mark.parametrize("B,heads,lr,d,Dv,ksz", [
