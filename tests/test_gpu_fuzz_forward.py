@@ -9,7 +9,8 @@ Tolerance (floating point): |err| <= 2e-2 + 1e-2*|ref| elementwise an
 profiles/r04_tolerance_budget.txt where the softmax follows single keys: cells of fewer than 3 pixels 3.6e-2, fewer than 1.5 pixels
 6e-2 (+ 1e-2*|ref|).  With cells of fewer than 5 pixels a few elements (<= 5e-4 of them, <= 3 x the bound) may lie outside when two top logits
 are closer than the bf16 stem's error; such a case passes only if BOTH halves hold their own tolerance: the HIP stem against the oracle's
-(mean 8e-3), and the HIP attention against the oracle's attention evaluated on the HIP stem's guidance (1.2e-2 + 1.2e-2*|ref|, every element).
+(mean 8e-3), and the HIP attention against the oracle's attention evaluated on the HIP stem's guidance, operands rounded to bf16 as the matrix cores see
+them (1.2e-2 + 1.2e-2*|ref|, every element).
 
 NAF_FUZZ_CASES (default 20) sets the number of cases, NAF_FUZZ_SEED the first seed; the round's long campaign
 (profiles/r05_fuzz_forward.txt) is this very test with NAF_FUZZ_CASES=400.
@@ -115,8 +116,11 @@ def test_whole_forward_fuzz_against_oracle(dev, seed):
                                 c["heads"])                                 # infinite periods: angles 0, RoPE = identity
         e_stem = (x_hip - x_ref).abs()
         assert float(e_stem.mean()) <= 8e-3 and float(e_stem.max()) <= 2.5e-1, line + "  stem: mean %.3e max %.3e" % (float(e_stem.mean()), float(e_stem.max()))
+        # ... on the operands the matrix cores see: rotated queries, pooled keys and values each rounded to bf16 once (as in every
+        # attention-kernel parity test of tests/test_gpu_parity.py)
+        bf16r = lambda t: t.to(torch.bfloat16).float()
         xr = O.rope(x_hip, p["image_encoder.rope.periods"], c["heads"])
-        ref2 = O.xna(xr, O.key_pool(xr, c["lr"]), ft.float(), c["k"], c["heads"])
+        ref2 = O.xna(bf16r(xr), bf16r(O.key_pool(xr, c["lr"])), bf16r(ft.float()), c["k"], c["heads"])
         e2 = (got - ref2).abs()
         bad2 = e2 > 1.2e-2 + 1.2e-2 * ref2.abs()
         line += "  | %d outside; attention on the HIP stem's guidance: max err %.3e" % (int(bad.sum()), float(e2.max()))
