@@ -733,8 +733,8 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
     (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
     (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
-    (1, 1024, (12, 13), (192, 208), 11),   # 11x11 window, Dv = 256 (BASELINE's G2 width): four-wave kernel, one workgroup per CU
-    (1, 512, (13, 14), (208, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow in one launch)
+    (1, 1024, (12, 13), (96, 208), 11),    # 11x11 window, Dv = 256 (BASELINE's G2 width): four-wave kernel, one workgroup per CU; two rounds per cell
+    (1, 512, (13, 14), (104, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow in one launch); two rounds per cell
     (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 128 + 64 (dQ of the second launch adds to the first's)
     (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 64 + 64, the swept S / dP form
     (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 64 + 32, one-row cells (three dead waves per round), two images
