@@ -3,7 +3,7 @@
 boundary of SURVEY.md section 8b exactly as a caller of the reference uses it (`/root/reference/src/model/naf.py:104-116`,
 `README.md:105-121`), every planner choice reachable from it: cell / sliding / union / rows / generic attention kernels, fused and
 pre-pass keys, pooled guidance (image larger than the output, `naf.py:34`), the bilinear pre-shrink (`naf.py:39-48`), batches,
-bf16 and fp32 features, other model widths and head counts.
+bf16 and fp32 features, other model widths and head counts, `return_weights=True` on a quarter of the cases.
 
 Tolerance (floating point): |err| <= 2e-2 + 1e-2*|ref| elementwise and mean |err| <= 6e-3, with the committed budgets of
 profiles/r04_tolerance_budget.txt where the softmax follows single keys: cells of fewer than 3 pixels 3.6e-2, fewer than 1.5 pixels
@@ -72,7 +72,8 @@ def draw_case(seed):
         C = r.choice([24, 64, 128, 128, 384, 768, 96]) if heads == 4 else r.choice([heads * 3, heads * 32, heads * 64])
         B = r.choice([1, 1, 1, 2, 3])
         return dict(seed=seed, k=k, lr=(h, w), out=(Ho, Wo), img=(H, W), dim=dim, heads=heads, C=C, B=B,
-                    feat_dtype=r.choice([torch.bfloat16, torch.float32]), size_as=r.choice([tuple, list, torch.Size]))
+                    feat_dtype=r.choice([torch.bfloat16, torch.float32]), size_as=r.choice([tuple, list, torch.Size]),
+                    weights=r.random() < 0.25)        # return_weights=True (attentions.py:64-67: the scaled scores, before the softmax)
 
 
 def tolerance(c):
@@ -91,17 +92,26 @@ def test_whole_forward_fuzz_against_oracle(dev, seed):
     img = O.hash_normal((c["B"], 3, *c["img"]), seed * 3 + 1)
     ft = O.hash_normal((c["B"], c["C"], *c["lr"]), seed * 3 + 2).to(c["feat_dtype"])
     with torch.no_grad():
-        got = m(img.to(dev), ft.to(dev), c["size_as"](c["out"]))
+        got = m(img.to(dev), ft.to(dev), c["size_as"](c["out"]), return_weights=c["weights"])
     torch.cuda.synchronize()
+    if c["weights"]:
+        got, scores = got
     assert got.shape == (c["B"], c["C"], *c["out"]), (c, got.shape)
     got = got.float().cpu()
     assert bool(torch.isfinite(got).all()), c
-    ref = O.naf_forward(p, img, ft.float(), c["out"], kernel_size=c["k"], heads_attn=c["heads"], heads_rope=c["heads"])
+    ref = O.naf_forward(p, img, ft.float(), c["out"], kernel_size=c["k"], heads_attn=c["heads"], heads_rope=c["heads"], return_weights=c["weights"])
+    if c["weights"]:
+        # the scores (|ref| up to 40): golden F6's bound -- the bf16 stem moves single scores by up to ~0.1, the mean stays small
+        ref, ref_scores = ref
+        assert scores.shape == ref_scores.shape == (c["B"], c["heads"], *c["out"], c["k"] ** 2), (c, scores.shape)
+        e_s = (scores.float().cpu() - ref_scores).abs()
+        assert float(e_s.mean()) <= 2e-2 and not bool((e_s > 1e-1 + 3e-2 * ref_scores.abs()).any()), \
+            "fuzz %d scores: max err %.3e mean %.3e (|ref| max %.1f)" % (seed, float(e_s.max()), float(e_s.mean()), float(ref_scores.abs().max()))
     err = (got - ref).abs()
     atol = tolerance(c)
     bad = err > atol + 1e-2 * ref.abs()
     line = "fuzz %d: k %d lr %s out %s img %s dim %d heads %d C %d B %d %s  max err %.3e  mean %.3e  tol %.1e" % (
-        seed, c["k"], c["lr"], c["out"], c["img"], c["dim"], c["heads"], c["C"], c["B"], str(c["feat_dtype"])[6:],
+        seed, c["k"], c["lr"], c["out"], c["img"], c["dim"], c["heads"], c["C"], c["B"], str(c["feat_dtype"])[6:] + (" +scores" if c["weights"] else ""),
         float(err.max()), float(err.mean()), atol)
     assert float(err.mean()) <= 6e-3, line
     if bool(bad.any()):
