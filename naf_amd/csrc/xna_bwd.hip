@@ -9,19 +9,26 @@ static bool bwd_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 // Value channels per launch.  A window whose K / V tiles, round buffers or accumulators do not fit at the full Dv is served in CHANNEL CHUNKS:
 // the softmax depends on q and k only, dV splits by channel, and dQ / dK are sums over channels of V -- so the backward for a slice of V
-// (and of dO) is a complete backward, and the slices' dQ / dK add up (XnaBwdParams::dq_accum; dK through the atomics).  13 x 13: chunks of
-// up to 128 channels (Dv 192 = 128 + 64, 256 = 128 + 128); 15 x 15 (BASELINE configs[2]'s largest window): chunks of up to 64 -- 225 keys x
+// (and of dO) is a complete backward, and the slices' dQ / dK add up (XnaBwdParams::dq_accum; dK through the atomics).  11 x 11 and 13 x 13: chunks
+// of up to 128 channels (Dv 192 = 128 + 64, 256 = 128 + 128) -- 11 x 11 fits whole in the four-wave kernel, but the eight-wave kernel, which takes
+// it up to Dv = 128, is more than twice as fast per channel (xna_bwd2_kernel.h); 15 x 15 (BASELINE configs[2]'s largest window): chunks of up to 64 -- 225 keys x
 // (64 + 64) accumulators and the two-sweep S / dP of xna_bwd_kernel.h are what one wave per SIMD holds without scratch.  0 = whole Dv.
-static int bwd_chunk_limit(int ks) { return ks >= 15 ? 64 : ks >= 13 ? 128 : 0; }
-static int bwd_next_chunk(int ks, int left) {
+static int bwd_chunk_limit(int ks) {
+    // NAF_BWD_CHUNK11=0 (with NAF_HIP_KNOBS=1): 11 x 11 whole on the four-wave kernel, as before the chunks (A/B measurements)
+    static const bool whole11 = [] { const char* e = naf_knob("NAF_BWD_CHUNK11"); return e != nullptr && atoi(e) == 0; }();
+    return ks >= 15 ? 64 : ks >= 13 ? 128 : (ks >= 11 && !whole11) ? 128 : 0;
+}
+static int bwd_next_chunk(int ks, int dv, int left) {
     const int lim = bwd_chunk_limit(ks);
-    if (lim == 0 || left <= lim) return left;
-    return lim;
+    if (lim == 0 || dv <= lim) return left;
+    const int n = (dv + lim - 1) / lim;                   // equal chunks where they are multiples of 32 (192 = 96 + 96: the 64-channel
+    if (dv % n == 0 && (dv / n) % 32 == 0) return dv / n; // instantiation of the eight-wave kernel at 11 x 11 carries 3 registers of scratch)
+    return left < lim ? left : lim;
 }
 
 // 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..15, Dq = 64, integer
 // ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0), Dv in {32, 64, 96, 128, 192, 256} and K/V windows + round buffers
-// within 160 KB of LDS (all Dv up to k = 11 in one launch; k = 13 and 15 in channel chunks, above).
+// within 160 KB of LDS (all Dv up to k = 9 in one launch; wider heads at k = 11, 13 and 15 in channel chunks, above).
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->ky != a->kx) return 0;
     const int ks = a->ky;
@@ -34,7 +41,7 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
         case 32: case 64: case 96: case 128: case 192: case 256: break;
         default: return 0;
     }
-    if (xna_bwd_lds_for(ks, bwd_next_chunk(ks, a->Dv)) > 160 * 1024) return 0;
+    if (xna_bwd_lds_for(ks, bwd_next_chunk(ks, a->Dv, a->Dv)) > 160 * 1024) return 0;
     if (!bwd_aligned(a->q) || !bwd_aligned(a->k_lr) || !bwd_aligned(a->v_lr) || !bwd_aligned(a->dout) || !bwd_aligned(a->dq)) return 0;
     for (int i = 0; i < 4; ++i)
         if (a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8 || a->dout_stride[i] % 8 || a->dq_stride[i] % 8) return 0;
@@ -76,7 +83,7 @@ int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     p.dq_accum = 0;
     // channel chunks (one launch where the whole Dv fits): v, dout and dv move to the chunk's first channel of every head
     for (int c0 = 0; c0 < a->Dv;) {
-        const int dvc = bwd_next_chunk(a->ky, a->Dv - c0);
+        const int dvc = bwd_next_chunk(a->ky, a->Dv, a->Dv - c0);
         p.v = static_cast<const bf16_t*>(a->v_lr) + c0;
         p.dout = static_cast<const bf16_t*>(a->dout) + c0;
         p.dv = a->dv_lr + c0;

@@ -63,7 +63,10 @@ struct XnaBwd2Geom {
     static constexpr int v_res_mt = (v_budget / ((DV / 32) * 4)) < G::MT ? (v_budget / ((DV / 32) * 4)) : G::MT;
 };
 
-template <int KS, int DV>
+// CH: a CHANNEL CHUNK of a wider head (xna_bwd.hip: 11 x 11 beyond Dv = 128 runs as chunks of <= 128 on this kernel instead of whole on the four-wave
+// one): dV rows are p.dv_pitch channels apart instead of DV, and launches after the first add their dQ to what is there (p.dq_accum).  A
+// template parameter so that the whole-head instantiations keep their code (their query waves sit at 229-253 of 256 registers).
+template <int KS, int DV, bool CH = false>
 __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) {
     using G = XnaBwdGeom<KS, DV>;
     using G2 = XnaBwd2Geom<KS, DV>;
@@ -405,6 +408,17 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                             a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, dsf[ks], a0, 0, 0, 0);
                             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, dsf[ks], a1, 0, 0, 0);
                         }
+                        if constexpr (CH) {
+                            if (p.dq_accum) {   // a later channel chunk: add what the earlier launches wrote (this lane's d = ct*16 + grp*4 .. +3, and + 16)
+                                const bf16x4_t o0 = *reinterpret_cast<const bf16x4_t*>(dqp + ct * 16 + grp * 4);
+                                const bf16x4_t o1 = *reinterpret_cast<const bf16x4_t*>(dqp + ct * 16 + 16 + grp * 4);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    a0[i] += (float)o0[i];
+                                    a1[i] += (float)o1[i];
+                                }
+                            }
+                        }
                         bf16x4_t ab, bb;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         // The atomics are written as asm in the saddr form -- wave-uniform base, ONE 32-bit lane offset, immediates: from atomicAdd(ptr + index)
         // hipcc forms a 64-bit VGPR address per atomic and hoists the lane-invariant part of every (tile, register) pair's out of the loop
         // (up to 24 pairs x two tensors at 9 x 9: 158 registers spilled at Dv = 256, 16 at Dv = 192).
-        const uint32_t fl_lane = lane_acc * 4u, fl_stepk = rowstep * 256u, fl_stepv = rowstep * (uint32_t)DV * 4u;
+        const uint32_t fl_lane = lane_acc * 4u, fl_stepk = rowstep * 256u, fl_stepv = rowstep * (uint32_t)(CH ? p.dv_pitch : DV) * 4u;
         auto flush_col = [&](float* dkp, float* dvp, int lo) __attribute__((always_inline)) {
             uint32_t la = fl_lane;
             // (the asm atomics read accumulator registers the step's last MFMAs wrote: hipcc's hazard recogniser does not look into asm operands,
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         // the cell the key waves work on at step g >= 1: round k_r of cell k_pos of run k_run, window [k_x0, k_x0 + KS); its run's first key
         int k_run = first, k_pos = 0, k_len = r0.len, k_cx = r0.xs, k_x0 = x0_of(r0.xs), k_r = 0;
         auto dk_of = [&](const Run& c) __attribute__((always_inline)) { return p.dk + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * 64; };
-        auto dv_of = [&](const Run& c) __attribute__((always_inline)) { return p.dv + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * DV; };
+        auto dv_of = [&](const Run& c) __attribute__((always_inline)) { return p.dv + ((((int64_t)c.b * p.h + c.y0) * p.w) * p.heads + c.head) * (CH ? p.dv_pitch : DV); };
         float* dk_run = dk_of(r0);     // key (y0, column 0) of the run, this head
         float* dv_run = dv_of(r0);
 #ifdef NAF_BWD_TIMING
@@ -661,10 +675,10 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     if (k_pos + 1 < k_len) {
                         ++k_pos; ++k_cx;
                         const int nx0 = x0_of(k_cx);
-                        if (nx0 > k_x0) flush_col(dk_run + (int64_t)k_x0 * p.heads * 64, dv_run + (int64_t)k_x0 * p.heads * DV, (k_x0 % KS) * KS);
+                        if (nx0 > k_x0) flush_col(dk_run + (int64_t)k_x0 * p.heads * 64, dv_run + (int64_t)k_x0 * p.heads * (CH ? p.dv_pitch : DV), (k_x0 % KS) * KS);
                         k_x0 = nx0;
                     } else {
-                        for (int x = k_x0; x < k_x0 + KS; ++x) flush_col(dk_run + (int64_t)x * p.heads * 64, dv_run + (int64_t)x * p.heads * DV, (x % KS) * KS);
+                        for (int x = k_x0; x < k_x0 + KS; ++x) flush_col(dk_run + (int64_t)x * p.heads * 64, dv_run + (int64_t)x * p.heads * (CH ? p.dv_pitch : DV), (x % KS) * KS);
                         k_run += nwg;
                         if (k_run < nrun) {
                             const Run c = decode(k_run);
@@ -741,6 +755,12 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
     } else {
         constexpr size_t lds = XnaBwd2Geom<KS, DV>::lds_bytes();
         auto kern = xna_bwd2_kernel<KS, DV>;
+        if constexpr (KS == 11 && DV <= 128) {
+            if (p.dv_pitch != DV) kern = xna_bwd2_kernel<KS, DV, true>;     // a channel chunk of a wider head
+        } else if (p.dv_pitch != DV) {
+            naf_set_error("xna_bwd2: channel chunks are built for 11 x 11 windows only (window %d, chunk %d of %d)", KS, DV, p.dv_pitch);
+            return NAF_ERR_UNSUPPORTED;
+        }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             naf_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));

@@ -733,9 +733,9 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
     (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
     (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
-    (1, 1024, (12, 13), (96, 208), 11),    # 11x11 window, Dv = 256 (BASELINE's G2 width): four-wave kernel, one workgroup per CU; two rounds per cell
+    (1, 1024, (12, 13), (96, 208), 11),    # 11x11 window, Dv = 256 (BASELINE's G2 width): the eight-wave kernel in two channel chunks of 128 (dQ accumulated across the launches)
     (1, 512, (13, 14), (104, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow in one launch); two rounds per cell
-    (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 128 + 64 (dQ of the second launch adds to the first's)
+    (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 96 + 96 (dQ of the second launch adds to the first's)
     (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 64 + 64, the swept S / dP form
     (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 64 + 32, one-row cells (three dead waves per round), two images
 ])
@@ -815,7 +815,7 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
         done += 1
         ragged += int((dy * (dx // 16)) % 4 != 0)
         small += int(ksz <= 7)
-        chunked += int((ksz == 13 and Dv > 128) or (ksz == 15 and Dv > 64))
+        chunked += int((ksz in (11, 13) and Dv > 128) or (ksz == 15 and Dv > 64))
         if done >= 70:
             break
     assert done >= 40 and ragged >= 10 and small >= 20 and chunked >= 5, (done, ragged, small, chunked)
@@ -829,6 +829,8 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     (2, 4, (33, 40), (4, 16), 192, 9),      # 9 x 9 at Dv = 192 (C = 768): 88-slot P / dS rows, columns staged in two passes
     (2, 4, (35, 37), (2, 32), 256, 9),      # 9 x 9 at Dv = 256 (C = 1024): one P / dS buffer (two barriers per round) AND one window buffer
     (2, 4, (33, 35), (4, 16), 128, 11),     # 11 x 11 at Dv = 128: the widest the eight-wave kernel takes at that window
+    (2, 4, (34, 33), (2, 16), 256, 11),     # 11 x 11 at Dv = 256 (BASELINE's G2 width): two channel chunks of 128 on the eight-wave kernel
+    (2, 4, (33, 34), (2, 16), 192, 11),     # 11 x 11 at Dv = 192: chunks 96 + 96
 ])
 def test_cell_backward_walks_several_runs_per_workgroup(dev, B, heads, lr, d, Dv, ksz):
     """The wave-specialised backward launches one resident workgroup per CU and lets it walk runs of cells (xna_bwd2_kernel.h); every other
