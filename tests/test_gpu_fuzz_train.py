@@ -8,6 +8,8 @@ Tolerances (floating point): output as the forward fuzz (SURVEY 8c, 3.6e-2 / 6e-
 largest reference entry of the tensor: 5e-2 for encoder parameters, 3e-2 for the features (as tests/test_gpu_parity.py::
 test_forward_train_gradients_match_oracle: P and dS pass through bf16 before contractions over up to d^2 k^2 pairs).
 
+Every case then repeats the step on the library's own differentiable stem (amp="hip") against the fp32 torch-stem path.
+
 NAF_FUZZ_TRAIN_CASES (default 8) / NAF_FUZZ_TRAIN_SEED select the cases; profiles/r05_fuzz_train.txt is this test with 120 cases.
 """
 import os
@@ -98,3 +100,21 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     bad = e_out > atol + 1e-2 * ref_out.detach().abs()
     assert int(bad.sum()) <= (0 if cell >= 5.0 else 5e-4 * bad.numel() + 1) and float(e_out.max()) <= 3 * atol, line
     assert rel_f <= 3e-2 + 1e-3 / gs and worst <= 5e-2, line
+    # The same step on the library's own differentiable stem (amp="hip": fused forward kernels with bf16 activations kept per layer, HIP
+    # data-gradient / GroupNorm + SiLU backward / weight-gradient kernels, RoPE + pooling backward): against the fp32 torch-stem path above,
+    # relative L2 per tensor as tests/test_gpu_train_stem.py::test_model_gradients_match_torch_stem (bf16-activation accuracy).
+    g32 = {n: prm.grad.detach().clone() for n, prm in m.named_parameters() if prm.grad is not None}
+    f32 = fd.grad.detach().clone()
+    m.zero_grad(set_to_none=True)
+    fd2 = ft.to(dev).requires_grad_(True)
+    out_h = m.forward_train(img.to(dev), fd2, c["out"], amp="hip")
+    (out_h.float() * wgt.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    gh = {n: prm.grad for n, prm in m.named_parameters() if prm.grad is not None}
+    assert set(gh) == set(g32), line
+    worst_h = max((rel(gh[n], g32[n]), n) for n in g32)
+    line_h = "   amp=hip vs fp32 stem: out rel %.3e  feature grad rel %.3e  worst param grad rel %.3e (%s)" % (
+        rel(out_h.detach().float(), out.detach().float()), rel(fd2.grad, f32), worst_h[0], worst_h[1])
+    print(line_h)
+    assert rel(out_h.detach().float(), out.detach().float()) < 2e-2 and rel(fd2.grad, f32) < 2e-2 and worst_h[0] < 6e-2, line + line_h

@@ -14,7 +14,7 @@ def timed(fn, n=int(os.environ.get("BWD_BENCH_N", "10"))):
 
 dev = torch.device("cuda:0")
 heads, Dq = 4, 64
-for name, C, lr, out, ks in (("G1", 768, 64, 1024, 7), ("G2-k7", 1024, 32, 512, 7), ("G3 (1 image)", 1024, 64, 1024, 7), ("k9 C384", 384, 64, 1024, 9), ("k9 C768", 768, 64, 1024, 9), ("448^2 C768 k9", 768, 28, 448, 9), ("k9 C1024", 1024, 64, 1024, 9), ("448^2 C1024 k9", 1024, 28, 448, 9), ("448^2 C384 k9", 384, 28, 448, 9)):
+for name, C, lr, out, ks in (("G1", 768, 64, 1024, 7), ("G2-k7", 1024, 32, 512, 7), ("G2-k11", 1024, 32, 512, 11), ("G2-k15", 1024, 32, 512, 15), ("512^2 C1024 k13", 1024, 32, 512, 13), ("G3 (1 image)", 1024, 64, 1024, 7), ("k9 C384", 384, 64, 1024, 9), ("k9 C768", 768, 64, 1024, 9), ("448^2 C768 k9", 768, 28, 448, 9), ("k9 C1024", 1024, 64, 1024, 9), ("448^2 C1024 k9", 1024, 28, 448, 9), ("448^2 C384 k9", 384, 28, 448, 9)):
     q = torch.randn(1, heads, out, out, Dq, device=dev).to(torch.bfloat16)
     k = torch.randn(1, heads, lr, lr, Dq, device=dev).to(torch.bfloat16)
     v = torch.randn(1, lr, lr, heads, C // heads, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2, 4)
