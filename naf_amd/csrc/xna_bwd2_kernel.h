@@ -58,7 +58,7 @@ struct XnaBwd2Geom {
 #define NAF_BWD2_VREGS 96
 #endif
     // (9 x 9 at Dv = 192: six key tiles of sT / gT and the K fragments streamed beside them -- three resident V tiles, 96 spilled 18 registers)
-    static constexpr int v_budget = (KS == 9 && DV >= 256) ? 0
+    static constexpr int v_budget = (KS >= 15) ? 0 : (KS == 13) ? (NAF_BWD2_VREGS < 64 ? NAF_BWD2_VREGS : 64) : (KS == 9 && DV >= 256) ? 0
                                   : (KS == 9 && DV >= 192) ? (NAF_BWD2_VREGS < 72 ? NAF_BWD2_VREGS : 72) : NAF_BWD2_VREGS;
     static constexpr int v_res_mt = (v_budget / ((DV / 32) * 4)) < G::MT ? (v_budget / ((DV / 32) * 4)) : G::MT;
 };
@@ -745,7 +745,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 // spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    return KS <= 11 && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
+    // 13 x 13 / 15 x 15: channel chunks of 64 / 32 only (xna_bwd.hip) -- twelve / sixteen key tiles of S^T / dP^T leave the query waves no room for more
+    return (KS <= 11 || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 32)) && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
 }
 
 template <int KS, int DV>
@@ -755,10 +756,10 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
     } else {
         constexpr size_t lds = XnaBwd2Geom<KS, DV>::lds_bytes();
         auto kern = xna_bwd2_kernel<KS, DV>;
-        if constexpr (KS == 11 && DV <= 128) {
+        if constexpr ((KS == 11 && DV <= 128) || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 32)) {
             if (p.dv_pitch != DV) kern = xna_bwd2_kernel<KS, DV, true>;     // a channel chunk of a wider head
         } else if (p.dv_pitch != DV) {
-            naf_set_error("xna_bwd2: channel chunks are built for 11 x 11 windows only (window %d, chunk %d of %d)", KS, DV, p.dv_pitch);
+            naf_set_error("xna_bwd2: no channel-chunk instantiation for window %d, chunk %d of %d", KS, DV, p.dv_pitch);
             return NAF_ERR_UNSUPPORTED;
         }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

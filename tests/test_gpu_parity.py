@@ -734,10 +734,10 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
     (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
     (1, 1024, (12, 13), (96, 208), 11),    # 11x11 window, Dv = 256 (BASELINE's G2 width): the eight-wave kernel in two channel chunks of 128 (dQ accumulated across the launches)
-    (1, 512, (13, 14), (104, 224), 13),    # 13x13, Dv = 128 (the widest its LDS windows allow in one launch); two rounds per cell
-    (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 96 + 96 (dQ of the second launch adds to the first's)
-    (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 64 + 64, the swept S / dP form
-    (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 64 + 32, one-row cells (three dead waves per round), two images
+    (1, 512, (13, 14), (104, 224), 13),    # 13x13, Dv = 128: chunks 64 + 64; two rounds per cell
+    (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 64 x 3 on the eight-wave kernel (dQ of the later launches adds to the first's)
+    (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 32 x 4 on the eight-wave kernel
+    (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 32 x 3, one-row cells (three dead waves per round), two images
 ])
 def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
     """naf_xna_bwd vs autograd through the oracle's forward, same bf16-rounded q, k, v and output gradient."""
@@ -831,6 +831,8 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     (2, 4, (33, 35), (4, 16), 128, 11),     # 11 x 11 at Dv = 128: the widest the eight-wave kernel takes at that window
     (2, 4, (34, 33), (2, 16), 256, 11),     # 11 x 11 at Dv = 256 (BASELINE's G2 width): two channel chunks of 128 on the eight-wave kernel
     (2, 4, (33, 34), (2, 16), 192, 11),     # 11 x 11 at Dv = 192: chunks 96 + 96
+    (2, 4, (33, 35), (2, 16), 128, 13),     # 13 x 13: chunks 64 + 64 on the eight-wave kernel (twelve key tiles, 8 of 12 V tiles resident)
+    (2, 4, (34, 33), (1, 16), 96, 15),      # 15 x 15 (BASELINE configs[2]'s largest window): chunks 32 x 3, sixteen key tiles, one-row cells
 ])
 def test_cell_backward_walks_several_runs_per_workgroup(dev, B, heads, lr, d, Dv, ksz):
     """The wave-specialised backward launches one resident workgroup per CU and lets it walk runs of cells (xna_bwd2_kernel.h); every other
