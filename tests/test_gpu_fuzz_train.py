@@ -95,7 +95,7 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     gs = float(fo.grad.abs().max())
     rel_f = float((fd.grad.float().cpu() - fo.grad).abs().max()) / gs
     line = "train fuzz %d: k %d lr %s out %s C %d B %d  backward kernel %-7s  out max err %.3e  feature grad %.3e  worst param grad %.3e (%s)" % (
-        seed, c["k"], c["lr"], c["out"], c["C"], c["B"], kern, float(e_out.max()), rel_f, worst, worst_name)
+        seed, c["k"], c["lr"], c["out"], c["C"], c["B"], kern, float(e_out.detach().max()), rel_f, worst, worst_name)
     print(line)
     bad = e_out > atol + 1e-2 * ref_out.detach().abs()
     assert int(bad.sum()) <= (0 if cell >= 5.0 else 5e-4 * bad.numel() + 1) and float(e_out.max()) <= 3 * atol, line
