@@ -12,7 +12,7 @@ are closer than the bf16 stem's error; such a case passes only if BOTH halves ho
 (mean 8e-3), and the HIP attention against the oracle's attention evaluated on the HIP stem's guidance, operands rounded to bf16 as the matrix cores see
 them (1.2e-2 + 1.2e-2*|ref|, every element).
 
-NAF_FUZZ_CASES (default 20) sets the number of cases, NAF_FUZZ_SEED the first seed; the round's long campaign
+NAF_FUZZ_CASES (default 20) sets the number of cases, NAF_FUZZ_SEED the first seed, NAF_FUZZ_MAX_PIXELS / NAF_FUZZ_MAX_LR the size caps; the round's long campaign
 (profiles/r05_fuzz_forward.txt) is this very test with NAF_FUZZ_CASES=400.
 """
 import os
@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 
 N_CASES = int(os.environ.get("NAF_FUZZ_CASES", "20"))
 SEED0 = int(os.environ.get("NAF_FUZZ_SEED", "5000"))
-MAX_PIXELS = 176 * 176          # the oracle's attention is a Python loop over window taps on full-resolution tensors
+MAX_PIXELS = int(os.environ.get("NAF_FUZZ_MAX_PIXELS", str(176 * 176)))   # the oracle's attention is a Python loop over window taps on full-resolution tensors
+MAX_LR = int(os.environ.get("NAF_FUZZ_MAX_LR", "18"))                       # largest feature-grid side (campaigns raise both)
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +45,7 @@ def draw_case(seed):
     r = random.Random(seed)
     while True:
         k = r.choice([3, 5, 7, 7, 9, 9, 11, 15])
-        h, w = r.randint(k, max(k, 18)), r.randint(k, max(k, 18))
+        h, w = r.randint(k, max(k, MAX_LR)), r.randint(k, max(k, MAX_LR))
         mode = r.random()
         if mode < 0.45:                                   # integer ratio (cell / sliding kernels, fused keys on 16 x 16 cells)
             dy = r.choice([2, 4, 7, 8, 14, 16, 16, 16])
