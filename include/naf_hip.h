@@ -425,7 +425,7 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 15, Wo/w a
  * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 at every Dv and 11 x 11 up to Dv = 128 on
  * the wave-specialised eight-wave kernel, wider heads at 11 x 11 and every head at 13 x 13 / 15 x 15 on the same kernel in
- * CHANNEL CHUNKS of at most 128 / 64 / 32 value channels per launch -- the softmax does not depend on V, dV splits by channel and dQ / dK are
+ * CHANNEL CHUNKS of at most 128 / 64 / 64 value channels per launch -- the softmax does not depend on V, dV splits by channel and dQ / dK are
  * sums over channels, so each launch is a complete backward for its slice and later launches add their dQ to the earlier ones'), the
  * row-streaming matrix-core kernel below, and a table-driven one for everything else (any ratio,
  * head dims, rectangular windows; one wave per query, atomics per key).  naf_xna_bwd_supported returns which

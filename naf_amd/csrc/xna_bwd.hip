@@ -11,16 +11,18 @@ static bool bwd_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 // the softmax depends on q and k only, dV splits by channel, and dQ / dK are sums over channels of V -- so the backward for a slice of V
 // (and of dO) is a complete backward, and the slices' dQ / dK add up (XnaBwdParams::dq_accum; dK through the atomics).  The chunk is what the EIGHT-wave
 // kernel (xna_bwd2_kernel.h, more than twice as fast per channel as the four-wave one) takes at the window: 11 x 11 up to 128 channels (Dv 192 = 96 + 96,
-// 256 = 128 + 128; the four-wave kernel would fit the whole head), 13 x 13 up to 64, 15 x 15 (BASELINE configs[2]'s largest window) up to 32 -- twelve / sixteen
-// key tiles of S^T / dP^T leave its query waves no room for more.  The four-wave kernel's chunks (NAF_BWD_BIG8=0): 128 / 64, 15 x 15 in the swept S / dP
+// 256 = 128 + 128; the four-wave kernel would fit the whole head), 13 x 13 and 15 x 15 (BASELINE configs[2]'s largest window) up to 64 -- twelve / sixteen
+// key tiles of S^T / dP^T leave its query waves no room for more, and at 15 x 15 the LDS is full (163.1 of 163.8 KB).  The four-wave kernel's chunks (NAF_BWD_BIG8=0): 128 / 64, 15 x 15 in the swept S / dP
 // form of xna_bwd_kernel.h.  0 = whole Dv.
 static int bwd_chunk_limit(int ks) {
     // NAF_BWD_CHUNK11=0 (with NAF_HIP_KNOBS=1): 11 x 11 whole on the four-wave kernel, as before the chunks (A/B measurements)
     static const bool whole11 = [] { const char* e = naf_knob("NAF_BWD_CHUNK11"); return e != nullptr && atoi(e) == 0; }();
-    // 13 x 13 / 15 x 15: chunks of 64 / 32 on the eight-wave kernel (NAF_BWD_BIG8=0 with NAF_HIP_KNOBS=1: 128 / 64 on the four-wave one, the first form --
+    // 13 x 13 / 15 x 15: chunks of 64 on the eight-wave kernel (NAF_BWD_BIG8=0 with NAF_HIP_KNOBS=1: 128 / 64 on the four-wave one, the first form --
     // 11-33 % slower, profiles/r05_bwd_large_windows.txt)
     static const bool big8 = [] { const char* e = naf_knob("NAF_BWD_BIG8"); return !(e != nullptr && atoi(e) == 0); }();
-    return ks >= 15 ? (big8 ? 32 : 64) : ks >= 13 ? (big8 ? 64 : 128) : (ks >= 11 && !whole11) ? 128 : 0;
+    // NAF_BWD_K15_C32=1: 15 x 15 in chunks of 32 on the eight-wave kernel, the form before its P / dS rows were cut to 240 slots (A/B)
+    static const bool k15c32 = [] { const char* e = naf_knob("NAF_BWD_K15_C32"); return e != nullptr && atoi(e) != 0; }();
+    return ks >= 15 ? (big8 && k15c32 ? 32 : 64) : ks >= 13 ? (big8 ? 64 : 128) : (ks >= 11 && !whole11) ? 128 : 0;
 }
 static int bwd_next_chunk(int ks, int dv, int left) {
     const int lim = bwd_chunk_limit(ks);

@@ -36,7 +36,9 @@ struct XnaBwd2Geom {
     // bf16 per row of the P / dS matrices [query][slot].  9 x 9: the sixth key tile holds ONE real slot (80), so a row keeps 88 slots and the
     // tile's transposed reads of columns 88 .. 95 run into the next row (finite or not, that data only reaches the accumulators of pad slots,
     // which are never added to memory; the query waves do not write those columns) -- 8 KB less, which is what lets Dv = 192 (C = 768) fit
-    static constexpr int PROW = (KS == 9) ? 88 : G::KPAD + 8;
+    // 15 x 15: 225 slots, so the sixteenth key tile (240 .. 255) holds none and a row keeps 240 -- the same argument; 6 KB less, which is what lets a chunk of
+    // 64 value channels fit (163.1 of 163.8 KB with one P / dS and one window buffer)
+    static constexpr int PROW = (KS == 9) ? 88 : (KS == 15) ? 240 : G::KPAD + 8;
     static constexpr size_t ps_elems = (size_t)4 * 16 * PROW;                   // bf16 per P (or dS) buffer of a round
     static constexpr size_t qg_elems = (size_t)4 * 16 * (G::KROW + G::VROW);    // bf16 per Q + dO buffer of a round
     // Round buffers: Q / dO always double; P / dS double where the LDS has room, SINGLE otherwise (9 x 9 at Dv = 256, C = 1024 at the reference's
@@ -745,8 +747,8 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 // spilled 50) the last key tile's come from the LDS in every round (v_res_mt): 253 registers, no scratch.
 template <int KS, int DV>
 constexpr bool xna_bwd2_serves() {
-    // 13 x 13 / 15 x 15: channel chunks of 64 / 32 only (xna_bwd.hip) -- twelve / sixteen key tiles of S^T / dP^T leave the query waves no room for more
-    return (KS <= 11 || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 32)) && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
+    // 13 x 13 / 15 x 15: channel chunks of at most 64 (xna_bwd.hip) -- twelve / sixteen key tiles of S^T / dP^T leave the query waves no room for more
+    return (KS <= 11 || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 64)) && XnaBwd2Geom<KS, DV>::lds_bytes() <= 160 * 1024;
 }
 
 template <int KS, int DV>
@@ -756,7 +758,7 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
     } else {
         constexpr size_t lds = XnaBwd2Geom<KS, DV>::lds_bytes();
         auto kern = xna_bwd2_kernel<KS, DV>;
-        if constexpr ((KS == 11 && DV <= 128) || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 32)) {
+        if constexpr ((KS == 11 && DV <= 128) || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 64)) {
             if (p.dv_pitch != DV) kern = xna_bwd2_kernel<KS, DV, true>;     // a channel chunk of a wider head
         } else if (p.dv_pitch != DV) {
             naf_set_error("xna_bwd2: no channel-chunk instantiation for window %d, chunk %d of %d", KS, DV, p.dv_pitch);

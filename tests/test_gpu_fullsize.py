@@ -493,7 +493,7 @@ def test_attention_G3_whole_batch_of_64_in_one_launch(dev):
     ("G1", 768, 64, 1024, 7),          # xna_bwd2_kernel<7, 192>: 256 runs of 64 cells, one per CU
     ("G2-k7", 1024, 32, 512, 7),       # xna_bwd2_kernel<7, 256>: one window buffer, a V key tile from the LDS per round
     ("G2-k11", 1024, 32, 512, 11),     # the eight-wave kernel in two channel chunks of 128
-    ("G2-k15", 1024, 32, 512, 15),     # eight channel chunks of 32 on the eight-wave kernel (dQ accumulated across launches)
+    ("G2-k15", 1024, 32, 512, 15),     # four channel chunks of 64 on the eight-wave kernel (dQ accumulated across launches)
 ])
 def test_attention_backward_at_benched_sizes_against_the_scalar_kernel(dev, name, C, lr, out, ksz):
     """The attention backward at BASELINE's sizes (the oracle's autograd would take minutes there): the matrix-core cell kernels against the
