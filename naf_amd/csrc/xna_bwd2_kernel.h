@@ -74,6 +74,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     using G2 = XnaBwd2Geom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
     constexpr int DKS = DV / 32, PROW = G2::PROW;
+    // key tiles that hold a key: 13 x 13 (169 slots) and 15 x 15 (225) leave the LAST tile of their 192 / 256 padded slots empty -- its S / dP MFMAs,
+    // its K / V fragment reads and its dK / dV accumulators are skipped (P and dS of its slots stay 0: sT = -inf below the mask, gT = 0)
+    constexpr int MTR = KS >= 13 ? (NSLOT + 15) / 16 : MT;
     constexpr bool KV2 = G2::kv_bufs == 2, KRES = G2::k_resident, PS2 = G2::ps_bufs == 2;
     constexpr bool KTILE = !KRES && ((KS == 9 && DV >= 256) || KS >= 11);   // K fragments one key tile at a time (elsewhere: all of the window's at the top of a round, or resident)
     constexpr int VRES = G2::v_res_mt;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 return Ks + r * KROW + (col & 3) * 4;
             };
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTR; ++mt) {
                 const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
                 const bf16_t* vr = Vs + krow(mt) * VROW + grp * 8;
                 if constexpr (KRES) {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 
                 if constexpr (!KRES && !KTILE) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
+                    for (int mt = 0; mt < MTR; ++mt) {
                         const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) kfr[mt][ks] = *reinterpret_cast<const bf16x8_t*>(kr + ks * 32);
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     sT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (mt >= MTR) continue;
                     if constexpr (KTILE) {     // the widest shape: a key tile's two K fragments, then its MFMAs
                         const bf16_t* kr = Ks + krow(mt) * KROW + grp * 8;
 #pragma unroll
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     gT[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (mt >= MTR) continue;
                     if (mt < VRES) {
 #pragma unroll
                         for (int ks = 0; ks < DKS; ++ks) gT[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[mt][ks], gf[ks], gT[mt], 0, 0, 0);
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
             // this costs 32 idle issue slots per column and removes the assumption)
             asm volatile("s_nop 15\n\ts_nop 15\n" : "+v"(la));      // ... and a lane constant the loop keeps in ONE register
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int d = mt * 16 + rr - lo;         // slot of lane group 0, relative to the column's first
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                         else bg[i] = tr2(ag + (uint32_t)(pr * 32 * VROW * 2) + (uint32_t)(min(wb + 4 * i, NVT - 1) - wb) * 32u, VROW);
                     }
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
+                    for (int mt = 0; mt < MTR; ++mt) {
                         // A operands: slot mt*16 + col, queries 4*grp..+3 of the two tiles -- the transposed read of [query][slot]
                         const bf16x8_t pa = tr2(ap + (uint32_t)(pr * 32 * PROW * 2 + mt * 32), PROW);
                         const bf16x8_t sa = tr2(ap + (uint32_t)(G2::ps_elems * 2 + pr * 32 * PROW * 2 + mt * 32), PROW);
