@@ -725,12 +725,12 @@ def test_rotate_on_load_refused_when_tiles_straddle_rows(dev):
     (1, 256, (8, 8), (128, 128), 7),       # Dv = 64, d = 16: four row tiles per wave round, full rounds
     (2, 128, (5, 6), (40, 96), 3),         # Dv = 32, d = (8, 16): 8 tiles per cell, non-square grid
     (1, 768, (7, 7), (7, 112), 7),         # Dv = 192, dy = 1: one tile per cell (three dead waves per round), k = h = w
-    (1, 384, (10, 9), (160, 288), 9),      # Dv = 96, 9x9 window (pad slots), dx = 32
+    (1, 384, (10, 9), (80, 288), 9),       # Dv = 96, 9x9 window (pad slots), dx = 32
     (1, 512, (10, 11), (160, 176), 9),     # Dv = 128, 9x9: eight-wave kernel with ONE window buffer and K fragments from the LDS
     (1, 768, (10, 12), (80, 192), 9),      # Dv = 192, 9x9 (ViT-B features at the reference's default window): 88-slot P / dS rows, three resident V key tiles
     (1, 1024, (10, 11), (80, 176), 9),     # Dv = 256, 9x9 (DINOv3-L features at the reference's default window): ONE P / dS buffer, two barriers per round, no resident V tile
-    (2, 768, (9, 12), (144, 192), 7),      # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
-    (2, 1024, (9, 10), (144, 160), 7),     # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
+    (2, 768, (9, 12), (72, 192), 7),       # Dv = 192, 7x7, two images: runs of cells across images and heads (G1's instantiation)
+    (2, 1024, (9, 10), (72, 160), 7),      # Dv = 256 at 7x7 (BASELINE's G2 / G3 width): eight-wave kernel, one V key tile from the LDS per round, columns staged in two passes
     (1, 384, (12, 14), (96, 224), 11),     # 11x11 at Dv = 96: the eight-wave kernel (eight key tiles, K fragments one tile at a time)
     (1, 512, (13, 12), (52, 192), 11),     # 11x11 at Dv = 128: ... with ONE P / dS buffer
     (1, 1024, (12, 13), (96, 208), 11),    # 11x11 window, Dv = 256 (BASELINE's G2 width): the eight-wave kernel in two channel chunks of 128 (dQ accumulated across the launches)
