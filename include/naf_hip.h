@@ -467,6 +467,10 @@ typedef struct naf_xna_bwd_args {
  * (0.3.x: stale LDS rows of the wave's previous tile, anywhere in the image) can reach the products. */
 int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
+/* 0.4.1: the launches of the NAF_XNA_MFMA backward for these arguments -- the widths of the channel chunks in launch order, at most `cap` of them written
+ * to out (out may be NULL with cap 0).  Returns their number: 1 = the whole head in one launch, 0 = another kernel serves the call
+ * (naf_xna_bwd_supported), negative naf_status on invalid arguments.  A pure host-side query (no device call); pointers are only checked, not read. */
+int naf_xna_bwd_chunk_plan(const naf_xna_bwd_args* a, int32_t* out, int cap);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 
 /* ---- whole forward in one call ----------------------------------------------------------------------

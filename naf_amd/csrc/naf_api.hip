@@ -380,6 +380,18 @@ int naf_xna_bwd_supported(const naf_xna_bwd_args* a) {
     return xna_bwd_pick(a);
 }
 
+int naf_xna_bwd_chunk_plan(const naf_xna_bwd_args* a, int32_t* out, int cap) {
+    const int rc = xna_bwd_validate(a);
+    if (rc != NAF_OK) return -rc;
+    if (cap < 0 || (out == nullptr && cap != 0)) {
+        naf_set_error("naf_xna_bwd_chunk_plan: out is NULL with cap %d", cap);
+        return -NAF_ERR_INVALID;
+    }
+    const int sel = xna_bwd_pick(a);
+    if (sel < 0) return sel;
+    return sel == NAF_XNA_MFMA ? naf_xna_bwd_chunks(a, out, cap) : 0;
+}
+
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a) {
     if (a == nullptr || xna_bwd_validate(a) != NAF_OK || xna_bwd_pick(a) != NAF_XNA_ROWS) return 0;
     return naf_xna_rows_bwd_workspace(a);

@@ -42,6 +42,7 @@ int naf_xna_rows_eligible(const naf_xna_args* a);                               
 int naf_tile_span(int L_out, int L_in, int k);                                   // xna_rows.hip: low-res columns under 16 consecutive queries
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);   // xna_bwd.hip
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a);                             // xna_bwd.hip
+int naf_xna_bwd_chunks(const naf_xna_bwd_args* a, int32_t* out, int cap);            // xna_bwd.hip
 int naf_launch_xna_generic_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);  // xna_generic.hip
 int naf_launch_xna_rows_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s);     // xna_rows_bwd.hip
 int naf_xna_rows_bwd_eligible(const naf_xna_bwd_args* a);                               // xna_rows_bwd.hip

@@ -54,6 +54,18 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     return 1;
 }
 
+// The launches naf_launch_xna_bwd issues for these arguments: chunk widths in launch order (include/naf_hip.h: naf_xna_bwd_chunk_plan)
+int naf_xna_bwd_chunks(const naf_xna_bwd_args* a, int32_t* out, int cap) {
+    if (!naf_xna_bwd_eligible(a)) return 0;
+    int n = 0;
+    for (int c0 = 0; c0 < a->Dv; ++n) {
+        const int dvc = bwd_next_chunk(a->ky, a->Dv, a->Dv - c0);
+        if (out != nullptr && n < cap) out[n] = dvc;
+        c0 += dvc;
+    }
+    return n;
+}
+
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     if (!naf_xna_bwd_eligible(a)) {
         naf_set_error(

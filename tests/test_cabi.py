@@ -279,6 +279,59 @@ def test_xna_auto_policy(built_lib):
     assert sel(28, 28, 64, 64, 384, 9, path=_lib.XNA_MFMA) == -2     # NAF_ERR_UNSUPPORTED
 
 
+def _xna_bwd_args(h, w, Ho, Wo, Cc, k, heads=4, B=1, Dq=64, path=0):
+    from naf_amd._lib import XnaBwdArgs, I64x4
+    a = XnaBwdArgs()
+    Dv = Cc // heads
+    a.q = a.k_lr = a.v_lr = a.dout = a.dq = a.dk_lr = a.dv_lr = 0x1000      # host logic only: never dereferenced
+    a.B, a.heads, a.Ho, a.Wo, a.h, a.w, a.Dq, a.Dv, a.ky, a.kx = B, heads, Ho, Wo, h, w, Dq, Dv, k, k
+    a.scale, a.path = 0.0, path
+    a.q_stride = a.dq_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
+    a.k_stride = I64x4(h * w * heads * Dq, Dq, w * heads * Dq, heads * Dq)
+    a.v_stride = I64x4(h * w * heads * Dv, Dv, w * heads * Dv, heads * Dv)
+    a.dout_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    return a
+
+
+def test_xna_backward_policy_and_chunk_plan(built_lib):
+    """Host logic of naf_xna_bwd (no device call): which kernel AUTO picks, what naf_xna_bwd_args.path (0.4.1) insists on, and the channel
+    chunks the cell kernels run wide heads in at the large windows -- every chunk a width the kernels are instantiated for, the chunks adding
+    up to Dv, one launch up to 9 x 9 (/root/reference/train.py:127-137 is what the call replaces)."""
+    from naf_amd import _lib
+    lib = _lib.load()
+    sel = lambda *g, **kw: lib.naf_xna_bwd_supported(C.byref(_xna_bwd_args(*g, **kw)))
+
+    def plan(*g, **kw):
+        out = (C.c_int32 * 8)()
+        n = lib.naf_xna_bwd_chunk_plan(C.byref(_xna_bwd_args(*g, **kw)), out, 8)
+        return list(out[:n]) if n >= 0 else n
+
+    assert sel(64, 64, 1024, 1024, 768, 7) == _lib.XNA_MFMA                  # G1
+    assert sel(32, 32, 512, 512, 1024, 15) == _lib.XNA_MFMA                  # G2's largest window (round 5: channel chunks)
+    assert sel(16, 16, 32, 32, 768, 9) == _lib.XNA_ROWS                      # the reference's own training geometry (ratio 2)
+    assert sel(28, 28, 392, 392, 384, 9) == _lib.XNA_ROWS                    # patch-14 backbone: no 16-pixel row tiles
+    assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=80) == _lib.XNA_GENERIC     # head dim without a matrix-core instantiation
+    assert sel(64, 64, 1024, 1024, 768, 7, path=_lib.XNA_GENERIC) == _lib.XNA_GENERIC   # the tests' independent reference, any shape
+    assert sel(64, 64, 1024, 1024, 768, 7, path=_lib.XNA_ROWS) == _lib.XNA_ROWS
+    assert sel(16, 16, 32, 32, 768, 9, path=_lib.XNA_MFMA) == -2             # NAF_ERR_UNSUPPORTED: insisting on a kernel that does not apply
+    assert sel(64, 64, 1024, 1024, 768, 7, path=3) == -1                     # NAF_XNA_UNION is a forward path: NAF_ERR_INVALID
+    for k in (3, 5, 7, 9):
+        for C_ in (128, 256, 384, 512, 768, 1024):
+            assert plan(2 * k, 2 * k, 32 * k, 32 * k, C_, k) == [C_ // 4]    # the whole head in one launch
+    widths = {11: 128, 13: 64, 15: 64}
+    for k, lim in widths.items():
+        for C_ in (128, 256, 384, 512, 768, 1024):
+            Dv = C_ // 4
+            got = plan(2 * k, 2 * k, 32 * k, 32 * k, C_, k)
+            assert sum(got) == Dv and all(c in (32, 64, 96, 128) and c <= lim for c in got), (k, Dv, got)
+            assert len(got) == -(-Dv // lim), (k, Dv, got)                   # as few launches as the chunk limit allows
+    assert plan(32, 32, 512, 512, 1024, 15) == [64, 64, 64, 64] and plan(32, 32, 512, 512, 1024, 11) == [128, 128]
+    assert plan(32, 32, 512, 512, 768, 11) == [96, 96] and plan(32, 32, 512, 512, 384, 15) == [64, 32]
+    assert plan(16, 16, 32, 32, 768, 9) == []                                # another kernel serves the call
+    assert lib.naf_xna_bwd_chunk_plan(C.byref(_xna_bwd_args(32, 32, 512, 512, 1024, 15)), None, 0) == 4
+    assert lib.naf_xna_bwd_chunk_plan(C.byref(_xna_bwd_args(32, 32, 512, 512, 1024, 15)), None, 4) == -1
+
+
 def test_module_mirrors_reference_interface():
     from naf_amd import NAF
     m = NAF()
