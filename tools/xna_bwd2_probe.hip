@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     p.nblocks = (uint32_t)(lr * heads * p.nseg);
     const unsigned grid = p.nblocks < 256u ? p.nblocks : 256u;
     p.scale = 0.125f; p.scale_log2e = 0.125f * 1.4426950408889634f;
+    p.dv_pitch = DV; p.dq_accum = 0;   // the whole head in one launch (xna_bwd.hip splits wide heads into channel chunks)
     const int64_t qs[4] = {(int64_t)nq, 64, (int64_t)out * heads * 64, (int64_t)heads * 64};
     const int64_t gs[4] = {(int64_t)ng, DV, (int64_t)out * heads * DV, (int64_t)heads * DV};
     const int64_t ks[4] = {(int64_t)nk, 64, (int64_t)lr * heads * 64, (int64_t)heads * 64};

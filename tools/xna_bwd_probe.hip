@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     p.B = 1; p.heads = heads; p.Ho = out; p.Wo = out; p.h = lr; p.w = lr; p.dy = out / lr; p.dx = out / lr;
     p.nblocks = (uint32_t)(lr * lr * heads);
     p.scale = 0.125f; p.scale_log2e = 0.125f * 1.4426950408889634f;
+    p.dv_pitch = DV; p.dq_accum = 0;   // the whole head in one launch (xna_bwd.hip splits wide heads into channel chunks)
     // channels-last layouts: [b][y][x][head][d]
     const int64_t qs[4] = {(int64_t)nq, 64, (int64_t)out * heads * 64, (int64_t)heads * 64};
     const int64_t gs[4] = {(int64_t)ng, DV, (int64_t)out * heads * DV, (int64_t)heads * DV};
