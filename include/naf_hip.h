@@ -452,7 +452,8 @@ typedef struct naf_xna_bwd_args {
     void* workspace;         /* version >= 104: device scratch of naf_xna_bwd_workspace_bytes() bytes, 16-byte aligned (NAF_XNA_ROWS) */
     int64_t workspace_bytes;
 } naf_xna_bwd_args;
-/* NAF_XNA_MFMA, NAF_XNA_ROWS or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run; negative naf_status on invalid arguments.
+/* NAF_XNA_MFMA, NAF_XNA_ROWS or NAF_XNA_GENERIC: the kernel naf_xna_bwd would run under a->path; negative naf_status on invalid arguments
+ * (-NAF_ERR_UNSUPPORTED when a->path insists on a kernel that does not serve the shape).
  * NAF_XNA_ROWS (round 3) is the matrix-core backward of the square windows <= 15 the cell kernel does not take, at any integer
  * ratio and at non-integer ratios whose 16-query tiles stay within 32 low-res columns (tap multiplicities as in the forward): the denoising call (denoising.py:213,301: ratio 1, one head of Dq = 64 ... 512 as in naf_xna_fwd's
  * NAF_XNA_ROWS, Dv <= 32) and heads of 64 with Dv in {32, 64, 96, 128, 192, 256} at any integer ratio -- the reference's own
