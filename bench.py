@@ -89,6 +89,41 @@ class EventTimer:
         return len(self.pairs.get(name, []))
 
 
+class StepClock:
+    """Device time of every timed step: one HIP event on the current stream in front of each step and one
+    behind the last -- the forward joins its lent stream back before it returns, so consecutive events bracket whole steps.
+    With more than 128 steps only every n-th boundary is recorded (an event record costs ~1 us of host time)."""
+
+    def __init__(self, steps):
+        self.stride = max(1, steps // 128)
+        self.events = []
+
+    def mark(self, i):
+        if i % self.stride == 0:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append(e)
+
+    def close(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.events.append(e)
+
+    def summary(self, steps):
+        """ms per step between consecutive recorded boundaries (after a synchronise)."""
+        ev = self.events
+        if len(ev) < 2:
+            return None
+        last = steps - (len(ev) - 2) * self.stride                     # steps inside the last interval
+        d = [ev[i].elapsed_time(ev[i + 1]) / (self.stride if i + 2 < len(ev) else max(1, last)) for i in range(len(ev) - 1)]
+        srt = sorted(d)
+        q = lambda f: srt[min(len(srt) - 1, int(f * len(srt)))]
+        return {"steps_per_sample": self.stride, "samples": len(d), "first": round(d[0], 4), "head": [round(x, 4) for x in d[:8]],
+                "min": round(srt[0], 4), "median": round(q(0.5), 4), "p90": round(q(0.9), 4), "max": round(srt[-1], 4),
+                "sum_ms": round(sum(x * (self.stride if i + 2 < len(ev) else max(1, last)) for i, x in enumerate(d)), 3),
+                "what": "device time between HIP events recorded in front of the timed steps (stream order); sum_ms against steps x ms_per_step is the host-side share of the reading"}
+
+
 def algorithmic_bytes(B, C, lr, out, elt=2, cq=256):
     return elt * B * (cq * out * out + (cq + C) * lr * lr + C * out * out)
 
@@ -348,7 +383,7 @@ def main():
         # Reading 1 (SURVEY 8d / test/forward_speed.py:31-52, the protocol of rounds 1-3): W warm-up steps from idle, then the same
         # --steps timed the same way, BEFORE any settle phase -- reported as ms_per_step_no_settle so that driver numbers stay
         # comparable across rounds.  Reading 2 (ms_per_step, `value`): after the settle phase below.
-        el_cold = None
+        el_cold = clock_cold = None
         if args.settle_seconds > 0 and not args.no_cold_reading:
             for _ in range(args.warmup):
                 o = step()
@@ -357,9 +392,12 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
+            clock_cold = StepClock(args.steps)
             t0c = time.perf_counter()
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                clock_cold.mark(i)
                 o = step()
+            clock_cold.close()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -386,9 +424,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         timer.enabled = True
+        clock = StepClock(args.steps)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            clock.mark(i)
             o = step()
+        clock.close()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -526,6 +567,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             # the same W warm-ups + K steps taken BEFORE the settle phase (the protocol of rounds 1-3): comparable across rounds
             "ms_per_step_no_settle": round(el_cold * 1e3 / args.steps, 4) if el_cold else None,
+            # where the time of each reading went, step by step (a clock ramp shows as a falling `head`, a slow first launch as `first`)
+            "step_ms": clock.summary(args.steps),
+            "step_ms_no_settle": clock_cold.summary(args.steps) if clock_cold else None,
             "settle": {"seconds": args.settle_seconds, "steps": settle_steps,
                        "what": "untimed set-up before the warm-up steps: the step is run for this long so that the device has left its idle power state"},
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
@@ -542,7 +586,14 @@ def main():
                        "scope": ("attention-only (scope A)" if args.attention_only else "whole forward (conv stem + RoPE/pool + attention)")
                                 + (", hipGraph replay" if args.graph else ""),
                        "weights": "random-init NAF() defaults (dim 256, 4 heads)",
-                       "streams": _planned_streams(model)},
+                       "streams": _planned_streams(model),
+                       # a driver that divides value(N) by value(1) compares two workloads: name them
+                       "scale_note": ("N = 1 times G1 (1 image, C = 768: the configuration BASELINE.json's metric is quoted on); the N > 1 lines time "
+                                      "G3 (64 images, C = 1024, ~6 % fewer Mpix/s per GPU) and carry the SAME 64 images on one GPU as one_gpu_ms / "
+                                      "speedup_vs_1 -- that is the like-for-like scaling figure (or run --gpus 1 --workload G3 --per-gpu-batch 8)"
+                                      if world == 1 else
+                                      "strong scaling of G3's 64 images; speedup_vs_1 = one_gpu_ms / ms_per_step compares with the same 64 images on "
+                                      "rank 0 alone and is the like-for-like figure: the N = 1 line of this script times another workload (G1: 1 image, C = 768)")},
             "roofline": roof,
             "phases_ms": {k: v for k, v in phases.items() if v is not None},
         }

@@ -43,19 +43,27 @@ extern "C" {
  * of w_packed for the 3x3 layers of the default width (naf_stem_weight_index; also naf_stem_branch.conv_weight_packed of naf_forward):
  * a 0.2.x host must be rebuilt, allocate the larger buffers and repack those weights; the attention entries are unchanged.
  * 0.4.0 makes that break DETECTABLE: the entry points that read or write GroupNorm-sum buffers are exported under names that
- * carry the copy count (naf_stem_conv0_fwd -> naf_stem_conv0_fwd_s16, ...; the #defines below keep the source names), so a binary
+ * carry the copy count (naf_stem_conv0_fwd -> naf_stem_conv0_fwd_s16, ...; the #defines below keep the source names and paste
+ * NAF_STATS_SLOTS into the exported ones), so a binary
  * built against a 0.2.x / 0.3.x header fails to resolve them at load time instead of overrunning its [B][8][2] buffers, and
  * naf_abi_check(NAF_HIP_VERSION) lets a host compare the header it was compiled with against the library it loaded in one call.
  * 0.4.0 also appends `flags` to naf_stem_conv0_args and adds naf_forward_ex / naf_forward_aux (caller-owned second stream);
  * naf_forward itself is unchanged in signature and now runs on the caller's stream only.
  * 0.4.1 (binary compatible with 0.4.0): naf_xna_bwd_args.reserved -- documented as 0 -- becomes `path` (0 = NAF_XNA_AUTO: the
  * behaviour of 0.4.0), and the cell backward takes 13 x 13 windows at every Dv and 15 x 15 windows (channel chunks). */
-#define naf_stem_conv0_fwd naf_stem_conv0_fwd_s16
-#define naf_stem_conv_fwd naf_stem_conv_fwd_s16
-#define naf_stem_conv_keys_fwd naf_stem_conv_keys_fwd_s16
-#define naf_stem_act_fwd naf_stem_act_fwd_s16
-#define naf_stem_act_bwd naf_stem_act_bwd_s16
-#define naf_stem_wgrad naf_stem_wgrad_s16
+/* The copy count is part of the ABI and the export names are DERIVED from it (round 6): a library built with another value
+ * (-DNAF_STATS_SLOTS=8) exports naf_stem_conv0_fwd_s8, ..., so that a host holding [16][B][8][2] buffers cannot resolve them. */
+#ifndef NAF_STATS_SLOTS
+#define NAF_STATS_SLOTS 16 /* copies of every GroupNorm-sum buffer (see "guidance conv stem" below) */
+#endif
+#define NAF_ABI_PASTE2(name, slots) name##_s##slots
+#define NAF_ABI_PASTE(name, slots) NAF_ABI_PASTE2(name, slots)
+#define naf_stem_conv0_fwd NAF_ABI_PASTE(naf_stem_conv0_fwd, NAF_STATS_SLOTS)
+#define naf_stem_conv_fwd NAF_ABI_PASTE(naf_stem_conv_fwd, NAF_STATS_SLOTS)
+#define naf_stem_conv_keys_fwd NAF_ABI_PASTE(naf_stem_conv_keys_fwd, NAF_STATS_SLOTS)
+#define naf_stem_act_fwd NAF_ABI_PASTE(naf_stem_act_fwd, NAF_STATS_SLOTS)
+#define naf_stem_act_bwd NAF_ABI_PASTE(naf_stem_act_bwd, NAF_STATS_SLOTS)
+#define naf_stem_wgrad NAF_ABI_PASTE(naf_stem_wgrad, NAF_STATS_SLOTS)
 
 typedef void* naf_stream_t; /* hipStream_t */
 
@@ -132,9 +140,7 @@ int naf_axis_index_table_device(int32_t* out_dev, int32_t L_out, int32_t L_in, i
  *   128 channels only;
  *   stats_in then are the sums a naf_stem_conv0_fwd(y = NULL) call produced.  Given the same stats_in the results
  *   are bit-identical to the two-call sequence. */
-#ifndef NAF_STATS_SLOTS
-#define NAF_STATS_SLOTS 16 /* copies of every GroupNorm-sum buffer (part of the ABI: a library built with another value is another ABI) */
-#endif
+/* NAF_STATS_SLOTS (defined at the top, beside the export names it versions) = copies of every GroupNorm-sum buffer. */
 /* Bytes of ONE GroupNorm-sum buffer for a batch of B images as THIS library lays it out ([NAF_STATS_SLOTS][B][8][2] fp64): what a
  * host allocates per `stats` pointer instead of hard-coding the shape (0 for B <= 0).  0.4.0. */
 size_t naf_stem_stats_bytes(int32_t B);

@@ -59,11 +59,12 @@ def scatter_batch(full: torch.Tensor | None, shape: Sequence[int], dtype, device
     final_device, device = device, ("cpu" if via_host else device)
     # The owner's argument check is COLLECTIVE (as in broadcast_batch): a one-element status broadcast first, so that a bad `full`
     # raises on every rank instead of leaving the others blocked in the scatter until the process-group timeout.
-    ok = rank != src or (full is not None and tuple(full.shape) == tuple(shape))
+    # shape AND dtype: a full tensor of another dtype would fail inside dist.scatter on the owner only
+    ok = rank != src or (full is not None and tuple(full.shape) == tuple(shape) and full.dtype == dtype)
     status = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.broadcast(status, src=src)
     if int(status.item()) != 1:
-        raise ValueError(f"scatter_batch: rank {src} must pass the full tensor of shape {tuple(shape)}")
+        raise ValueError(f"scatter_batch: rank {src} must pass the full tensor of shape {tuple(shape)} and dtype {dtype}")
     recv = torch.empty((mx, *shape[1:]), dtype=dtype, device=device)
     chunks = None
     if rank == src:

@@ -25,8 +25,13 @@ def _declared_symbols():
 
 
 def _export_names():
-    """header name -> exported name: the `#define naf_x naf_x_s16` lines that version the entry points by buffer layout (0.4.0)."""
-    return dict(re.findall(r"^#define\s+(naf_[a-z_0-9]+)\s+(naf_[a-z_0-9]+)\s*$", _header_text(), flags=re.M))
+    """header name -> exported name: the `#define naf_x NAF_ABI_PASTE(naf_x, NAF_STATS_SLOTS)` lines that version the entry points by
+    buffer layout (0.4.0; since round 6 the suffix is pasted from NAF_STATS_SLOTS instead of spelled out)."""
+    txt = _header_text()
+    slots = int(re.search(r"#define\s+NAF_STATS_SLOTS\s+(\d+)", txt).group(1))
+    names = re.findall(r"^#define\s+(naf_[a-z_0-9]+)\s+NAF_ABI_PASTE\((naf_[a-z_0-9]+),\s*NAF_STATS_SLOTS\)\s*$", txt, flags=re.M)
+    assert all(a == b for a, b in names)
+    return {a: f"{a}_s{slots}" for a, _ in names}
 
 
 def test_library_builds_and_exports_every_declared_symbol(built_lib):

@@ -62,8 +62,8 @@ def _worker(rank, world, port, ret):
             bad = None if rank != 0 else (None, full_img[:-1], full_img.double())[which]
             with pytest.raises(ValueError):
                 nd.broadcast_batch(bad, (N, 3, 4, 4), torch.float32, "cpu", src=0)
-        for which in range(2):                               # the same for the scatter (round 5: its owner-side check is collective too)
-            bad = None if rank != 0 else (None, full_img[:-1])[which]
+        for which in range(3):                               # the same for the scatter (round 5: collective; round 6: the dtype too)
+            bad = None if rank != 0 else (None, full_img[:-1], full_img.double())[which]
             with pytest.raises(ValueError):
                 nd.scatter_batch(bad, (N, 3, 4, 4), torch.float32, "cpu", src=0)
         empty = nd.scatter_batch(torch.zeros(0, 2) if rank == 0 else None, (0, 2), torch.float32, "cpu", src=0)
