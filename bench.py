@@ -461,7 +461,11 @@ def main():
                 raise SystemExit(f"bench.py: {world} ranks on {len(set(ids))} distinct GPUs: {ids}")
         # Weak-scaling leg beside the strong one: every rank runs `micro_batch` images (one micro-batch, the same per-GPU work
         # at every N) between barriers; afterwards rank 0 runs the same alone.  Raw times only.
-        wb = min(args.micro_batch, B)
+        # the same image count on EVERY rank (uneven shards: the smallest one), agreed collectively so that all ranks take the same
+        # branch around the barriers below (a rank with an empty shard would otherwise skip them and hang the others)
+        wbt = torch.tensor([min(args.micro_batch, B)], dtype=torch.int64, device=dev)
+        dist.all_reduce(wbt, op=dist.ReduceOp.MIN)
+        wb = int(wbt.item())
         if wb > 0:
             with torch.no_grad():
                 for rep in range(2):

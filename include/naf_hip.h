@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NAF_HIP_VERSION 401 /* major*10000 + minor*100 + patch */
+#define NAF_HIP_VERSION 402 /* major*10000 + minor*100 + patch */
 /* Binary compatibility: the argument structs carry no size field, so a host must be BUILT against the header of the library it
  * loads whenever the minor version differs (compare naf_version() / 100 with NAF_HIP_VERSION / 100 at start-up, as
  * examples/c_host.c does).  0.1.x appended fields to naf_xna_bwd_args (workspace) and naf_forward_args (phase_events): hosts
@@ -50,7 +50,11 @@ extern "C" {
  * 0.4.0 also appends `flags` to naf_stem_conv0_args and adds naf_forward_ex / naf_forward_aux (caller-owned second stream);
  * naf_forward itself is unchanged in signature and now runs on the caller's stream only.
  * 0.4.1 (binary compatible with 0.4.0): naf_xna_bwd_args.reserved -- documented as 0 -- becomes `path` (0 = NAF_XNA_AUTO: the
- * behaviour of 0.4.0), and the cell backward takes 13 x 13 windows at every Dv and 15 x 15 windows (channel chunks). */
+ * behaviour of 0.4.0), and the cell backward takes 13 x 13 windows at every Dv and 15 x 15 windows (channel chunks).
+ * 0.4.2 (binary compatible with 0.4.x): the training-side stem entries serve every width the forward serves (multiples of 16 up to
+ * 256, the reference's denoising models): naf_stem_wgrad_args and naf_stem_conv0_wgrad_args gain `channels` in what was alignment
+ * padding (a zero-initialised struct of an older host reads 0 = 128, struct sizes and all other offsets unchanged), the plain mode
+ * of naf_stem_conv_fwd and naf_stem_act_fwd / _bwd lose their 128- / 64-multiple restrictions. */
 /* The copy count is part of the ABI and the export names are DERIVED from it (round 6): a library built with another value
  * (-DNAF_STATS_SLOTS=8) exports naf_stem_conv0_fwd_s8, ..., so that a host holding [16][B][8][2] buffers cannot resolve them. */
 #ifndef NAF_STATS_SLOTS
@@ -274,6 +278,7 @@ typedef struct naf_stem_wgrad_args {
     int32_t ksize;
     int32_t B, H, W;
     float eps;
+    int32_t channels; /* 0.4.2 (was alignment padding): C, a multiple of 16 up to 256; 0 = 128.  dw is f32 [k][k][C oc][C ic], db [C] */
     int64_t dy_stride[3];
     int64_t x_stride[3];
 } naf_stem_wgrad_args;
@@ -291,10 +296,29 @@ typedef struct naf_stem_conv0_wgrad_args {
     int32_t image_dtype; /* naf_dtype */
     int32_t ksize;
     int32_t B, H, W;
+    int32_t channels; /* 0.4.2 (was alignment padding): C of the convolution 3 -> C, a multiple of 16 up to 256; 0 = 128.  dw [3*k*k][C], db [C] */
     int64_t dy_stride[3];
     int64_t image_stride[4];
 } naf_stem_conv0_wgrad_args;
 int naf_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, naf_stream_t stream);
+
+/* naf_stem_conv0_dgrad (0.4.2) : gradient of the first convolution w.r.t. the IMAGE (what autograd runs through Conv2d(3 -> C,
+ *   padding_mode="reflect") of convolutions.py:68-75 when the image requires a gradient): dimage[b, c, y, x] (= or +=, `accumulate`)
+ *   sum over output pixels and taps that read (y, x) -- through the reflection too -- of dy[., oc] * weight[oc][c][ty][tx].
+ *   dy device bf16 [B, H, W, C] by strides {b, y, x} (channels contiguous); weight device f32 [C][3][k][k] contiguous (the
+ *   parameter); dimage device f32 by element strides {b, c, y, x}.  ksize 1 or 3; channels a multiple of 16 up to 256 (0 = 128). */
+typedef struct naf_stem_conv0_dgrad_args {
+    const void* dy;
+    const float* weight;
+    float* dimage;
+    int32_t ksize;
+    int32_t B, H, W;
+    int32_t channels;
+    int32_t accumulate; /* 0: dimage is written; 1: added to (the second branch of the stem) */
+    int64_t dy_stride[3];
+    int64_t dimage_stride[4];
+} naf_stem_conv0_dgrad_args;
+int naf_stem_conv0_dgrad(const naf_stem_conv0_dgrad_args* a, naf_stream_t stream);
 
 /* ---- RoPE tables --------------------------------------------------------------------------------
  * Replaces RoPE.create_coordinate + the angle/sin/cos part of RoPE.rotate (rope.py:84-105,137-146),

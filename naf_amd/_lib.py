@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported before the HIP library is dlopen'e
 # NAF_HIP_LIB lets an experiment point at an alternative build of the SAME library (A/B kernel variants)
 LIB_PATH = os.environ.get("NAF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnaf_hip.so")
 
-HEADER_VERSION = 401          # NAF_HIP_VERSION of the include/naf_hip.h these ctypes mirrors were written against
+HEADER_VERSION = 402          # NAF_HIP_VERSION of the include/naf_hip.h these ctypes mirrors were written against
 NAF_BF16, NAF_F32 = 0, 1
 XNA_AUTO, XNA_MFMA, XNA_GENERIC, XNA_UNION, XNA_ROWS = 0, 1, 2, 3, 4
 
@@ -85,14 +85,22 @@ class StemWgradArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("gn_weight", C.c_void_p), ("gn_bias", C.c_void_p),
         ("stats_in", C.c_void_p), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("eps", C.c_float),
-        ("dy_stride", I64x3), ("x_stride", I64x3),
+        ("channels", C.c_int32), ("dy_stride", I64x3), ("x_stride", I64x3),
     ]
 
 
 class StemConv0WgradArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("image", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("image_dtype", C.c_int32),
-        ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("dy_stride", I64x3), ("image_stride", I64x4),
+        ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("channels", C.c_int32), ("dy_stride", I64x3),
+        ("image_stride", I64x4),
+    ]
+
+
+class StemConv0DgradArgs(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("weight", C.c_void_p), ("dimage", C.c_void_p), ("ksize", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+        ("W", C.c_int32), ("channels", C.c_int32), ("accumulate", C.c_int32), ("dy_stride", I64x3), ("dimage_stride", I64x4),
     ]
 
 
@@ -180,6 +188,7 @@ SIGNATURES = {
     "naf_rope_pool_bwd": (C.c_int, [C.POINTER(RopePoolBwdArgs), C.c_void_p]),
     "naf_stem_wgrad": (C.c_int, [C.POINTER(StemWgradArgs), C.c_void_p]),
     "naf_stem_conv0_wgrad": (C.c_int, [C.POINTER(StemConv0WgradArgs), C.c_void_p]),
+    "naf_stem_conv0_dgrad": (C.c_int, [C.POINTER(StemConv0DgradArgs), C.c_void_p]),
     "naf_stem_act_fwd": (C.c_int, [C.POINTER(StemActArgs), C.c_void_p]),
     "naf_stem_act_bwd": (C.c_int, [C.POINTER(StemActBwdArgs), C.c_void_p]),
     "naf_rope_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

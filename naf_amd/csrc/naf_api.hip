@@ -151,8 +151,7 @@ int naf_stem_conv_fwd(const naf_stem_conv_args* a, naf_stream_t stream) {
     const bool plain = a->stats_in == nullptr && a->gn_weight == nullptr && a->gn_bias == nullptr;   // conv only (+ optional bias)
     NAF_REQUIRE((a->x || a->first) && a->y && a->w_packed && (plain || (a->bias && a->gn_weight && a->gn_bias && a->stats_in)),
                 "naf_stem_conv_fwd: NULL pointer");
-    NAF_REQUIRE(!plain || (a->first == nullptr && (a->channels == 0 || a->channels == 128)),
-                "naf_stem_conv_fwd: the plain (no GroupNorm / SiLU) mode exists for the 128-channel kernels, without `first`");
+    NAF_REQUIRE(!plain || a->first == nullptr, "naf_stem_conv_fwd: the plain (no GroupNorm / SiLU) mode has no `first`");
     if (a->first != nullptr) {
         const naf_stem_conv0_args* f = a->first;
         NAF_REQUIRE(a->ksize == 1 && f->ksize == 1, "naf_stem_conv_fwd: `first` (recomputed conv0 input) exists for the 1x1 branch only");
@@ -222,6 +221,7 @@ int naf_stem_wgrad(const naf_stem_wgrad_args* a, naf_stream_t stream) {
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_wgrad: reflect padding needs H, W >= 2");
     NAF_REQUIRE(al16(a->dy) && al16(a->x), "naf_stem_wgrad: tensors must be 16-byte aligned");
     for (int i = 0; i < 3; ++i) NAF_REQUIRE(a->dy_stride[i] % 8 == 0 && a->x_stride[i] % 8 == 0, "naf_stem_wgrad: strides must be multiples of 8 elements");
+    if (a->channels != 0 && a->channels != 128) return naf_launch_stem_wgrad_generic(a, static_cast<hipStream_t>(stream));
     return naf_launch_stem_wgrad(a, static_cast<hipStream_t>(stream));
 }
 
@@ -232,7 +232,22 @@ int naf_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, naf_stream_t stream
     NAF_REQUIRE(a->image_dtype == NAF_BF16 || a->image_dtype == NAF_F32, "naf_stem_conv0_wgrad: image_dtype %d", a->image_dtype);
     NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_conv0_wgrad: size out of range");
     NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv0_wgrad: reflect padding needs H, W >= 2");
+    NAF_REQUIRE(a->channels == 0 || (a->channels >= 16 && a->channels <= 256 && a->channels % 16 == 0),
+                "naf_stem_conv0_wgrad: %d channels (multiples of 16 up to 256)", a->channels);
     return naf_launch_stem_conv0_wgrad(a, static_cast<hipStream_t>(stream));
+}
+
+int naf_stem_conv0_dgrad(const naf_stem_conv0_dgrad_args* a, naf_stream_t stream) {
+    NAF_REQUIRE(a != nullptr, "naf_stem_conv0_dgrad: args is NULL");
+    NAF_REQUIRE(a->dy && a->weight && a->dimage, "naf_stem_conv0_dgrad: NULL pointer");
+    NAF_REQUIRE(a->ksize == 1 || a->ksize == 3, "naf_stem_conv0_dgrad: kernel size %d (1 or 3)", a->ksize);
+    NAF_REQUIRE(a->B > 0 && a->B <= 65535 && a->H > 0 && a->W > 0, "naf_stem_conv0_dgrad: size out of range");
+    NAF_REQUIRE(a->ksize == 1 || (a->H >= 2 && a->W >= 2), "naf_stem_conv0_dgrad: reflect padding needs H, W >= 2");
+    NAF_REQUIRE(a->channels == 0 || (a->channels >= 16 && a->channels <= 256 && a->channels % 16 == 0),
+                "naf_stem_conv0_dgrad: %d channels (multiples of 16 up to 256)", a->channels);
+    NAF_REQUIRE(al16(a->dy), "naf_stem_conv0_dgrad: dy must be 16-byte aligned");
+    for (int i = 0; i < 3; ++i) NAF_REQUIRE(a->dy_stride[i] % 8 == 0, "naf_stem_conv0_dgrad: dy strides must be multiples of 8 elements");
+    return naf_launch_stem_conv0_dgrad(a, static_cast<hipStream_t>(stream));
 }
 
 int naf_stem_act_fwd(const naf_stem_act_args* a, naf_stream_t stream) {

@@ -65,7 +65,9 @@ int naf_launch_stem_conv0_generic(const naf_stem_conv0_args* a, hipStream_t s); 
 int naf_launch_stem_conv_generic(const naf_stem_conv_args* a, hipStream_t s);
 int naf_launch_rope_pool_bwd(const naf_rope_pool_bwd_args* a, hipStream_t s);
 int naf_launch_stem_wgrad(const naf_stem_wgrad_args* a, hipStream_t s);
+int naf_launch_stem_wgrad_generic(const naf_stem_wgrad_args* a, hipStream_t s);   // stem_generic_bwd.hip: widths other than 128
 int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t s);
+int naf_launch_stem_conv0_dgrad(const naf_stem_conv0_dgrad_args* a, hipStream_t s);
 int naf_launch_stem_act_fwd(const naf_stem_act_args* a, hipStream_t s);
 int naf_launch_stem_act_bwd(const naf_stem_act_bwd_args* a, hipStream_t s);
 

@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p
     __syncthreads();
     const int chunk = threadIdx.x & (p.tpp - 1), plane = threadIdx.x / p.tpp, nplanes = 256 / p.tpp;
     const bool active = chunk * 8 < p.C;
-    float sc[8], sh[8], rs[8], rm[8], gam[8], s1[8], s2[8];
-    float m1 = 0.f, m2 = 0.f;
+    float sc[8], sh[8], rs[8], rm[8], gam[8], s1[8], s2[8], m1[8], m2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = active ? chunk * 8 + e : 0;
@@ -123,11 +122,11 @@ __global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p
         rm[e] = cv[3 * p.C + c];
         gam[e] = p.gamma[c];
         s1[e] = s2[e] = 0.f;
-    }
-    if (PHASE == 2 && active) {   // 8 channels of a chunk sit in one group (C / 8 channels per group, a multiple of 8... or of 2: see launcher)
-        const int g = (chunk * 8) / (p.C / GROUPS);
-        m1 = gm[g];
-        m2 = gm[GROUPS + g];
+        // the group means per CHANNEL (round 6): at widths that are not multiples of 64 (the denoising models, hidden 48 ... 240)
+        // a 16-byte chunk of 8 channels straddles GroupNorm groups (C / 8 channels each, an even number)
+        const int g = c / (p.C / GROUPS);
+        m1[e] = PHASE == 2 ? gm[g] : 0.f;
+        m2[e] = PHASE == 2 ? gm[GROUPS + g] : 0.f;
     }
     const int r0 = blockIdx.x * p.rows_per_block, r1 = min(p.H, r0 + p.rows_per_block);
     const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p
                         s1[e] += dz;
                         s2[e] = fmaf(dz, xh, s2[e]);
                     } else {
-                        o[e] = (bf16_t)(rs[e] * (gam[e] * dz - m1 - xh * m2));
+                        o[e] = (bf16_t)(rs[e] * (gam[e] * dz - m1[e] - xh * m2[e]));
                     }
                 }
                 if (PHASE == 2) *reinterpret_cast<bf16x8_t*>(ob + (int64_t)y * p.dxs[1] + (int64_t)x * p.dxs[2]) = o;
@@ -198,8 +197,8 @@ __global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p
 }
 
 static int act_common(StemActParams& p, int C, int H, const char* who) {
-    if (C < 16 || C > 256 || C % 64 != 0) {   // a 16-byte chunk (8 channels) must not straddle two of the 8 GroupNorm groups
-        naf_set_error("%s: %d channels (multiples of 64 up to 256)", who, C);
+    if (C < 16 || C > 256 || C % 16 != 0) {   // 16-byte chunks of 8 channels; GroupNorm(8) groups of C / 8 channels
+        naf_set_error("%s: %d channels (multiples of 16 up to 256)", who, C);
         return NAF_ERR_UNSUPPORTED;
     }
     int tpp = 1;
@@ -246,18 +245,19 @@ int naf_launch_stem_act_bwd(const naf_stem_act_bwd_args* a, hipStream_t s) {
 }
 
 
-// ---- weight / bias gradient of the first convolution (3 -> 128, convolutions.py:68-75) ---------------------------------
+// ---- weight / bias gradient of the first convolution (3 -> C, convolutions.py:68-75) ---------------------------------
 // dW0[oc][c][ty][tx] = sum over pixels of dy[px][oc] * image[reflect(px + tap)][c]: 27 (or 3) outputs per oc -- far too thin for
-// the matrix pipe; a thread owns an output channel (lanes = consecutive oc: the dy reads of a wave are one 128-byte run per pixel),
+// the matrix pipe; a thread owns an output channel (lanes = consecutive oc: the dy reads of a wave are one contiguous run per pixel),
 // keeps its 27 sums in registers and reads the image taps as LDS broadcasts from the three staged rows.  Stored tap-major
-// ([c][ty][tx][oc], fp32 atomics on 128-byte runs); the host permutes the 3 456 numbers into the parameter's layout.
+// ([c][ty][tx][oc], fp32 atomics on contiguous runs); the host permutes the numbers into the parameter's layout.
+// Round 6: any width C (a multiple of 16 up to 256): the 256 threads are CW = 64 / 128 / 256 channel lanes x 256 / CW pixel phases.
 namespace {
 struct Conv0WgradParams {
     const bf16_t* dy;
     const void* image;
-    float* dw;   // [3 * KS * KS][128]
-    float* db;   // [128]
-    int32_t B, H, W, rows_per_block;
+    float* dw;   // [3 * KS * KS][C]
+    float* db;   // [C]
+    int32_t B, H, W, rows_per_block, C, cw_log2;
     int64_t dys[3], is[4];
 };
 }  // namespace
@@ -266,12 +266,14 @@ template <int KS, typename T>
 __global__ __launch_bounds__(256) void stem_conv0_wgrad_kernel(const Conv0WgradParams p) {
     constexpr int HALO = KS / 2, NT = 3 * KS * KS;
     extern __shared__ __attribute__((aligned(16))) float simg[];   // [KS rows][3 ch][W + 2 HALO]
-    const int tid = threadIdx.x, oc = tid & 127, sub = tid >> 7;
+    const int CW = 1 << p.cw_log2, nsub = 256 >> p.cw_log2;
+    const int tid = threadIdx.x, oc = tid & (CW - 1), sub = tid >> p.cw_log2;
+    const bool live = oc < p.C;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * p.rows_per_block, r1 = min(p.H, r0 + p.rows_per_block);
     const int WP = p.W + 2 * HALO;
     const T* ib = reinterpret_cast<const T*>(p.image) + (int64_t)b * p.is[0];
-    const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0] + oc;
+    const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0] + (live ? oc : 0);
     float acc[NT], bs = 0.f;
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = 0.f;
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(256) void stem_conv0_wgrad_kernel(const Conv0WgradP
             simg[i] = (float)ib[c * p.is[1] + (int64_t)yy * p.is[2] + (int64_t)xx * p.is[3]];
         }
         __syncthreads();
-        for (int x = sub; x < p.W; x += 2) {
-            const float g = (float)dyb[(int64_t)y * p.dys[1] + (int64_t)x * p.dys[2]];
+        for (int x = sub; x < p.W; x += nsub) {
+            const float g = live ? (float)dyb[(int64_t)y * p.dys[1] + (int64_t)x * p.dys[2]] : 0.f;
             bs += g;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -295,19 +297,26 @@ __global__ __launch_bounds__(256) void stem_conv0_wgrad_kernel(const Conv0WgradP
                         acc[(c * KS + ty) * KS + tx] = fmaf(g, simg[(ty * 3 + c) * WP + x + tx], acc[(c * KS + ty) * KS + tx]);
         }
     }
-    // the two pixel halves of an output channel meet in LDS, then one set of atomics per workgroup
+    // the pixel phases of an output channel meet in LDS, then one set of atomics per workgroup
     __syncthreads();
-    float* red = simg;   // [NT + 1][128] <= the staged rows for every W >= 13 (the launcher sizes the LDS for both uses)
-    if (sub == 1) {
+    float* red = simg;   // [nsub - 1][NT + 1][CW] (the launcher sizes the LDS for both uses)
+    if (sub > 0) {
+        float* r = red + (size_t)(sub - 1) * (NT + 1) * CW;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) red[i * 128 + oc] = acc[i];
-        red[NT * 128 + oc] = bs;
+        for (int i = 0; i < NT; ++i) r[i * CW + oc] = acc[i];
+        r[NT * CW + oc] = bs;
     }
     __syncthreads();
-    if (sub == 0) {
+    if (sub == 0 && live) {
+        for (int q = 0; q < nsub - 1; ++q) {
+            const float* r = red + (size_t)q * (NT + 1) * CW;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) atomicAdd(&p.dw[i * 128 + oc], acc[i] + red[i * 128 + oc]);
-        atomicAdd(&p.db[oc], bs + red[NT * 128 + oc]);
+            for (int i = 0; i < NT; ++i) acc[i] += r[i * CW + oc];
+            bs += r[NT * CW + oc];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) atomicAdd(&p.dw[i * p.C + oc], acc[i]);
+        atomicAdd(&p.db[oc], bs);
     }
 }
 
@@ -315,6 +324,8 @@ int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t 
     Conv0WgradParams p;
     p.dy = static_cast<const bf16_t*>(a->dy); p.image = a->image; p.dw = a->dw; p.db = a->db;
     p.B = a->B; p.H = a->H; p.W = a->W;
+    p.C = a->channels ? a->channels : 128;
+    p.cw_log2 = p.C <= 64 ? 6 : (p.C <= 128 ? 7 : 8);
     for (int i = 0; i < 3; ++i) p.dys[i] = a->dy_stride[i];
     for (int i = 0; i < 4; ++i) p.is[i] = a->image_stride[i];
     const int target = naf_cu_count() * 2;
@@ -322,8 +333,10 @@ int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t 
     if (rows < 1) rows = 1;
     p.rows_per_block = rows;
     const int NT = 3 * a->ksize * a->ksize, WP = a->W + 2 * (a->ksize / 2);
+    const int CW = 1 << p.cw_log2, nsub = 256 >> p.cw_log2;
     size_t lds = (size_t)a->ksize * 3 * WP * sizeof(float);
-    if (lds < (size_t)(NT + 1) * 128 * sizeof(float)) lds = (size_t)(NT + 1) * 128 * sizeof(float);
+    const size_t red = (size_t)(nsub > 1 ? nsub - 1 : 1) * (NT + 1) * CW * sizeof(float);
+    if (lds < red) lds = red;
     if (lds > 150 * 1024) {
         naf_set_error("naf_stem_conv0_wgrad: image width %d too large for the staged rows", a->W);
         return NAF_ERR_UNSUPPORTED;

@@ -147,19 +147,24 @@ __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int cpg = C / 8;
+    // PLAIN (stats_in == NULL, round 6): a bare convolution of the bf16 input -- no GroupNorm, no SiLU -- which is the data
+    // gradient of the training path on flipped / transposed weights (model._HipStem.backward), as at the default width
+    const bool plain = p.stats_in == nullptr;
     for (int c = tid; c < C; c += NWG * 64) {
-        const int g = c / cpg;
-        const double n = (double)p.H * (double)p.W * (double)cpg;
-        double s1, s2;
-        naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-        const float gm = p.gamma[c];
-        cvec[c] = p.bias[c];
-        cvec[C + c] = gm * rstd;
-        cvec[2 * C + c] = p.beta[c] - (float)mean * gm * rstd;
+        cvec[c] = p.bias != nullptr ? p.bias[c] : 0.f;
+        if (!plain) {
+            const int g = c / cpg;
+            const double n = (double)p.H * (double)p.W * (double)cpg;
+            double s1, s2;
+            naf_gn_sums(p.stats_in, p.B, b, g, s1, s2);
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float gm = p.gamma[c];
+            cvec[C + c] = gm * rstd;
+            cvec[2 * C + c] = p.beta[c] - (float)mean * gm * rstd;
+        }
         s1c[c] = 0.f;
         s2c[c] = 0.f;
     }
@@ -175,6 +180,10 @@ __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParam
         const int py = pp / PW, pxx = pp - py * PW;
         const int sy = reflect(min(ty0 + py - KS / 2, p.H - 1 + KS / 2), p.H), sx = reflect(min(tx0 + pxx - KS / 2, p.W - 1 + KS / 2), p.W);
         const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)sy * p.xs[1] + (int64_t)sx * p.xs[2] + ch * 8);
+        if (plain) {
+            *reinterpret_cast<u32x4_t*>(patch + pp * CP + ch * 8) = raw;
+            continue;
+        }
         bf16x8_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -198,14 +198,16 @@ class _HipStem(torch.autograd.Function):
       weight gradient  naf_stem_wgrad: a GEMM contracted over pixels (transposing LDS reads feed both MFMA operands), with
                        a = SiLU(GroupNorm(x)) recomputed in its loader.
     bf16 roundings of stored activations / gradients are treated as identities (as torch.autocast does for bf16 convolutions:
-    this is the reference's use_bf16 training mode, train.py:120).  Default width (128 hidden channels) only."""
+    this is the reference's use_bf16 training mode, train.py:120).  Every width the forward stem serves (round 6: hidden widths that
+    are multiples of 16 up to 256 -- the reference's denoising models, denoising.py:209-220 -- through stem_generic.hip's plain
+    convolution, stem_generic_bwd.hip's weight gradient and the width-general norm / first-convolution kernels of stem_bwd.hip)."""
 
     @staticmethod
     def forward(ctx, enc, image, *params):
         B, _, H, W = image.shape
         dev = image.device
         branches = (enc.encoder, enc.sem_encoder)
-        hid = 128
+        hid = enc.encoder[0].out_channels
         nlayer = len(_stem_layers(enc.encoder))
         stats = ops.new_stats(B, dev, lead=(2, nlayer + 1))
         cat = torch.empty((B, H, W, 2 * hid), dtype=torch.bfloat16, device=dev)
@@ -240,8 +242,8 @@ class _HipStem(torch.autograd.Function):
             pos += n
         B, _, H, W = image.shape
         dev = g.device
-        hid = 128
-        gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()          # [B, H, W, 256]; a no-op for a channels-last gradient
+        hid = enc.encoder[0].out_channels
+        gcl = g.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()          # [B, H, W, 2 hid]; a no-op for a channels-last gradient
         grads = []
         dimage = None
         need_img = ctx.needs_input_grad[1]
@@ -284,21 +286,17 @@ class _HipStem(torch.autograd.Function):
                 bgrads.append((s32[:, 1].to(norm.weight.dtype), s32[:, 0].to(norm.bias.dtype),
                                dw.to(conv.weight.dtype), db.to(conv.bias.dtype)))
                 gl = dx
-            # first convolution (3 -> 128 on the image): naf_stem_conv0_wgrad; through ATen only when the image wants a gradient
+            # first convolution (3 -> hid on the image): naf_stem_conv0_wgrad for the parameters and, when the image wants a
+            # gradient, naf_stem_conv0_dgrad (round 6: no ATen / MIOpen convolution is left on the training path)
             conv0 = seq[0]
-            if not need_img:
-                dw0, db0 = ops.stem_conv0_wgrad(gl, image.detach(), conv0.kernel_size[0])
-                grads += [dw0.to(conv0.weight.dtype), db0.to(conv0.bias.dtype)]
-            else:
-                with torch.enable_grad():
-                    im = image.detach().float().requires_grad_(True)
-                    w0 = conv0.weight.detach().requires_grad_(True)
-                    b0 = conv0.bias.detach().requires_grad_(True)
-                    pad = conv0.kernel_size[0] // 2
-                    y0 = F.conv2d(_ReflectPad.apply(im, pad) if pad else im, w0, b0)
-                    outs = torch.autograd.grad(y0, [w0, b0, im], gl.permute(0, 3, 1, 2).float())
-                dimage = outs[2] if dimage is None else dimage + outs[2]
-                grads += [outs[0], outs[1]]
+            dw0, db0 = ops.stem_conv0_wgrad(gl, image.detach(), conv0.kernel_size[0])
+            grads += [dw0.to(conv0.weight.dtype), db0.to(conv0.bias.dtype)]
+            if need_img:
+                if dimage is None:
+                    dimage = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+                    ops.stem_conv0_dgrad(gl, conv0.weight.detach().float().contiguous(), dimage, accumulate=False)
+                else:
+                    ops.stem_conv0_dgrad(gl, conv0.weight.detach().float().contiguous(), dimage, accumulate=True)
             for t in reversed(bgrads):
                 grads += list(t)
         assert len(grads) == ctx.nparams
@@ -382,6 +380,10 @@ class ImageEncoder(nn.Module):
 
     def _hip_stem_default_width(self) -> bool:
         return self._hip_stem_ok() and self.encoder[0].out_channels == 128
+
+    def _hip_train_stem_ok(self) -> bool:
+        """Widths ``_HipStem`` (forward with saved activations + HIP backward kernels) serves: all the forward stem does."""
+        return self._hip_stem_ok()
 
     def _packed(self, conv: nn.Conv2d) -> torch.Tensor:
         """``ops.pack_conv_weight`` of a conv weight (bf16, the order naf_stem_conv_fwd reads), cached until the parameter changes."""
@@ -672,7 +674,7 @@ class NAF(nn.Module):
         """Capture this forward for the given shapes in a hipGraph; see ``GraphedForward``."""
         return GraphedForward(self, image, features, output_size, capture_error_mode=capture_error_mode)
 
-    def forward_train(self, image, features, output_size, amp=False):
+    def forward_train(self, image, features, output_size, amp="auto"):
         """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
         and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
@@ -681,10 +683,14 @@ class NAF(nn.Module):
         has a backward kernel (``ops.xna_backward_select``): the MFMA cell kernel (integer ratio, Wo/w a multiple of 16, window <= 13
         with K/V windows inside the LDS), the row-streaming matrix-core kernel (every other integer ratio: the reference's own training
         geometry 16^2 -> 32^2, patch-14 backbones, the denoising call), the table-driven scalar kernel for the rest.
-        ``amp=True`` runs the stem's convolutions in bf16 under ``torch.autocast`` -- the reference's ``use_bf16`` training
-        mode (train.py:120, denoising.py:209); GroupNorm statistics, RoPE and pooling stay fp32.  ``amp="hip"`` is the same
-        precision class on this library's own stem: ``_HipStem`` (fused forward kernels, bf16 activations kept per layer, HIP
-        data-gradient / GroupNorm+SiLU backward kernels)."""
+        ``amp="auto"`` (the default, and what ``model(image, feats, size)`` uses when a gradient is wanted; round 6) trains through the
+        library's own differentiable stem ``_HipStem`` whenever ``image_encoder.stem_impl == "hip"`` and the width has HIP training
+        kernels -- with or without ``torch.autocast``: its contract (bf16 activations between layers, fp32 accumulation, fp64 GroupNorm
+        sums) is what the inference forward computes, so training and inference see the same function.  The torch stem stays as the
+        explicit A/B arm: ``amp=False`` = fp32 MIOpen convolutions, ``amp=True`` = the reference's ``use_bf16`` mode (bf16 stem
+        convolutions under ``torch.autocast``, train.py:120, denoising.py:209; GroupNorm statistics, RoPE and pooling fp32);
+        ``stem_impl = "torch"`` makes "auto" choose between those two by the ambient autocast state.  ``amp="hip"`` insists on
+        ``_HipStem`` (raises when the width is not served)."""
         if not (image.is_cuda and features.is_cuda):
             raise RuntimeError("naf_amd.NAF runs only on a ROCm device (HIP kernels, no CPU fallback)")
         enc = self.image_encoder
@@ -695,9 +701,15 @@ class NAF(nn.Module):
         if x.shape[-2] > 4 * ho or x.shape[-1] > 4 * wo:                       # naf.py:39-48
             x = F.interpolate(x.float(), size=(min(x.shape[-2], 4 * ho, 4 * wo), min(x.shape[-1], 4 * wo, 4 * ho)),
                               mode="bilinear", align_corners=False)
+        if amp == "auto":
+            if enc.use_encoder and enc.stem_impl == "hip" and enc._hip_train_stem_ok():
+                amp = "hip"
+            else:
+                amp = bool(torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         if enc.use_encoder and amp == "hip":
-            if not enc._hip_stem_default_width():
-                raise RuntimeError("forward_train(amp='hip'): the differentiable HIP stem serves the default width (dim 256)")
+            if not enc._hip_train_stem_ok():
+                raise RuntimeError("forward_train(amp='hip'): the differentiable HIP stem serves hidden widths that are multiples of 16 "
+                                   f"up to 256 with GroupNorm(8) (got {enc.encoder[0].out_channels})")
             x = _HipStem.apply(enc, x, *_hip_stem_params(enc))
             if x.shape[-2:] != (ho, wo):
                 x = x.float()
@@ -765,13 +777,9 @@ class NAF(nn.Module):
             if return_weights:
                 raise NotImplementedError("naf_amd: return_weights is an inference feature (notebooks/attention_maps.ipynb); "
                                           "call under torch.no_grad() or after .eval()")
-            # under torch.autocast(bfloat16) -- the reference's use_bf16 training mode (train.py:120, denoising.py:209) -- the
-            # default-width model trains through this library's own differentiable stem (bf16 activations, HIP backward kernels)
-            amp = False
-            if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-                enc = self.image_encoder
-                amp = "hip" if (enc.stem_impl == "hip" and enc._hip_stem_default_width()) else True
-            return self.forward_train(image, features, output_size, amp=amp)
+            # the library's own differentiable stem whenever it serves the width, with or without torch.autocast (round 6: the
+            # bf16-activation contract is what the inference path computes); else the torch stem in the ambient precision
+            return self.forward_train(image, features, output_size, amp="auto")
         with torch.no_grad():
             return self._forward_inference(image, features, output_size, return_weights)
 

@@ -237,13 +237,13 @@ def _fill_key_pool(keys, x) -> KeyPoolArgs:
 
 
 def stem_conv_plain(x: torch.Tensor, w_packed: torch.Tensor, y: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
-    """y = conv(x) (+ bias): ``naf_stem_conv_fwd`` without GroupNorm / SiLU, bf16 [B,H,W,128] views, reflect padding for the
+    """y = conv(x) (+ bias): ``naf_stem_conv_fwd`` without GroupNorm / SiLU, bf16 [B,H,W,C] views (any width the stem serves), reflect padding for the
     3x3 kernel.  With ``w_packed = pack_conv_weight(weight.flip(2, 3).transpose(0, 1))`` it is a layer's data gradient (see include/naf_hip.h)."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape
-    if Cc != 128 or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
-        raise ValueError("stem_conv_plain: bf16 [B,H,W,128] activations with channels contiguous")
+    if Cc % 16 or not (16 <= Cc <= 256) or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or x.stride(3) != 1 or y.stride(3) != 1:
+        raise ValueError("stem_conv_plain: bf16 [B,H,W,C] activations with channels contiguous, C a multiple of 16 up to 256")
     if tuple(w_packed.shape[1:]) != (Cc, Cc) or w_packed.dtype != torch.bfloat16 or not w_packed.is_contiguous():
         raise ValueError(f"stem_conv_plain: packed weight {tuple(w_packed.shape)} / {w_packed.dtype}")
     a = StemConvArgs()
@@ -280,14 +280,16 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
 
 def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tensor], gn_weight: Optional[torch.Tensor],
                gn_bias: Optional[torch.Tensor], eps: float, ksize: int, with_bias: bool = False):
-    """Weight gradient [128, 128, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))) + b: ``naf_stem_wgrad``; dy, x bf16 [B,H,W,128].
+    """Weight gradient [C, C, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))) + b: ``naf_stem_wgrad``; dy, x bf16 [B,H,W,C]
+    (C = 128: the hand-scheduled kernel of stem_wgrad.hip; other multiples of 16 up to 256: stem_generic_bwd.hip).
     ``stats_in=None``: x already is the activation SiLU(GroupNorm(.)) (``stem_act(..., pad=0)``).  ``with_bias``: also returns
     the bias gradient [128] (sum of dy over pixels, accumulated by the same kernel)."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape
-    if Cc != 128 or tuple(dy.shape) != (B, H, W, Cc) or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.stride(3) != 1 or x.stride(3) != 1:
-        raise ValueError("stem_wgrad: bf16 [B,H,W,128] tensors with channels contiguous")
+    if (Cc % 16 or not (16 <= Cc <= 256) or tuple(dy.shape) != (B, H, W, Cc) or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
+            or dy.stride(3) != 1 or x.stride(3) != 1):
+        raise ValueError("stem_wgrad: bf16 [B,H,W,C] tensors with channels contiguous, C a multiple of 16 up to 256")
     buf = torch.zeros((ksize * ksize * Cc * Cc + Cc,), dtype=torch.float32, device=x.device)   # one memset for both
     dw = buf[: ksize * ksize * Cc * Cc].view(ksize, ksize, Cc, Cc)                       # taps outermost: coalesced atomics
     db = buf[ksize * ksize * Cc * Cc:]
@@ -298,7 +300,7 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tenso
         a.gn_weight, a.gn_bias, a.stats_in = gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_wgrad")
     else:
         a.gn_weight = a.gn_bias = a.stats_in = None
-    a.ksize, a.B, a.H, a.W, a.eps = int(ksize), B, H, W, float(eps)
+    a.ksize, a.B, a.H, a.W, a.eps, a.channels = int(ksize), B, H, W, float(eps), Cc
     a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
     a.x_stride = I64x3(int(x.stride(0)), int(x.stride(1)), int(x.stride(2)))
     with torch.cuda.device(x.device), _Timed("stem_wgrad%d" % ksize):
@@ -308,11 +310,11 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tenso
 
 
 def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(dW [128, 3, k, k], db [128]) of the first convolution (``naf_stem_conv0_wgrad``): dy bf16 [B,H,W,128], image [B,3,H,W]."""
+    """(dW [C, 3, k, k], db [C]) of the first convolution (``naf_stem_conv0_wgrad``): dy bf16 [B,H,W,C], image [B,3,H,W]."""
     lib = _lib.load()
     _gpu(dy, "dy")
     B, H, W, Cc = dy.shape
-    if Cc != 128 or dy.dtype != torch.bfloat16 or dy.stride(3) != 1 or tuple(image.shape) != (B, 3, H, W):
+    if Cc % 16 or not (16 <= Cc <= 256) or dy.dtype != torch.bfloat16 or dy.stride(3) != 1 or tuple(image.shape) != (B, 3, H, W):
         raise ValueError(f"stem_conv0_wgrad: dy {tuple(dy.shape)} / image {tuple(image.shape)}")
     if image.dtype not in _DT:
         image = image.float()
@@ -320,13 +322,33 @@ def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int) -> Tuple
     buf = torch.zeros(((nt + 1) * Cc,), dtype=torch.float32, device=dy.device)
     a = _lib.StemConv0WgradArgs()
     a.dy, a.image, a.dw, a.db = dy.data_ptr(), image.data_ptr(), buf.data_ptr(), buf[nt * Cc:].data_ptr()
-    a.image_dtype, a.ksize, a.B, a.H, a.W = _DT[image.dtype], int(ksize), B, H, W
+    a.image_dtype, a.ksize, a.B, a.H, a.W, a.channels = _DT[image.dtype], int(ksize), B, H, W, Cc
     a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
     a.image_stride = _strides4(image, (0, 1, 2, 3))
     with torch.cuda.device(dy.device), _Timed("stem_conv0_wgrad"):
         rc = lib.naf_stem_conv0_wgrad(C.byref(a), _stream(dy))
     _lib.check(rc, "naf_stem_conv0_wgrad")
     return buf[: nt * Cc].view(3, ksize, ksize, Cc).permute(3, 0, 1, 2), buf[nt * Cc:]
+
+
+def stem_conv0_dgrad(dy: torch.Tensor, weight: torch.Tensor, dimage: torch.Tensor, accumulate: bool = False) -> None:
+    """Gradient of the first convolution Conv2d(3 -> C, k in {1, 3}, reflect) w.r.t. the image (``naf_stem_conv0_dgrad``):
+    dy bf16 [B,H,W,C], weight f32 [C,3,k,k] (the parameter), dimage f32 [B,3,H,W] written or -- ``accumulate`` -- added to."""
+    lib = _lib.load()
+    _gpu(dy, "dy")
+    B, H, W, Cc = dy.shape
+    k = int(weight.shape[-1])
+    if (Cc % 16 or not (16 <= Cc <= 256) or dy.dtype != torch.bfloat16 or dy.stride(3) != 1 or tuple(dimage.shape) != (B, 3, H, W)
+            or dimage.dtype != torch.float32 or tuple(weight.shape) != (Cc, 3, k, k) or weight.dtype != torch.float32 or not weight.is_contiguous()):
+        raise ValueError(f"stem_conv0_dgrad: dy {tuple(dy.shape)} / weight {tuple(weight.shape)} / dimage {tuple(dimage.shape)} {dimage.dtype}")
+    a = _lib.StemConv0DgradArgs()
+    a.dy, a.weight, a.dimage = dy.data_ptr(), weight.data_ptr(), dimage.data_ptr()
+    a.ksize, a.B, a.H, a.W, a.channels, a.accumulate = k, B, H, W, Cc, int(bool(accumulate))
+    a.dy_stride = I64x3(int(dy.stride(0)), int(dy.stride(1)), int(dy.stride(2)))
+    a.dimage_stride = _strides4(dimage, (0, 1, 2, 3))
+    with torch.cuda.device(dy.device), _Timed("stem_conv0_dgrad"):
+        rc = lib.naf_stem_conv0_dgrad(C.byref(a), _stream(dy))
+    _lib.check(rc, "naf_stem_conv0_dgrad")
 
 
 def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,

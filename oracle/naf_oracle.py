@@ -5,10 +5,16 @@ module.  Nothing under ``naf_amd/`` imports it; the product path fails loudly wi
 
 What it is
 ----------
-A plain fp32/fp64 PyTorch-CPU restatement of the reference's forward
+A plain fp32/fp64 PyTorch restatement of the reference's forward
 ``naf(image, lr_features, target_size)`` written from the reference's formulas (file:line cited on
 each function, paths relative to /root/reference).  Every function is a straight-line tensor
-program with no module state.
+program with no module state, evaluated on the CPU: the golden fixtures, bench.py's cpu_baseline
+and every parity test at sizes the host finishes in seconds.  The functions create their index /
+coordinate tensors on their inputs' device, so the SAME code can also be evaluated by ATen's fp32 /
+fp64 device kernels: the GPU suite does that for its largest cases only (the 2048^2 stem, the G3
+shard, fp64 autograd of wide heads with 11x11 ... 15x15 windows -- minutes of host time otherwise)
+after ``tests/test_gpu_parity.py::test_oracle_on_the_device_equals_the_oracle_on_the_host`` has held
+the device evaluation to the host evaluation on that very box.  Nothing hand-written runs in it.
 
 Parity status
 -------------
@@ -143,8 +149,8 @@ def conv_stem(image: Tensor, p: Dict[str, Tensor]) -> Tensor:
 def rope_angles(H: int, W: int, periods: Tensor) -> Tensor:
     """[H*W, D_head] angles.  rope.py:98-105 (normalize 'separate'), :139-143."""
     dt = periods.dtype
-    ch = torch.arange(0.5, H, dtype=dt) / H
-    cw = torch.arange(0.5, W, dtype=dt) / W
+    ch = torch.arange(0.5, H, dtype=dt, device=periods.device) / H
+    cw = torch.arange(0.5, W, dtype=dt, device=periods.device) / W
     coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).flatten(0, 1)
     coords = 2.0 * coords - 1.0
     ang = 2 * math.pi * coords[:, :, None] / periods[None, None, :]
@@ -264,14 +270,14 @@ def xna_tables(q: Tensor, k_lr: Tensor, v_lr: Tensor, idx_y: np.ndarray, idx_x: 
     ky, kx = idx_y.shape[1], idx_x.shape[1]
     if scale is None:
         scale = Dq ** -0.5                                              # attentions.py:46
-    iy = torch.from_numpy(np.ascontiguousarray(idx_y))
-    ix = torch.from_numpy(np.ascontiguousarray(idx_x))
+    iy = torch.from_numpy(np.ascontiguousarray(idx_y)).to(q.device)
+    ix = torch.from_numpy(np.ascontiguousarray(idx_x)).to(q.device)
     kh = k_lr.reshape(B, heads, Dq, *k_lr.shape[-2:]).permute(0, 1, 3, 4, 2)   # b n h w d
     vh = v_lr.reshape(B, heads, Dv, *v_lr.shape[-2:]).permute(0, 1, 3, 4, 2).to(q.dtype)
     kh = kh.to(q.dtype)
     qh = q.reshape(B, heads, Dq, Ho, Wo).permute(0, 1, 3, 4, 2)                 # b n H W d
-    out = torch.empty(B, heads, Ho, Wo, Dv, dtype=q.dtype)
-    logits_all = torch.empty(B, heads, Ho, Wo, ky * kx, dtype=q.dtype) if return_logits else None
+    out = torch.empty(B, heads, Ho, Wo, Dv, dtype=q.dtype, device=q.device)
+    logits_all = torch.empty(B, heads, Ho, Wo, ky * kx, dtype=q.dtype, device=q.device) if return_logits else None
     for r0 in range(0, Ho, rows_per_chunk):
         r1 = min(Ho, r0 + rows_per_chunk)
         yy = iy[r0:r1]                                                  # [R, ky]
@@ -308,10 +314,10 @@ def xna_lowres(q: Tensor, k_lr: Tensor, v_lr: Tensor, kernel_size: int, heads: i
     dy, dx = Ho // h, Wo // w
     k = kernel_size
     Dq, Dv = Cq // heads, C // heads
-    sy = torch.clamp(torch.arange(h) - k // 2, 0, h - k)
-    sx = torch.clamp(torch.arange(w) - k // 2, 0, w - k)
-    wy = sy[:, None] + torch.arange(k)[None, :]                        # [h, k]
-    wx = sx[:, None] + torch.arange(k)[None, :]                        # [w, k]
+    sy = torch.clamp(torch.arange(h, device=q.device) - k // 2, 0, h - k)
+    sx = torch.clamp(torch.arange(w, device=q.device) - k // 2, 0, w - k)
+    wy = sy[:, None] + torch.arange(k, device=q.device)[None, :]       # [h, k]
+    wx = sx[:, None] + torch.arange(k, device=q.device)[None, :]       # [w, k]
     kh = k_lr.reshape(B, heads, Dq, h, w).to(q.dtype)
     vh = v_lr.reshape(B, heads, Dv, h, w).to(q.dtype)
     kw = kh[:, :, :, wy][:, :, :, :, :, wx]                            # b n D h k w k

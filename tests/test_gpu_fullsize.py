@@ -49,9 +49,15 @@ def _assert_close(got, ref, atol, rtol, what):
                                  f"{np.unravel_index(int(err.argmax()), err.shape)}, ref absmax {float(ref.abs().max()):.3f}")
 
 
-def _oracle_rows(p, img, ft, out_sz, ksz, rows, heads=4):
+def _oracle_rows(p, img, ft, out_sz, ksz, rows, heads=4, on=None):
     """Oracle forward of ONE image restricted to output rows ``rows`` (GroupNorm needs the whole image, so the stem and
-    RoPE run at full size; only the attention is row-sampled).  Returns (stem [1,256,H,W], out_rows [1,C,len(rows),W])."""
+    RoPE run at full size; only the attention is row-sampled).  Returns (stem [1,256,H,W], out_rows [1,C,len(rows),W]).
+    ``on`` = a device: the same oracle code evaluated by ATen's fp32 device kernels (G4's 5.5 TFLOP stem and the G3 shard's two
+    stems took a minute of host time; tests/test_gpu_parity.py::test_oracle_on_the_device_equals_the_oracle_on_the_host holds the
+    device evaluation to the host's).  G1 -- the graded configuration -- and the G2 windows stay on the host."""
+    if on is not None:
+        p = {k: v.to(on) for k, v in p.items()}
+        img, ft = img.to(on), ft.to(on)
     with torch.no_grad():
         stem = O.conv_stem(img, p)
         x = O.rope(stem, p["image_encoder.rope.periods"], heads)
@@ -59,10 +65,10 @@ def _oracle_rows(p, img, ft, out_sz, ksz, rows, heads=4):
         iy = O.axis_index_table(out_sz, ft.shape[-2], ksz)[rows]
         ix = O.axis_index_table(out_sz, ft.shape[-1], ksz)
         ref = O.xna_tables(x[:, :, rows].contiguous(), k, ft, iy, ix, heads)
-    return stem, ref
+    return stem.cpu(), ref.cpu()
 
 
-def _assert_fused_keys(m, p, lr_hw, what, images=None, heads=4):
+def _assert_fused_keys(m, p, lr_hw, what, images=None, heads=4, on=None):
     """VERDICT r04 (weak 3): the keys the stem's LAST layers pooled (naf_stem_conv_keys_fwd inside the one-call forward), ALL cells at
     full size, against the oracle's pool(RoPE(.)) (naf.py:63-69 after rope.py:139-153) of the very bf16 guidance that call wrote
     -- both read back from the call's workspace (ForwardPlan.view) -- at tests/test_gpu_keys.py's tolerance (one bf16 rounding)."""
@@ -75,9 +81,10 @@ def _assert_fused_keys(m, p, lr_hw, what, images=None, heads=4):
     per = p["image_encoder.rope.periods"]
     worst = 0.0
     for b in sel:
-        y = guide[b:b + 1].float().cpu().permute(0, 3, 1, 2).contiguous()
+        y = guide[b:b + 1].float()
+        y = (y.cpu() if on is None else y.to(on)).permute(0, 3, 1, 2).contiguous()
         with torch.no_grad():
-            ref = O.key_pool(O.rope(y, per, heads), lr_hw)
+            ref = O.key_pool(O.rope(y, per if on is None else per.to(on), heads), lr_hw).cpu()     # `on`: see _oracle_rows
         del y
         got = keys[b:b + 1].float().cpu().permute(0, 3, 1, 2)
         err = (got - ref).abs()
@@ -116,14 +123,14 @@ def test_whole_forward_G1_full_size(dev):
     _assert_fused_keys(m, p, (lr, lr), "G1")
 
 
-def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows):
+def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows, oracle_on=None):
     """Stem at EVERY pixel (mean / max and uniformity over 32-pixel strips and 64-row bands: a geometry bug would make one
     stand out) + the whole bf16 forward on sampled rows, against the fp32 oracle."""
     p = O.make_params(seed=seed)
     m = _load_model(dev, p, kernel_size=ksz)
     img = O.hash_normal((1, 3, out_sz, out_sz), 100 * seed + 1)
     ft = O.hash_normal((1, C, lr, lr), 100 * seed + 2).to(torch.bfloat16).float()
-    stem_ref, ref = _oracle_rows(p, img, ft, out_sz, ksz, rows)
+    stem_ref, ref = _oracle_rows(p, img, ft, out_sz, ksz, rows, on=oracle_on)
     got_stem = m.image_encoder.guidance(img.to(dev), (out_sz, out_sz)).float().cpu()
     err = (got_stem - stem_ref).abs()
     del got_stem, stem_ref
@@ -136,7 +143,7 @@ def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows):
     got = out[:, :, rows].float().cpu()
     _assert_close(got, ref, 2e-2, 1e-2, f"{name} whole forward, sampled rows")
     assert float((got - ref).abs().mean()) <= 6e-3
-    _assert_fused_keys(m, p, (lr, lr), name)        # every cell: the POOL launch's segment rounds at this size (4 x 128 rows at 2048^2)
+    _assert_fused_keys(m, p, (lr, lr), name, on=oracle_on)        # every cell: the POOL launch's segment rounds at this size (4 x 128 rows at 2048^2)
 
 
 def test_whole_forward_G4_full_size(dev):
@@ -145,7 +152,7 @@ def test_whole_forward_G4_full_size(dev):
     compared with anything; the attention's bf16 output is 3.2 G elements (offsets past 2^31).  The oracle stem at 2048^2 is
     5.5 TFLOP of fp32 CPU convolutions: about a minute on the GPU box's host cores."""
     rows = sorted({0, 1, 15, 16, 511, 512, 1023, 1024, 1300, 1535, 1536, 2031, 2032, 2046, 2047})
-    _whole_forward_case(dev, "G4", 2048, 768, 128, 7, 24, rows)
+    _whole_forward_case(dev, "G4", 2048, 768, 128, 7, 24, rows, oracle_on=dev)      # the oracle's code on the device (see _oracle_rows)
 
 
 @pytest.mark.parametrize("ksz", [7, 11, 15])
@@ -169,7 +176,7 @@ def test_whole_forward_G3_shard_through_the_sharded_driver(dev):
     assert out.shape == (nb, C, out_sz, out_sz) and out.dtype == torch.bfloat16
     rows = sorted({0, 16, 511, 512, 1023})
     for b in (0, 7):
-        _, ref = _oracle_rows(p, img[b:b + 1], ft[b:b + 1], out_sz, ksz, rows)
+        _, ref = _oracle_rows(p, img[b:b + 1], ft[b:b + 1], out_sz, ksz, rows, on=dev if b else None)   # image 0 on the host, image 7 on the device
         got = out[b:b + 1, :, rows].float().cpu()
         _assert_close(got, ref, 2e-2, 1e-2, f"G3 shard image {b}, sampled rows")
         assert float((got - ref).abs().mean()) <= 6e-3
@@ -306,12 +313,13 @@ def test_forward_is_differentiable_when_a_gradient_is_wanted(dev):
     _assert_close(out_t.detach().float().cpu(), out.float().cpu(), 2e-2, 1e-2, "forward_train vs inference path")   # measured 7.3e-3
 
 
-@pytest.mark.parametrize("launcher", ["torch.distributed.run", "plain"])
-def test_bench_multi_rank_path_dry_run(dev, launcher):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process) AND as the plain command
-    line `python bench.py --gpus 2` (bench.py then starts its ranks itself on a free port), on ONE GPU with the
-    collectives on gloo (NAF_BENCH_BACKEND=gloo: a dry run of the code path, never a measurement): the G3 experiment --
-    rank 0 owns the batch, parameters by flat broadcast, inputs by scatter, every rank runs its shard through
+@pytest.mark.parametrize("launcher,world,total", [("torch.distributed.run", 2, 6), ("plain", 8, 12)])
+def test_bench_multi_rank_path_dry_run(dev, launcher, world, total):
+    """bench.py --gpus N as the driver launches it (torch.distributed.run, one rank per process; 2 ranks) AND as the plain command
+    line `python bench.py --gpus 8` (bench.py then starts its ranks itself on a free port) -- the world size the driver's scaling run
+    ends at, with 12 images so that the shards are UNEVEN (2,2,2,2,1,1,1,1: scatter padding, a micro-batch larger than a shard) -- on
+    ONE GPU with the collectives on gloo (NAF_BENCH_BACKEND=gloo: a rehearsal of the code path, never a measurement): the G3
+    experiment -- rank 0 owns the batch, parameters by flat broadcast, inputs by scatter, every rank runs its shard through
     ShardedNAF, rank 0 then runs the whole batch alone for speedup_vs_1 -- prints one well-formed JSON line."""
     import json
     import socket
@@ -320,34 +328,40 @@ def test_bench_multi_rank_path_dry_run(dev, launcher):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NAF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-batch", "6"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--total-batch", str(total)]
     if launcher == "plain":
         cmd = [sys.executable, *tail]
         env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port), *tail]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["global_batch"] == 6 and j["config"]["per_gpu_batch"] == 3
-    assert j["config"]["workload"].startswith("G3") and "DRY RUN" in j["data"]
+    shard0 = -(-total // world)                                  # rank 0 holds the largest shard (block partition)
+    assert j["n_gpus"] == world and j["scaling"] == "strong" and j["config"]["global_batch"] == total and j["config"]["per_gpu_batch"] == shard0
+    assert j["config"]["workload"].startswith("G3") and "DRY RUN" in j["data"] and "speedup_vs_1" in j["config"]["scale_note"]
     assert j["value"] > 0 and j["one_gpu_ms"] > 0 and j["speedup_vs_1"] > 0 and j["scatter_ms"] > 0
     assert j["roofline"]["kernel_ms"] > 0 and j["cpu_baseline"] is None
+    # per-step device times of both readings (round 6): as many samples as steps, the first one and the spread on record
+    for key in ("step_ms", "step_ms_no_settle"):
+        assert j[key]["samples"] == 2 and j[key]["first"] > 0 and j[key]["min"] <= j[key]["median"] <= j[key]["max"]
     # the line proves what ran where: one entry per rank with the device it computed on and its own step time (under RCCL
     # the identities must be distinct -- bench.py exits otherwise; in this dry run the ranks share the GPU), a weak-scaling
     # leg beside the strong one, and the phases of the single call
-    assert [r["rank"] for r in j["ranks"]] == [0, 1] and all(r["images"] == 3 and r["ms_per_step"] > 0 and r["name"] for r in j["ranks"])
+    assert [r["rank"] for r in j["ranks"]] == list(range(world)) and all(r["ms_per_step"] > 0 and r["name"] for r in j["ranks"])
+    assert sum(r["images"] for r in j["ranks"]) == total and max(r["images"] for r in j["ranks"]) - min(r["images"] for r in j["ranks"]) <= 1
     assert all("uuid" in r and "pci" in r for r in j["ranks"])
-    assert j["weak_leg"]["images_per_gpu"] == 3 and j["weak_leg"]["ms_all_ranks_busy"] > 0 and j["weak_leg"]["ms_rank0_alone"] > 0
+    assert j["weak_leg"]["images_per_gpu"] == min(8, total // world) and j["weak_leg"]["ms_all_ranks_busy"] > 0 and j["weak_leg"]["ms_rank0_alone"] > 0
     ph = j["phases_ms"]
     assert ph["stem"] > 0 and ph["rope_pool"] > 0 and ph["attention"] > 0 and ph["stem_conv3"] > 0
     assert 0 < j["roofline"]["frac_with_prepass"] < j["roofline"]["frac"]
 
 
-def test_denoising_configuration_trains_on_the_matrix_core_backward(dev):
+@pytest.mark.parametrize("amp", ["auto", False])
+def test_denoising_configuration_trains_on_the_matrix_core_backward(dev, amp):
     """denoising.py:209-220's step -- model(noisy_norm, noisy, (S, S)) in train mode, loss, backward -- at NAF(dim 96, one head,
     window 15): the attention's backward runs xna_rows_bwd_kernel (round 3; the scalar table-driven kernel before), and every
     parameter gradient plus the gradient w.r.t. the noisy image agrees with fp32 autograd through the oracle."""
@@ -371,12 +385,15 @@ def test_denoising_configuration_trains_on_the_matrix_core_backward(dev):
     nd = noisy.to(dev).requires_grad_(True)
     ops.xna_backward = spy
     try:
-        out = m.forward_train(img.to(dev), nd, (S, S))
+        out = m.forward_train(img.to(dev), nd, (S, S), amp=amp)      # "auto" = what model(...) runs: the library's own stem at width 48 (round 6)
         (out.float() * wgt.to(dev)).sum().backward()
     finally:
         ops.xna_backward = real
     assert seen == ["rows"], seen
-    checked = 0
+    # fp32 torch stem (amp=False): the bounds of rounds 3-5; the HIP stem ("auto"): bf16 activations between ten layers, the budget
+    # tests/test_gpu_train_stem.py holds the default width to (6e-2 relative)
+    tol_p, tol_f = (5e-2, 3e-2) if amp is False else (8e-2, 4e-2)
+    checked, worst = 0, 0.0
     for name, prm in m.named_parameters():
         ref = po[name].grad
         if ref is None:
@@ -384,11 +401,14 @@ def test_denoising_configuration_trains_on_the_matrix_core_backward(dev):
         got = prm.grad.float().cpu()
         scale = float(ref.abs().max())
         err = float((got - ref).abs().max())
-        assert err <= 5e-2 * scale + 1e-3, f"{name}: grad err {err:.3e} vs max {scale:.3e}"
+        assert err <= tol_p * scale + 1e-3, f"{name}: grad err {err:.3e} vs max {scale:.3e}"
+        worst = max(worst, err / max(scale, 1e-30))
         checked += 1
     assert checked >= 20
     gs = float(no.grad.abs().max())
-    assert float((nd.grad.float().cpu() - no.grad).abs().max()) <= 3e-2 * gs + 1e-3
+    ef = float((nd.grad.float().cpu() - no.grad).abs().max())
+    print("denoising training step, amp=%s: worst parameter gradient %.3e, feature gradient %.3e (relative to the largest entry)" % (amp, worst, ef / gs))
+    assert ef <= tol_f * gs + 1e-3
 
 
 @pytest.mark.parametrize("dim,shape", [(96, (1, 40, 56)), (128, (2, 33, 47)), (512, (1, 24, 40)), (32, (1, 20, 24))])

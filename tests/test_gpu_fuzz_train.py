@@ -72,7 +72,7 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     for prm in m.parameters():
         prm.requires_grad_(True)
     fd = ft.to(dev).requires_grad_(True)
-    out = m.forward_train(img.to(dev), fd, c["out"])
+    out = m.forward_train(img.to(dev), fd, c["out"], amp=False)
     (out.float() * wgt.to(dev)).sum().backward()
     torch.cuda.synchronize()
     heads = 4
@@ -82,7 +82,7 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     kern = ops.xna_backward_select(q5, k5, v5, c["k"])
     cell = min(c["out"][0] / c["lr"][0], c["out"][1] / c["lr"][1])
     atol = 6e-2 if cell < 1.5 else 3.6e-2 if cell < 3.0 else 2e-2
-    e_out = (out.float().cpu() - ref_out.detach()).abs()
+    e_out = (out.detach().float().cpu() - ref_out.detach()).abs()      # detached: no grad_fn travels into the float() conversions below
     worst_name, worst = "", 0.0
     for name, prm in m.named_parameters():
         ref = po[name].grad

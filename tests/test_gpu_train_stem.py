@@ -24,21 +24,23 @@ def rel(a, b):
 
 
 def group_stats(x):
-    """fp64 {sum, sum^2} per (sample, group of 16 channels) of a [B, H, W, 128] tensor, as the forward kernels accumulate them."""
+    """fp64 {sum, sum^2} per (sample, group of C / 8 channels) of a [B, H, W, C] tensor, as the forward kernels accumulate them."""
     from naf_amd import ops
-    B = x.shape[0]
-    xd = x.double().reshape(B, -1, 8, 16)
+    B, C = x.shape[0], x.shape[-1]
+    xd = x.double().reshape(B, -1, 8, C // 8)
     return ops.stats_from_total(torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1).contiguous())
 
 
-@pytest.mark.parametrize("k,H,W", [(3, 24, 40), (1, 16, 32), (3, 7, 33), (1, 5, 9)])
-def test_plain_convolution(dev, k, H, W):
-    """naf_stem_conv_fwd without GroupNorm / SiLU == F.conv2d (reflect padding) on the bf16 inputs, fp32 accumulation."""
+@pytest.mark.parametrize("k,H,W,C", [(3, 24, 40, 128), (1, 16, 32, 128), (3, 7, 33, 128), (1, 5, 9, 128),
+                                     (3, 11, 21, 48), (1, 9, 17, 96), (3, 10, 18, 256), (3, 2, 2, 16)])
+def test_plain_convolution(dev, k, H, W, C):
+    """naf_stem_conv_fwd without GroupNorm / SiLU == F.conv2d (reflect padding) on the bf16 inputs, fp32 accumulation; round 6: at
+    every width the stem serves (the data gradient of the denoising models' layers), not only 128."""
     from naf_amd import ops
     g = torch.Generator(device="cpu").manual_seed(k * 100 + H)
-    x = torch.randn(2, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
-    w = (torch.randn(128, 128, k, k, generator=g) / (128 * k * k) ** 0.5).to(dev)
-    b = torch.randn(128, generator=g).to(dev)
+    x = torch.randn(2, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
     wp = ops.pack_conv_weight(w)
     y = torch.empty_like(x)
     ops.stem_conv_plain(x, wp, y, bias=b)
@@ -68,18 +70,20 @@ def test_act_forward(dev, pad, H, W):
     assert float((a.float() - ref).abs().max()) < 3e-2 and rel(a.float(), ref) < 4e-3
 
 
-@pytest.mark.parametrize("fold,H,W", [(False, 12, 20), (True, 12, 20), (True, 3, 4), (True, 2, 2)])
-def test_act_backward(dev, fold, H, W):
+@pytest.mark.parametrize("fold,H,W,C", [(False, 12, 20, 128), (True, 12, 20, 128), (True, 3, 4, 128), (True, 2, 2, 128),
+                                        (True, 9, 14, 48), (False, 7, 11, 96), (True, 6, 10, 240), (False, 5, 5, 16)])
+def test_act_backward(dev, fold, H, W, C):
     """dx, d gamma, d beta of a = SiLU(GroupNorm(x)) vs autograd; with fold the incoming gradient lives on the reflect-padded
-    domain and autograd differentiates through F.pad(mode='reflect') as well."""
+    domain and autograd differentiates through F.pad(mode='reflect') as well.  Widths whose 8-channel chunks straddle GroupNorm
+    groups (48: groups of 6, 240: groups of 30, 16: groups of 2) are the denoising models' (round 6)."""
     from naf_amd import ops
     g = torch.Generator(device="cpu").manual_seed(11 + H)
     B = 2
-    x = (torch.randn(B, H, W, 128, generator=g) * 1.5 - 0.3).to(dev).to(torch.bfloat16)
-    gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
-    shp = (B, H + 2, W + 2, 128) if fold else (B, H, W, 128)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5 - 0.3).to(dev).to(torch.bfloat16)
+    gw, gb = (1 + 0.3 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    shp = (B, H + 2, W + 2, C) if fold else (B, H, W, C)
     da = torch.randn(shp, generator=g).to(dev).to(torch.bfloat16)
-    dx = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev)
     sums = ops.stem_act_bwd(da, x, group_stats(x), gw, gb, 1e-5, dx, fold=fold)
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     gwr, gbr = gw.clone().requires_grad_(True), gb.clone().requires_grad_(True)
@@ -91,20 +95,22 @@ def test_act_backward(dev, fold, H, W):
     assert rel(sums[..., 1].sum(0).float(), gwr.grad) < 2e-3 and rel(sums[..., 0].sum(0).float(), gbr.grad) < 2e-3
 
 
-@pytest.mark.parametrize("k,B,H,W", [(3, 1, 20, 64), (1, 2, 9, 32), (3, 2, 13, 45), (1, 1, 7, 19), (3, 1, 2, 2)])
-def test_weight_gradient(dev, k, B, H, W):
-    """naf_stem_wgrad vs autograd of conv(reflect_pad(SiLU(GroupNorm(x)))) w.r.t. the weight, on the same bf16 tensors."""
+@pytest.mark.parametrize("k,B,H,W,C", [(3, 1, 20, 64, 128), (1, 2, 9, 32, 128), (3, 2, 13, 45, 128), (1, 1, 7, 19, 128), (3, 1, 2, 2, 128),
+                                       (3, 2, 13, 45, 48), (1, 1, 9, 33, 96), (3, 1, 17, 40, 256), (3, 1, 6, 70, 144), (1, 2, 5, 5, 16)])
+def test_weight_gradient(dev, k, B, H, W, C):
+    """naf_stem_wgrad vs autograd of conv(reflect_pad(SiLU(GroupNorm(x)))) w.r.t. the weight, on the same bf16 tensors; the widths
+    other than 128 run stem_generic_bwd.hip (round 6: 144 and 256 split their output channels over two workgroups)."""
     from naf_amd import ops
     g = torch.Generator(device="cpu").manual_seed(31 + H)
-    x = (torch.randn(B, H, W, 128, generator=g) * 1.3 + 0.2).to(dev).to(torch.bfloat16)
-    dy = torch.randn(B, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
-    gw, gb = (1 + 0.3 * torch.randn(128, generator=g)).to(dev), (0.2 * torch.randn(128, generator=g)).to(dev)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.3 + 0.2).to(dev).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+    gw, gb = (1 + 0.3 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
     dw, db = ops.stem_wgrad(dy, x, group_stats(x), gw, gb, 1e-5, k, with_bias=True)
     assert rel(db, dy.float().sum((0, 1, 2))) < 1e-4
     a = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 8, gw, gb, 1e-5)).to(torch.bfloat16).float()   # the kernel's bf16 operand
     if k == 3:
         a = F.pad(a, (1, 1, 1, 1), mode="reflect")
-    w = torch.zeros(128, 128, k, k, device=dev, requires_grad=True)
+    w = torch.zeros(C, C, k, k, device=dev, requires_grad=True)
     F.conv2d(a, w).backward(dy.float().permute(0, 3, 1, 2))
     assert dw.shape == w.grad.shape
     assert rel(dw, w.grad) < 3e-3, rel(dw, w.grad)
@@ -115,20 +121,27 @@ def test_weight_gradient(dev, k, B, H, W):
         assert rel(dw[:, :, t // k, t % k], w.grad[:, :, t // k, t % k]) < 5e-3, t
 
 
-@pytest.mark.parametrize("k,B,H,W", [(3, 2, 12, 20), (1, 1, 9, 33), (3, 1, 2, 2)])
-def test_first_convolution_weight_gradient(dev, k, B, H, W):
+@pytest.mark.parametrize("k,B,H,W,C", [(3, 2, 12, 20, 128), (1, 1, 9, 33, 128), (3, 1, 2, 2, 128), (3, 2, 11, 19, 48), (1, 1, 8, 8, 256), (3, 1, 5, 6, 16)])
+def test_first_convolution_gradients(dev, k, B, H, W, C):
+    """naf_stem_conv0_wgrad (weight, bias) and naf_stem_conv0_dgrad (image; round 6) vs autograd of Conv2d(3 -> C, reflect)."""
     from naf_amd import ops
     g = torch.Generator(device="cpu").manual_seed(41 + H)
     image = torch.randn(B, 3, H, W, generator=g).to(dev)
-    dy = torch.randn(B, H, W, 128, generator=g).to(dev).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
     dw, db = ops.stem_conv0_wgrad(dy, image, k)
-    w = torch.zeros(128, 3, k, k, device=dev, requires_grad=True)
-    bb = torch.zeros(128, device=dev, requires_grad=True)
-    xin = F.pad(image, (1, 1, 1, 1), mode="reflect") if k == 3 else image
+    w = (torch.randn(C, 3, k, k, generator=g) / (3 * k * k) ** 0.5).to(dev).requires_grad_(True)
+    bb = torch.zeros(C, device=dev, requires_grad=True)
+    im = image.clone().requires_grad_(True)
+    xin = F.pad(im, (1, 1, 1, 1), mode="reflect") if k == 3 else im
     F.conv2d(xin, w, bb).backward(dy.float().permute(0, 3, 1, 2))
     assert dw.shape == w.grad.shape and rel(dw, w.grad) < 1e-4 and rel(db, bb.grad) < 1e-4
     dwb, dbb = ops.stem_conv0_wgrad(dy, image.to(torch.bfloat16), k)            # bf16 image
     assert rel(dwb, w.grad) < 1e-2
+    dimg = torch.full((B, 3, H, W), float("nan"), device=dev)
+    ops.stem_conv0_dgrad(dy, w.detach().contiguous(), dimg)                       # written ...
+    assert rel(dimg, im.grad) < 1e-5, rel(dimg, im.grad)
+    ops.stem_conv0_dgrad(dy, w.detach().contiguous(), dimg, accumulate=True)      # ... or added to (the stem's second branch)
+    assert rel(dimg, 2 * im.grad) < 1e-5
 
 
 def test_strided_views(dev):
@@ -258,3 +271,48 @@ def test_hip_training_path_other_geometries(dev, img_hw, out_hw, lr_hw):
     assert rel(res["hip"][0], res[False][0]) < 2e-2
     worst = max((rel(res["hip"][1][n], res[False][1][n]), n) for n in res[False][1])
     assert worst[0] < 6e-2, worst
+
+
+@pytest.mark.parametrize("dim,heads,ksz,C", [(256, 4, 3, 32), (96, 1, 5, 3), (512, 4, 3, 32), (160, 1, 3, 8)])
+def test_training_call_without_autocast_runs_the_hip_stem(dev, dim, heads, ksz, C):
+    """``model(image, feats, size)`` in .train() mode with NO autocast -- the reference's fp32 default (train.py:127-137,
+    denoising.py:209-220: NAF(dim 96 ... 512, one head) on the noisy image itself) -- trains through the library's own differentiable
+    stem since round 6, at every width the forward serves: a profiler table of the step holds no ATen / MIOpen
+    convolution and no ATen GroupNorm, and the gradients agree with the explicit fp32 torch-stem arm (``amp=False``) to the
+    bf16-activation budget the default width is held to."""
+    from naf_amd import NAF
+    torch.manual_seed(7)
+    model = NAF(dim=dim, heads_attn=heads, heads_rope=heads, kernel_size=ksz).to(dev).train()
+    model.image_encoder.rope.rescale_coords = None            # deterministic coordinates: the two arms see the same function
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    S, lr = 48, 48 if C == 3 else 6
+    g = torch.Generator(device="cpu").manual_seed(17)
+    image = torch.randn(2, 3, S, S, generator=g).to(dev)
+    feats = torch.randn(2, C, lr, lr, generator=g).to(dev)
+    wout = torch.randn(2, C, S, S, generator=g).to(dev)
+    res = {}
+    for mode in ("call", False):
+        model.zero_grad(set_to_none=True)
+        im = image.clone().requires_grad_(True)
+        if mode == "call":
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+                out = model(im, feats, (S, S))
+                (out.float() * wout).sum().backward()
+            names = {e.key for e in prof.key_averages()}
+            bad = sorted(n for n in names if any(t in n.lower() for t in ("conv", "miopen", "group_norm")))
+            assert not bad, bad
+        else:
+            out = model.forward_train(im, feats, (S, S), amp=False)
+            (out.float() * wout).sum().backward()
+        res[mode] = (out.detach().float(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                     im.grad.detach().clone())
+    out_h, gh, gi_h = res["call"]
+    out_r, gr, gi_r = res[False]
+    assert rel(out_h, out_r) < 2e-2, rel(out_h, out_r)
+    assert set(gr) == set(gh) and len(gr) == 36
+    worst = max((rel(gh[n], gr[n]), n) for n in gr)
+    assert worst[0] < 6e-2, worst
+    assert rel(gi_h, gi_r) < 6e-2, rel(gi_h, gi_r)
