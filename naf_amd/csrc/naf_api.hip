@@ -466,7 +466,8 @@ struct StreamJoin {
     }
 };
 struct FwdLayout {
-    size_t stats, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t stats, steal, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t zeroed;   // bytes from `stats` the forward's one memset clears: the GroupNorm sums and the attention's claim words behind them
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
     int Ho, Wo;   // output size
@@ -489,6 +490,8 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.img = off;
     if (L.shrunk) off = align256(off + px * 3 * sizeof(float));
     L.stats = off; off = align256(off + (size_t)2 * (a->nlayer + 1) * NAF_STATS_SLOTS * a->B * 16 * sizeof(double));
+    L.steal = off; off = align256(off + (size_t)NAF_XNA_STEAL_WORDS * sizeof(uint32_t));   // xna_slide_kernel.h: tail hand-over flags
+    L.zeroed = off - L.stats;
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
@@ -693,7 +696,7 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
     // kernel of the 1x1 branch, zeroed the buffers and kept its own sums as per-workgroup partials: G2-k7 0.612-0.615 ms against
     // 0.601-0.603 with the memset, 256^2 0.2448 against 0.2434, interleaved; profiles/r05_negative_results.txt.  The fill kernel
     // overlaps the tail of whatever ran before; the kernel that replaced it did not.)
-    if (hipMemsetAsync(stats, 0, (size_t)2 * (a->nlayer + 1) * stat_stride * sizeof(double), s) != hipSuccess) {
+    if (hipMemsetAsync(stats, 0, L.zeroed, s) != hipSuccess) {      // the sums and, right behind them, the attention's claim words
         naf_set_error("naf_forward: hipMemsetAsync failed");
         return NAF_ERR_LAUNCH;
     }
@@ -930,7 +933,16 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
         naf_set_error("naf_forward: hipEventRecord failed");
         return NAF_ERR_LAUNCH;
     }
-    rc = naf_xna_fwd(&x, stream);
+    {   // naf_xna_fwd(&x, stream), with the forward's zeroed claim words lent to the sliding-window kernel
+        const int sel = naf_xna_select(&x);
+        if (sel < 0) return -sel;
+        if (sel == NAF_XNA_MFMA) {
+            const float scale = x.scale > 0.f ? x.scale : 1.0f / sqrtf((float)x.Dq);
+            rc = naf_launch_xna_mfma(&x, scale, s, reinterpret_cast<uint32_t*>(ws + L.steal));
+        } else {
+            rc = naf_xna_fwd(&x, stream);
+        }
+    }
     if (rc != NAF_OK) return rc;
     if (a->events[1] && hipEventRecord(static_cast<hipEvent_t>(a->events[1]), s) != hipSuccess) {
         naf_set_error("naf_forward: hipEventRecord failed");

@@ -31,7 +31,9 @@ int naf_cu_count();   // compute units of the current device (cached per device)
     } while (0)
 
 // ---- kernel launchers implemented in the .hip files ----
-int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s);      // xna_mfma.hip
+int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s, uint32_t* steal = nullptr);      // xna_mfma.hip
+// `steal`: NAF_XNA_STEAL_WORDS caller-zeroed device words for the sliding-window kernel's tail hand-over (xna_slide_kernel.h); NULL: static split
+#define NAF_XNA_STEAL_WORDS 2048
 int naf_xna_mfma_eligible(const naf_xna_args* a, int* dvt_out, size_t* lds_out);  // xna_mfma.hip
 int naf_xna_mfma_rope_ok(const naf_xna_args* a);                                   // xna_mfma.hip
 int naf_launch_xna_generic(const naf_xna_args* a, float scale, hipStream_t s);   // xna_generic.hip

@@ -43,7 +43,7 @@ int naf_xna_mfma_rope_ok(const naf_xna_args* a) {
     return naf_xna_mfma_eligible(a, nullptr, nullptr);
 }
 
-int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
+int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s, uint32_t* steal) {
     int dvt = 0;
     size_t lds = 0;
     if (!naf_xna_mfma_eligible(a, &dvt, &lds)) {
@@ -115,6 +115,18 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s) {
             return NAF_ERR_INVALID;
         }
         sp.m.nblocks = (uint32_t)nbs;
+        // Tail hand-over (round 6): only where ONE resident workgroup per CU walks a long segment -- no more workgroups than CUs,
+        // windows of 11 x 11 and up (their windows leave room for one workgroup per CU), segments of at least 8 cells: the last
+        // quarter of every segment (at most 4 cells) is claimable.  NAF_XNA_STEAL=0 (with NAF_HIP_KNOBS=1): the static split (A/B).
+        static const bool no_steal = [] { const char* e = naf_knob("NAF_XNA_STEAL"); return e && atoi(e) == 0; }();
+        static const int tail_knob = [] { const char* e = naf_knob("NAF_XNA_STEAL_TAIL"); return e ? atoi(e) : 0; }();
+        sp.steal = nullptr; sp.tail = 0; sp.steal_lds = 0;
+        if (steal != nullptr && !no_steal && a->ky >= 11 && nbs <= naf_cu_count() && sp.seg_len >= 8) {
+            int tail = tail_knob > 0 ? tail_knob : sp.seg_len / 4;
+            if (tail > 4 && tail_knob <= 0) tail = 4;
+            if (tail > sp.seg_len - 2) tail = sp.seg_len - 2;
+            if (tail >= 1 && nbs * tail <= NAF_XNA_STEAL_WORDS) { sp.steal = steal; sp.tail = tail; }
+        }
         switch (a->ky) {
             case 7: return naf_xna_slide_launch_k7(sp, dvt_u, a->out_dtype, s);
             case 9: return naf_xna_slide_launch_k9(sp, dvt_u, a->out_dtype, s);

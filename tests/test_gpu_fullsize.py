@@ -65,7 +65,7 @@ def _oracle_rows(p, img, ft, out_sz, ksz, rows, heads=4, on=None):
         iy = O.axis_index_table(out_sz, ft.shape[-2], ksz)[rows]
         ix = O.axis_index_table(out_sz, ft.shape[-1], ksz)
         ref = O.xna_tables(x[:, :, rows].contiguous(), k, ft, iy, ix, heads)
-    return stem.cpu(), ref.cpu()
+    return stem, ref                      # on `on` (or the host): the caller compares where the tensors live
 
 
 def _assert_fused_keys(m, p, lr_hw, what, images=None, heads=4, on=None):
@@ -131,8 +131,8 @@ def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows, oracle_on=Non
     img = O.hash_normal((1, 3, out_sz, out_sz), 100 * seed + 1)
     ft = O.hash_normal((1, C, lr, lr), 100 * seed + 2).to(torch.bfloat16).float()
     stem_ref, ref = _oracle_rows(p, img, ft, out_sz, ksz, rows, on=oracle_on)
-    got_stem = m.image_encoder.guidance(img.to(dev), (out_sz, out_sz)).float().cpu()
-    err = (got_stem - stem_ref).abs()
+    got_stem = m.image_encoder.guidance(img.to(dev), (out_sz, out_sz)).float()
+    err = (got_stem.to(stem_ref.device) - stem_ref).abs()        # 268 M - 1 G values: compared where the oracle's result lives
     del got_stem, stem_ref
     assert float(err.mean()) <= 8e-3 and float(err.max()) <= 2.5e-1, (f"{name} stem", float(err.mean()), float(err.max()))
     band = err.mean(dim=(0, 1)).view(out_sz // 64, 64, out_sz // 32, 32).mean(dim=(1, 3))
@@ -141,6 +141,7 @@ def _whole_forward_case(dev, name, out_sz, C, lr, ksz, seed, rows, oracle_on=Non
     out = m(img.to(dev), ft.to(dev).to(torch.bfloat16), (out_sz, out_sz))
     assert out.shape == (1, C, out_sz, out_sz) and out.dtype == torch.bfloat16
     got = out[:, :, rows].float().cpu()
+    ref = ref.cpu()
     _assert_close(got, ref, 2e-2, 1e-2, f"{name} whole forward, sampled rows")
     assert float((got - ref).abs().mean()) <= 6e-3
     _assert_fused_keys(m, p, (lr, lr), name, on=oracle_on)        # every cell: the POOL launch's segment rounds at this size (4 x 128 rows at 2048^2)
@@ -176,13 +177,14 @@ def test_whole_forward_G3_shard_through_the_sharded_driver(dev):
     assert out.shape == (nb, C, out_sz, out_sz) and out.dtype == torch.bfloat16
     rows = sorted({0, 16, 511, 512, 1023})
     for b in (0, 7):
-        _, ref = _oracle_rows(p, img[b:b + 1], ft[b:b + 1], out_sz, ksz, rows, on=dev if b else None)   # image 0 on the host, image 7 on the device
+        _, ref = _oracle_rows(p, img[b:b + 1], ft[b:b + 1], out_sz, ksz, rows, on=dev)   # the oracle's code on the device (G1 keeps the host)
+        ref = ref.cpu()
         got = out[b:b + 1, :, rows].float().cpu()
         _assert_close(got, ref, 2e-2, 1e-2, f"G3 shard image {b}, sampled rows")
         assert float((got - ref).abs().mean()) <= 6e-3
     # the last micro-batch (images 6, 7: two images per launch, eight rounds of 128-row segments in the 3x3 key-pooling launch)
     # is still in the plan's workspace: all of its cells against the oracle
-    _assert_fused_keys(m, p, (lr, lr), "G3 shard, last micro-batch")
+    _assert_fused_keys(m, p, (lr, lr), "G3 shard, last micro-batch", on=dev)
     # micro-batching is invisible up to the order of the GroupNorm partial sums (the stem's per-workgroup fp32 partials are
     # cut differently for 1 and 2 images per launch, the fp64 atomics land in any order): a handful of bf16 roundings flip
     alone = m(img[3:4].to(dev), ft[3:4].to(dev).to(torch.bfloat16), (out_sz, out_sz))
@@ -392,7 +394,7 @@ def test_denoising_configuration_trains_on_the_matrix_core_backward(dev, amp):
     assert seen == ["rows"], seen
     # fp32 torch stem (amp=False): the bounds of rounds 3-5; the HIP stem ("auto"): bf16 activations between ten layers, the budget
     # tests/test_gpu_train_stem.py holds the default width to (6e-2 relative)
-    tol_p, tol_f = (5e-2, 3e-2) if amp is False else (8e-2, 4e-2)
+    tol_p, tol_f = (5e-2, 3e-2) if amp is False else (6e-2, 3e-2)      # measured 3.9e-2 / 1.3e-2 (gpurun call 634)
     checked, worst = 0, 0.0
     for name, prm in m.named_parameters():
         ref = po[name].grad

@@ -15,6 +15,23 @@ for step in "$@"; do
       timeout 1400 python -m pytest tests -m gpu -x -q --durations=70 > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -90 $out/tests.log | cut -c1-220 ;;
     bench)       # the driver's line
       python bench.py > $out/bench.json 2> $out/bench.err; tail -c 3000 $out/bench.json ;;
+    train)       # round 6: the training path on the HIP stem (every width), the device-evaluated oracle cases, the 8-rank rehearsal
+      timeout 1400 python -m pytest tests/test_gpu_train_stem.py tests/test_gpu_fuzz_train.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -s --durations=25 \
+        -k "train or backward or oracle_on_the_device or F8 or denoising or G4 or G3 or dry_run or differentiable or plain_convolution or act_ or weight_gradient or first_convolution or strided" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log
+      grep -E "denoising training step|passed|failed|rc=|Error|error" $out/tests.log | tail -30; tail -45 $out/tests.log | cut -c1-220 ;;
+    steal)       # round 6 item 2: the sliding-window kernel's tail hand-over -- parity first, then interleaved A/B against the static split
+      timeout 900 python -m pytest tests -m gpu -q -x -k "G2_full_size or sliding_window or benched_instantiations or full_size_properties or fuzz_forward" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log | cut -c1-200
+      for w in G2-k11 G2-k13x; do
+        [ $w = G2-k13x ] && continue
+        for i in 1 2 3; do
+          for st in 1 0; do
+            NAF_HIP_KNOBS=1 NAF_XNA_STEAL=$st python bench.py --workload $w --steps 400 --no-cpu-baseline --no-live-traffic --no-cold-reading 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.readline()); r = j['roofline']
+print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f' % (j['ms_per_step'], r['kernel_ms'], r['frac'], r['mfma_frac']))"
+          done
+        done
+      done | tee $out/ab.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
