@@ -115,10 +115,13 @@ int naf_launch_xna_mfma(const naf_xna_args* a, float scale, hipStream_t s, uint3
             return NAF_ERR_INVALID;
         }
         sp.m.nblocks = (uint32_t)nbs;
-        // Tail hand-over (round 6): only where ONE resident workgroup per CU walks a long segment -- no more workgroups than CUs,
-        // windows of 11 x 11 and up (their windows leave room for one workgroup per CU), segments of at least 8 cells: the last
-        // quarter of every segment (at most 4 cells) is claimable.  NAF_XNA_STEAL=0 (with NAF_HIP_KNOBS=1): the static split (A/B).
-        static const bool no_steal = [] { const char* e = naf_knob("NAF_XNA_STEAL"); return e && atoi(e) == 0; }();
+        // Tail hand-over (round 6): only where ONE resident workgroup per CU walks a long segment -- no more
+        // workgroups than CUs, windows of 11 x 11 / 13 x 13, segments of at least 8 cells: the last quarter of every segment (at most 4
+        // cells) is claimable.  MEASURED AND NOT ADOPTED (profiles/r06_other_workloads.txt): parity-green and bit-identical, but G2-k11
+        // runs 0.1491-0.1497 ms with it against 0.1377-0.1472 ms without on the same lease -- a stolen cell costs a window fill (6.7 us)
+        // on top of its 8.5 us, the owners' two-cells-ahead claims leave only the last cell of the very slowest runs to take, and the
+        // run loop's mutable state costs 70 registers.  OFF by default; NAF_XNA_STEAL=1 (with NAF_HIP_KNOBS=1) enables it (A/B).
+        static const bool no_steal = [] { const char* e = naf_knob("NAF_XNA_STEAL"); return !(e && atoi(e) == 1); }();
         static const int tail_knob = [] { const char* e = naf_knob("NAF_XNA_STEAL_TAIL"); return e ? atoi(e) : 0; }();
         sp.steal = nullptr; sp.tail = 0; sp.steal_lds = 0;
         if (steal != nullptr && !no_steal && a->ky >= 11 && nbs <= naf_cu_count() && sp.seg_len >= 8) {
