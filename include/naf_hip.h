@@ -500,7 +500,13 @@ int naf_xna_bwd_supported(const naf_xna_bwd_args* a);
 size_t naf_xna_bwd_workspace_bytes(const naf_xna_bwd_args* a);
 /* 0.4.1: the launches of the NAF_XNA_MFMA backward for these arguments -- the widths of the channel chunks in launch order, at most `cap` of them written
  * to out (out may be NULL with cap 0).  Returns their number: 1 = the whole head in one launch, 0 = another kernel serves the call
- * (naf_xna_bwd_supported), negative naf_status on invalid arguments.  A pure host-side query (no device call); pointers are only checked, not read. */
+ * (naf_xna_bwd_supported), negative naf_status on invalid arguments.  A pure host-side query (no device call); pointers are only checked, not read.
+ * NUMERICS OF A CHUNKED CALL: dV splits by channel and dK_lr is accumulated in fp32, so neither depends on the plan; dQ is a sum over the
+ * chunks that travels through the caller's bf16 dq buffer -- launch n > 1 reads dq back, adds its fp32 partial and rounds to bf16 again -- so dq
+ * carries one bf16 rounding PER CHUNK (n * 2^-9 relative to the running sum, worst case) instead of one: with the plans in force (at most 4
+ * chunks: 15 x 15 at Dv 256) that is <= 0.8 % of |dq| in the worst case and 0.2-0.3 % measured against the one-launch kernel on the same
+ * inputs (tests/test_gpu_parity.py::test_chunked_backward_dq_against_the_one_launch_kernel).  A host that needs the single rounding calls the
+ * backward per chunk itself with fp32-accumulating glue, or uses windows / widths that run whole (k <= 9, or Dv <= 128 at 11 x 11). */
 int naf_xna_bwd_chunk_plan(const naf_xna_bwd_args* a, int32_t* out, int cap);
 int naf_xna_bwd(const naf_xna_bwd_args* a, naf_stream_t stream);
 

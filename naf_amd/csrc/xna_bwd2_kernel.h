@@ -1,7 +1,9 @@
 // Cross-scale neighbourhood attention BACKWARD, wave-specialised cell kernel (gfx950 / CDNA4), round 5.
 //
-// Same mathematics and the same operand tricks as xna_bwd_kernel.h (which this kernel replaces for windows up to 9 x 9 whose
-// buffers fit the LDS); what changes is WHO does what and WHEN ("change the round
+// Same mathematics and the same operand tricks as xna_bwd_kernel.h, which this kernel replaces for EVERY window the cell backward serves
+// (dispatch, xna_bwd.hip: 3 x 3 ... 9 x 9 whole at every Dv; 11 x 11 whole up to Dv = 128 and in two channel chunks above; 13 x 13 and
+// 15 x 15 in channel chunks of <= 64; the four-wave kernel only behind the A/B knobs NAF_BWD_V1 / NAF_BWD_BIG8=0 / NAF_BWD_CHUNK11=0);
+// what changes is WHO does what and WHEN ("change the round
 // structure").  The four-wave kernel ran every wave through [S / dP MFMAs behind 32 LDS fragment reads, softmax, dQ, P / dS -> LDS |
 // barrier | dK / dV MFMAs | barrier]: all eight waves of a CU in the same phase at the same time, 1.7 k cycles of MFMAs in a
 // 10 k-cycle round (profiles/r02_xna_bwd_phase.txt).  Here one workgroup = EIGHT waves = one (batch, cell, head), and the waves have roles:

@@ -595,6 +595,23 @@ def xna_backward_select(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor,
     return {_lib.XNA_MFMA: "mfma", _lib.XNA_ROWS: "rows"}.get(sel, "generic")
 
 
+def xna_backward_chunks(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, kernel_size) -> list:
+    """Channel-chunk widths of the launches the cell backward issues for these shapes (``naf_xna_bwd_chunk_plan``): one entry = the
+    whole head in one launch, [] = another kernel serves the call.  dQ carries one bf16 rounding per chunk (include/naf_hip.h)."""
+    lib = _lib.load()
+    ky, kx = (int(kernel_size), int(kernel_size)) if isinstance(kernel_size, int) else (int(kernel_size[0]), int(kernel_size[1]))
+    a = _fill_xna_bwd(q, k_lr, v_lr, q, q, q, q, ky, kx, None)      # shape / alignment query only
+    B, heads, Ho, Wo, Dq = q.shape
+    Dv = v_lr.shape[-1]
+    a.dout_stride = I64x4(Ho * Wo * heads * Dv, Dv, Wo * heads * Dv, heads * Dv)
+    a.dq_stride = I64x4(Ho * Wo * heads * Dq, Dq, Wo * heads * Dq, heads * Dq)
+    out = (C.c_int32 * 16)()
+    n = lib.naf_xna_bwd_chunk_plan(C.byref(a), out, 16)
+    if n < 0:
+        _lib.check(-n, "naf_xna_bwd_chunk_plan")
+    return [int(out[i]) for i in range(min(n, 16))]
+
+
 def xna_backward(q: torch.Tensor, k_lr: torch.Tensor, v_lr: torch.Tensor, dout: torch.Tensor, kernel_size, *,
                  scale: Optional[float] = None, path: str = "auto"):
     """Gradients of ``xna_forward`` w.r.t. q, k_lr, v_lr given ``dout`` (5-D [B, heads, Ho, Wo, Dv], any strides with

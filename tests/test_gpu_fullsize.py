@@ -574,7 +574,7 @@ def test_tail_handover_arm_of_the_sliding_kernel_is_bit_identical(dev):
     """the sliding-window kernel's tail hand-over (xna_slide_kernel.h, STEAL: the last cells of every segment claimed
     cell by cell, finished workgroups take other runs' unclaimed tail cells) was built, measured slower and left OFF
     (profiles/r06_other_workloads.txt); it stays as an A/B arm behind NAF_XNA_STEAL=1.  Which workgroup computes a cell must not change a
-    single bit of it: G2-k11 and a 13 x 13 case with short, uneven segments through the whole forward, default vs the arm, in two
+    single bit of it: G2-k11, a 13 x 13 window and a non-square grid with uneven segments (12, 12, 12, 10 cells) through the whole forward, default vs the arm, in two
     processes (the knob is read once per process)."""
     import hashlib
     import subprocess
@@ -584,17 +584,17 @@ def test_tail_handover_arm_of_the_sliding_kernel_is_bit_identical(dev):
         "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
         "from oracle import naf_oracle as O\n"
         "from naf_amd import NAF\n"
-        "for (S, lr, C, k) in ((512, 32, 1024, 11), (416, 26, 768, 13)):\n"
+        "for (Ho, Wo, lh, lw, C, k) in ((512, 512, 32, 32, 1024, 11), (512, 512, 32, 32, 768, 13), (256, 736, 16, 46, 1024, 11)):\n"
         "    p = O.make_params(seed=61)\n"
         "    m = NAF(kernel_size=k).eval(); m.load_state_dict(p, strict=True); m = m.cuda()\n"
-        "    img = O.hash_normal((1, 3, S, S), 6101).cuda(); ft = O.hash_normal((1, C, lr, lr), 6102).cuda().to(torch.bfloat16)\n"
-        "    out = m(img, ft, (S, S)); torch.cuda.synchronize()\n"
-        "    print('SHA', S, k, hashlib.sha256(out.contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n" % root)
+        "    img = O.hash_normal((1, 3, Ho, Wo), 6101).cuda(); ft = O.hash_normal((1, C, lh, lw), 6102).cuda().to(torch.bfloat16)\n"
+        "    out = m(img, ft, (Ho, Wo)); torch.cuda.synchronize()\n"
+        "    print('SHA', Ho, Wo, k, hashlib.sha256(out.contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n" % root)
     got = {}
     for arm in ("0", "1"):
         env = dict(os.environ, NAF_HIP_KNOBS="1", NAF_XNA_STEAL=arm)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         got[arm] = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
-        assert len(got[arm]) == 2, r.stdout
+        assert len(got[arm]) == 3, r.stdout
     assert got["0"] == got["1"], (got["0"], got["1"])

@@ -799,6 +799,30 @@ def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
             f"{name}: max err {float(err.max()):.3e} mean {float(err.mean()):.3e} (ref max {scale:.3e})"
 
 
+@pytest.mark.parametrize("C,lr,out_sz,ksz,nchunk", [(1024, (12, 13), (48, 208), 11, 2), (1024, (15, 16), (30, 256), 15, 4), (768, (13, 14), (26, 224), 13, 3)])
+def test_chunked_backward_dq_against_the_one_launch_kernel(dev, C, lr, out_sz, ksz, nchunk):
+    """wide heads at 11 x 11 and every head at 13 x 13 / 15 x 15 run the cell backward in channel chunks, and dQ -- a sum over
+    the chunks -- travels through the caller's bf16 buffer: one rounding PER CHUNK (include/naf_hip.h, naf_xna_bwd_chunk_plan).  The
+    row-streaming kernel (path="rows") computes the same dQ in ONE launch with one rounding: against the fp64 oracle the chunked dQ may be
+    worse than that by the extra roundings only (measured 1.1-1.3 x; bound: 1.6 x + 5e-4), and the two agree to bf16 accuracy."""
+    from naf_amd import ops
+    heads = 4
+    q = bf16r(O.hash_normal((1, 256, *out_sz), 561))
+    k = bf16r(O.hash_normal((1, 256, *lr), 562))
+    v = bf16r(O.hash_normal((1, C, *lr), 563))
+    dout = bf16r(O.hash_normal((1, C, *out_sz), 564))
+    rq, _, _ = oracle_xna_backward(dev, q, k, v, dout, ksz, heads)
+    q5, k5, v5, g5 = (to5(t, heads).to(dev) for t in (q, k, v, dout))
+    assert ops.xna_backward_select(q5, k5, v5, ksz) == "mfma" and len(ops.xna_backward_chunks(q5, k5, v5, ksz)) == nchunk
+    back = lambda t5: t5.permute(0, 1, 4, 2, 3).reshape(t5.shape[0], -1, *t5.shape[2:4]).float().cpu()
+    dq_c = back(ops.xna_backward(q5, k5, v5, g5, ksz)[0])
+    dq_r = back(ops.xna_backward(q5, k5, v5, g5, ksz, path="rows")[0])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e_c, e_r, e_cr = rel(dq_c, rq), rel(dq_r, rq), rel(dq_c, dq_r)
+    print("chunked dQ, k %d, %d chunks: %.3e of |dq| from the oracle (one launch: %.3e), %.3e between the two" % (ksz, nchunk, e_c, e_r, e_cr))
+    assert e_r <= 6e-3 and e_c <= 1.6 * e_r + 5e-4 and e_cr <= 8e-3, (e_c, e_r, e_cr)
+
+
 @pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
     (1, 160, 24, 4, (5, 7), (23, 30), 3),       # non-integer ratio (F4 shapes), heads of 40 dims: irregular neighbourhoods, duplicates
     (1, 80, 3, 1, (12, 10), (12, 10), 5),       # ratio 1, one head of 80 (no matrix-core instantiation), C = 3
@@ -825,8 +849,9 @@ def test_xna_backward_table_driven_matches_oracle(dev, B, Cq, C, heads, lr, out_
 def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     """Seeded random geometries of the MFMA cell backward -- every window 3 .. 15, every Dv (13 x 13 and 15 x 15 in channel chunks), row-tile counts that are not multiples of the
     four tiles of a round (dead query waves), one-row cells, several images and heads -- against the independent scalar table-driven
-    kernel (fp32 throughout) on the same bf16 inputs.  Windows up to 7 x 7 run the wave-specialised kernel (xna_bwd2_kernel.h: query
-    waves / key waves, double round buffers), the others the four-wave kernel."""
+    kernel (fp32 throughout) on the same bf16 inputs.  Every window runs the wave-specialised eight-wave kernel (xna_bwd2_kernel.h: query
+    waves / key waves): 3 ... 11 whole (11 x 11 beyond Dv = 128 in two chunks), 13 x 13 / 15 x 15 in channel chunks of <= 64; the four-wave
+    kernel of xna_bwd_kernel.h only behind the A/B knobs NAF_BWD_V1 / NAF_BWD_BIG8=0 / NAF_BWD_CHUNK11=0."""
     from naf_amd import ops
     seed, want = int(os.environ.get("NAF_FUZZ_BWD_SEED", "9753")), int(os.environ.get("NAF_FUZZ_BWD_CASES", "70"))   # campaigns: profiles/r05_fuzz_backward.txt
     rng = np.random.RandomState(seed)
