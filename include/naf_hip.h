@@ -584,6 +584,10 @@ typedef struct naf_forward_args {
     void* phase_events[8];
 } naf_forward_args;
 size_t naf_forward_workspace_bytes(const naf_forward_args* a);
+/* 0.4.2: the same for a given naf_forward_ex `flags`: with NAF_FWD_ONE_STREAM the fourth activation buffer ([B, H, W, 128] bf16, a quarter
+ * of the workspace at 1024^2) is left out -- a call that cannot fork (naf_forward, naf_forward_ex without a lent stream or with
+ * NAF_FWD_ONE_STREAM) accepts that smaller workspace; every other buffer keeps its offset (naf_forward_workspace_view). */
+size_t naf_forward_workspace_bytes_ex(const naf_forward_args* a, uint32_t flags);
 /* 1 when naf_forward serves these arguments, 0 when not (then NAF_ERR_UNSUPPORTED), negative naf_status if invalid. */
 int naf_forward_supported(const naf_forward_args* a);
 /* Every launch on the caller's stream, the two branches' layers alternating (= naf_forward_ex(a, NULL, 0, stream)). */

@@ -207,6 +207,7 @@ SIGNATURES = {
     "naf_xna_bwd_chunk_plan": (C.c_int, [C.POINTER(XnaBwdArgs), C.POINTER(C.c_int32), C.c_int]),
     "naf_xna_bwd": (C.c_int, [C.POINTER(XnaBwdArgs), C.c_void_p]),
     "naf_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ForwardArgs)]),
+    "naf_forward_workspace_bytes_ex": (C.c_size_t, [C.POINTER(ForwardArgs), C.c_uint32]),
     "naf_forward_supported": (C.c_int, [C.POINTER(ForwardArgs)]),
     "naf_forward": (C.c_int, [C.POINTER(ForwardArgs), C.c_void_p]),
 }

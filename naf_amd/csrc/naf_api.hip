@@ -467,6 +467,7 @@ struct StreamJoin {
 };
 struct FwdLayout {
     size_t stats, steal, buf0, buf1, buf2, buf3, cat, guide, keys, vp, q, idx_y, idx_x, total;
+    size_t total_one;   // bytes a ONE-stream forward touches (everything but buf3)
     size_t zeroed;   // bytes from `stats` the forward's one memset clears: the GroupNorm sums and the attention's claim words behind them
     bool fused;   // rotate-on-load: the attention kernel reads the un-rotated guidance, no query buffer
     bool pooled;  // image larger than the output: `guide` = adaptive-average-pooled `cat` (naf.py:34), else guide == cat
@@ -495,7 +496,6 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.buf0 = off;  off = align256(off + px * 128 * 2);
     L.buf1 = off;  off = align256(off + px * 128 * 2);
     L.buf2 = off;  off = align256(off + px * 128 * 2);   // third rotating activation buffer: the two branches' layers alternate
-    L.buf3 = off;  off = align256(off + px * 128 * 2);   // two streams: a ping-pong pair per branch
     L.cat = off;   off = align256(off + px * 256 * 2);
     L.pooled = L.Ho != L.Hs || L.Wo != L.Ws;
     const size_t opx = (size_t)a->B * L.Ho * L.Wo;
@@ -507,6 +507,10 @@ FwdLayout fwd_layout(const naf_forward_args* a) {
     L.q = off;     off = align256(off + (L.fused ? 0 : opx * 256 * 2));
     L.idx_y = off; off = align256(off + (size_t)L.Ho * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
     L.idx_x = off; off = align256(off + (size_t)L.Wo * (a->ksize > 0 ? a->ksize : 1) * sizeof(int32_t));
+    // the fourth activation buffer (two streams: a ping-pong pair per branch) sits LAST, so that a one-stream host can leave it out
+    // without moving anything else (naf_forward_workspace_bytes_ex)
+    L.total_one = off;
+    L.buf3 = off;  off = align256(off + px * 128 * 2);
     L.total = off;
     return L;
 }
@@ -573,6 +577,11 @@ bool fwd_rope_fusable(const naf_forward_args* a) {
 size_t naf_forward_workspace_bytes(const naf_forward_args* a) {
     if (a == nullptr || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->h <= 0 || a->w <= 0 || a->C <= 0 || a->nlayer < 0) return 0;
     return fwd_layout(a).total;
+}
+size_t naf_forward_workspace_bytes_ex(const naf_forward_args* a, uint32_t flags) {
+    if (a == nullptr || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->h <= 0 || a->w <= 0 || a->C <= 0 || a->nlayer < 0) return 0;
+    const FwdLayout L = fwd_layout(a);
+    return (flags & NAF_FWD_ONE_STREAM) ? L.total_one : L.total;
 }
 
 int naf_forward_workspace_view(const naf_forward_args* a, int32_t which, size_t* offset, size_t* bytes) {
@@ -682,13 +691,17 @@ int naf_forward_ex(const naf_forward_args* a, const naf_forward_aux* aux, uint32
         return NAF_ERR_UNSUPPORTED;
     }
     const FwdLayout L = fwd_layout(a);
-    NAF_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= L.total, "naf_forward: workspace of %zu bytes needed, %zu given", L.total, a->workspace_bytes);
+    NAF_REQUIRE((flags & NAF_FWD_ONE_STREAM) == 0 || (flags & NAF_FWD_TWO_STREAMS) == 0, "naf_forward_ex: NAF_FWD_ONE_STREAM and NAF_FWD_TWO_STREAMS are exclusive");
+    // a call that cannot fork (no lent stream, or NAF_FWD_ONE_STREAM) never touches the fourth activation buffer: the smaller
+    // workspace of naf_forward_workspace_bytes_ex(a, NAF_FWD_ONE_STREAM) is enough for it
+    const bool may_fork = aux != nullptr && aux->stream != nullptr && (flags & NAF_FWD_ONE_STREAM) == 0;
+    const size_t ws_need = may_fork ? L.total : L.total_one;
+    NAF_REQUIRE(a->workspace != nullptr && a->workspace_bytes >= ws_need, "naf_forward: workspace of %zu bytes needed, %zu given", ws_need, a->workspace_bytes);
     NAF_REQUIRE(reinterpret_cast<uintptr_t>(a->workspace) % 256 == 0, "naf_forward: workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(a->workspace);
     double* stats = reinterpret_cast<double*>(ws + L.stats);
     const size_t stat_stride = (size_t)NAF_STATS_SLOTS * a->B * 16;   // doubles per (branch, stage): [NAF_STATS_SLOTS][B][8][2]
-    NAF_REQUIRE((flags & NAF_FWD_ONE_STREAM) == 0 || (flags & NAF_FWD_TWO_STREAMS) == 0, "naf_forward_ex: NAF_FWD_ONE_STREAM and NAF_FWD_TWO_STREAMS are exclusive");
     const bool have_aux = aux != nullptr && aux->stream != nullptr;
     NAF_REQUIRE(!have_aux || (aux->fork_event != nullptr && aux->join_event != nullptr), "naf_forward_ex: aux->stream without fork_event / join_event");
     NAF_REQUIRE(!have_aux || aux->stream != stream, "naf_forward_ex: aux->stream must differ from the stream of the call");

@@ -851,6 +851,9 @@ class ForwardPlan:
         self.args, self.lib = a, lib
         self.out_dtype, self.shape_out = out_dtype, (B, Ho, Wo, Cc)
         self.ws_bytes = int(lib.naf_forward_workspace_bytes(C.byref(a))) if self.supported else 0
+        # a forward that runs on ONE stream never touches the fourth activation buffer (C ABI 0.4.2: a quarter of the workspace at 1024^2)
+        self.ws_bytes_one = int(lib.naf_forward_workspace_bytes_ex(C.byref(a), _lib.FWD_ONE_STREAM)) if self.supported else 0
+        self._planned = {}
         self.key = (tuple(image.shape), tuple(image.stride()), image.dtype, tuple(features.shape), tuple(features.stride()), features.dtype,
                     (Ho, Wo))
 
@@ -860,8 +863,11 @@ class ForwardPlan:
 
     def planned_streams(self) -> int:
         """How many streams ``run`` will use (2 = the branches side by side on the lent stream)."""
-        flags = {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)]
-        return int(self.lib.naf_forward_streams(C.byref(self.args), flags))
+        st = int(self.streams)
+        if st not in self._planned:          # a pure function of the geometry and the flag: asked once
+            flags = {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[st]
+            self._planned[st] = int(self.lib.naf_forward_streams(C.byref(self.args), flags))
+        return self._planned[st]
 
     def release_workspaces(self, keep_stream: Optional[int] = None) -> None:
         """Drop the plan's scratch buffers (all of them, or all but the one of raw stream handle ``keep_stream``).  Safe once
@@ -903,16 +909,20 @@ class ForwardPlan:
         # default 8 GiB: at least the current stream's workspace always stays); ``release_workspaces()`` drops all of them.
         skey = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
         pool = self.__dict__.setdefault("_ws_by_stream", {})
+        one = self.planned_streams() == 1       # then the call is made with NAF_FWD_ONE_STREAM and the smaller workspace is enough
+        need = self.ws_bytes_one if one else self.ws_bytes
         ws = pool.pop(skey, None)
+        if ws is not None and ws.numel() < need:
+            ws = None
         if ws is None:
             while pool and (len(pool) >= 4 or (len(pool) + 1) * self.ws_bytes > self.WS_POOL_BYTES):
                 pool.pop(next(iter(pool)))     # least recently used (dicts keep insertion order)
-            ws = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+            ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         pool[skey] = ws
         self._ws = ws                           # the one the last call used (GraphedForward keeps it alive)
         out = torch.empty(self.shape_out, dtype=self.out_dtype, device=dev)
         a.image, a.features, a.out = image.data_ptr(), features.data_ptr(), out.data_ptr()
-        a.workspace, a.workspace_bytes = ws.data_ptr(), self.ws_bytes
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.events[0] = events[0].cuda_event if events else None
         a.events[1] = events[1].cuda_event if events else None
         for i in range(8):     # naf_forward_args.phase_events: hipEvent_t handles at the phase boundaries of the one call
@@ -923,9 +933,9 @@ class ForwardPlan:
             logits = torch.empty((self.shape_out[0], a.heads, self.shape_out[1], self.shape_out[2], a.ksize * a.ksize),
                                  dtype=torch.float32, device=dev)
         a.logits = logits.data_ptr() if logits is not None else None
-        flags = (_lib.FWD_CONV0_EXACT if self.conv0_exact else 0) | {0: 0, 1: _lib.FWD_ONE_STREAM, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)]
+        flags = (_lib.FWD_CONV0_EXACT if self.conv0_exact else 0) | (_lib.FWD_ONE_STREAM if one else {0: 0, 2: _lib.FWD_TWO_STREAMS}[int(self.streams)])
         with torch.cuda.device(dev):
-            if self.streams == 1:
+            if one:
                 rc = self.lib.naf_forward_ex(C.byref(a), None, flags, _stream(image))
             else:
                 with AUX_POOL.lease(skey[0], skey[1]) as aux:

@@ -1559,6 +1559,21 @@ def test_forward_stream_plan_and_flags(dev):
     torch.cuda.synchronize()
     d = (exact.float() - outs[0].float()).abs()
     assert 0.0 < float(d.max()) <= 3e-2 and float(d.mean()) <= 2e-4, (float(d.max()), float(d.mean()))
+    # C ABI 0.4.2: a one-stream call takes the workspace WITHOUT the fourth activation buffer; a call that may fork does not
+    import ctypes as C
+    from naf_amd import _lib, ops
+    assert plan.ws_bytes_one == plan.ws_bytes - ((512 * 512 * 128 * 2 + 255) // 256) * 256 and plan.planned_streams() == 1
+    plan.release_workspaces()
+    again = plan.run(img, ft)                                             # the library's plan here is one stream: the host allocates the smaller one
+    assert plan._ws.numel() == plan.ws_bytes_one and torch.equal(again, outs[0])
+    plan.streams = 2
+    small = torch.empty((plan.ws_bytes_one,), dtype=torch.uint8, device=dev)
+    a = plan.args
+    a.workspace, a.workspace_bytes = small.data_ptr(), small.numel()
+    with ops.AUX_POOL.lease(dev.index or 0, int(torch.cuda.current_stream(dev).cuda_stream)) as aux:
+        rc = plan.lib.naf_forward_ex(C.byref(a), C.byref(aux), _lib.FWD_TWO_STREAMS, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc != 0 and b"workspace" in plan.lib.naf_last_error()
+    plan.streams = 0
     ref = O.naf_forward(p, img.cpu(), ft.float().cpu(), (512, 512), kernel_size=7)
     assert_close(exact.float().cpu(), ref, 2e-2, 1e-2, "forward with exact first-convolution products vs oracle")
     assert_close(outs[0].float().cpu(), ref, 2e-2, 1e-2, "forward with 16-bit first-convolution products vs oracle")
