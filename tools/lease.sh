@@ -32,6 +32,8 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
           done
         done
       done | tee $out/ab.txt ;;
+    collect)     # the round's evidence files (tools/collect_profiles_r06.sh -> gpurun_out/r06)
+      bash tools/collect_profiles_r06.sh 2>&1 | tail -80 | cut -c1-220 ;;
     *) echo "unknown step $step" ;;
   esac
 done
