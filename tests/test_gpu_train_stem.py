@@ -245,7 +245,7 @@ def test_autocast_training_call_uses_the_hip_stem(dev, monkeypatch):
         loss = (out.float() - target).pow(2).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert calls["n"] == 3 * 8                       # eight 128 -> 128 layers, one data-gradient launch each
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     assert out.shape == (1, 32, 64, 64) and all(l == l for l in losses) and losses[-1] != losses[0]   # parameters moved
