@@ -10,7 +10,8 @@ test_forward_train_gradients_match_oracle: P and dS pass through bf16 before con
 
 Every case then repeats the step on the library's own differentiable stem (amp="hip") against the fp32 torch-stem path.
 
-NAF_FUZZ_TRAIN_CASES (default 8) / NAF_FUZZ_TRAIN_SEED select the cases; profiles/r05_fuzz_train.txt is this test with 120 cases.
+NAF_FUZZ_TRAIN_CASES (default 8) / NAF_FUZZ_TRAIN_SEED select the cases; profiles/r05_fuzz_train.txt is this test with 120 cases at the
+default width, profiles/r06_fuzz_train.txt a campaign with the model width drawn as well (round 6: dim 64 ... 512, one or four heads).
 """
 import os
 import random
@@ -51,15 +52,26 @@ def draw_case(seed):
             Ho, Wo = h, w
         if Ho * Wo * k * k > 2.0e6 or k * (Ho // h) > Ho or k * (Wo // w) > Wo:      # the oracle's autograd: seconds per case
             continue
-        return dict(seed=seed, k=k, lr=(h, w), out=(Ho, Wo), C=r.choice([64, 128, 128, 384]), B=r.choice([1, 1, 2]))
+        case = dict(seed=seed, k=k, lr=(h, w), out=(Ho, Wo), C=r.choice([64, 128, 128, 384]), B=r.choice([1, 1, 2]))
+        # round 6: the model WIDTH is drawn too (its own stream of random numbers, so that a seed keeps the geometry it had in round 5):
+        # the default 256 / 4 heads in half of the cases, else a denoising-model width (denoising.py:213: dim 96 ... 512) with one head of
+        # dim channels, or 512 with four heads of 128 -- the HIP stem's general-width kernels (forward, data / weight gradients) and the
+        # row-streaming / scalar attention backward behind them
+        r2 = random.Random(seed * 7919 + 13)
+        dim, heads = r2.choice([(256, 4), (256, 4), (256, 4), (96, 1), (160, 1), (512, 4), (64, 1)])
+        if dim != 256:
+            case["C"] = r2.choice([3, 16, 64])
+        case.update(dim=dim, heads=heads)
+        return case
 
 
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_CASES))
 def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     from naf_amd import NAF, ops
     c = draw_case(seed)
-    p = O.make_params(seed=seed % 89)
-    m = NAF(kernel_size=c["k"]).eval()
+    heads = c["heads"]
+    p = O.make_params(seed=seed % 89, dim=c["dim"], heads_rope=heads)
+    m = NAF(dim=c["dim"], heads_attn=heads, heads_rope=heads, kernel_size=c["k"]).eval()
     m.load_state_dict(p, strict=True)
     m = m.to(dev)
     img = O.hash_normal((c["B"], 3, *c["out"]), seed * 5 + 1)
@@ -67,7 +79,7 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     wgt = O.hash_normal((c["B"], c["C"], *c["out"]), seed * 5 + 3)
     po = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "periods" not in k) for k, v in p.items()}
     fo = ft.clone().requires_grad_(True)
-    ref_out = O.naf_forward(po, img, fo, c["out"], kernel_size=c["k"])
+    ref_out = O.naf_forward(po, img, fo, c["out"], kernel_size=c["k"], heads_attn=heads, heads_rope=heads)
     (ref_out * wgt).sum().backward()
     for prm in m.parameters():
         prm.requires_grad_(True)
@@ -75,9 +87,9 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
     out = m.forward_train(img.to(dev), fd, c["out"], amp=False)
     (out.float() * wgt.to(dev)).sum().backward()
     torch.cuda.synchronize()
-    heads = 4
-    q5 = torch.empty((c["B"], heads, *c["out"], 64), dtype=torch.bfloat16, device=dev)
-    k5 = torch.empty((c["B"], heads, *c["lr"], 64), dtype=torch.bfloat16, device=dev)
+    dq = c["dim"] // heads
+    q5 = torch.empty((c["B"], heads, *c["out"], dq), dtype=torch.bfloat16, device=dev)
+    k5 = torch.empty((c["B"], heads, *c["lr"], dq), dtype=torch.bfloat16, device=dev)
     v5 = torch.empty((c["B"], heads, *c["lr"], c["C"] // heads), dtype=torch.bfloat16, device=dev)
     kern = ops.xna_backward_select(q5, k5, v5, c["k"])
     cell = min(c["out"][0] / c["lr"][0], c["out"][1] / c["lr"][1])
@@ -94,8 +106,8 @@ def test_forward_train_fuzz_against_oracle_autograd(dev, seed):
             worst_name, worst = name, rel
     gs = float(fo.grad.abs().max())
     rel_f = float((fd.grad.float().cpu() - fo.grad).abs().max()) / gs
-    line = "train fuzz %d: k %d lr %s out %s C %d B %d  backward kernel %-7s  out max err %.3e  feature grad %.3e  worst param grad %.3e (%s)" % (
-        seed, c["k"], c["lr"], c["out"], c["C"], c["B"], kern, float(e_out.detach().max()), rel_f, worst, worst_name)
+    line = "train fuzz %d: dim %d / %d head(s) k %d lr %s out %s C %d B %d  backward kernel %-7s  out max err %.3e  feature grad %.3e  worst param grad %.3e (%s)" % (
+        seed, c["dim"], heads, c["k"], c["lr"], c["out"], c["C"], c["B"], kern, float(e_out.detach().max()), rel_f, worst, worst_name)
     print(line)
     bad = e_out > atol + 1e-2 * ref_out.detach().abs()
     assert int(bad.sum()) <= (0 if cell >= 5.0 else 5e-4 * bad.numel() + 1) and float(e_out.max()) <= 3 * atol, line
