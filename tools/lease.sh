@@ -34,6 +34,11 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
       done | tee $out/ab.txt ;;
     collect)     # the round's evidence files (tools/collect_profiles_r06.sh -> gpurun_out/r06)
       bash tools/collect_profiles_r06.sh 2>&1 | tail -80 | cut -c1-220 ;;
+    fuzz)        # campaigns of the two fuzzers (more cases than the suite's defaults): the training path with the model width drawn per case
+      NAF_FUZZ_TRAIN_CASES=${NAF_FUZZ_TRAIN_CASES:-120} NAF_FUZZ_TRAIN_SEED=${NAF_FUZZ_TRAIN_SEED:-7200} timeout 1200 python -m pytest tests/test_gpu_fuzz_train.py -m gpu -q -s > $out/train.log 2>&1; echo "rc=$?" >> $out/train.log
+      grep -cE "^.?train fuzz" $out/train.log; tail -3 $out/train.log | cut -c1-200
+      NAF_FUZZ_CASES=${NAF_FUZZ_CASES:-150} NAF_FUZZ_SEED=${NAF_FUZZ_SEED:-5600} timeout 1200 python -m pytest tests/test_gpu_fuzz_forward.py -m gpu -q -s > $out/forward.log 2>&1; echo "rc=$?" >> $out/forward.log
+      tail -3 $out/forward.log | cut -c1-200 ;;
     *) echo "unknown step $step" ;;
   esac
 done
