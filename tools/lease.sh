@@ -39,6 +39,8 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
       grep -cE "^.?train fuzz" $out/train.log; tail -3 $out/train.log | cut -c1-200
       NAF_FUZZ_CASES=${NAF_FUZZ_CASES:-150} NAF_FUZZ_SEED=${NAF_FUZZ_SEED:-5600} timeout 1200 python -m pytest tests/test_gpu_fuzz_forward.py -m gpu -q -s > $out/forward.log 2>&1; echo "rc=$?" >> $out/forward.log
       tail -3 $out/forward.log | cut -c1-200 ;;
+    denoise)     # the denoising training step at its model widths: HIP stem (auto) vs the torch arms, with a kernel table
+      python tools/denoise_train_time.py --profile > $out/denoise_train.txt 2>&1; grep -E "^NAF|stem_|xna_|Self CUDA" $out/denoise_train.txt | cut -c1-260 ;;
     *) echo "unknown step $step" ;;
   esac
 done
