@@ -60,7 +60,8 @@ def draw_case(seed):
         r2 = random.Random(seed * 7919 + 13)
         dim, heads = r2.choice([(256, 4), (256, 4), (256, 4), (96, 1), (160, 1), (512, 4), (64, 1)])
         if dim != 256:
-            case["C"] = r2.choice([3, 16, 64])
+            c3 = r2.choice([3, 16, 64])
+            case["C"] = c3 if c3 % heads == 0 else 16          # the feature channels split over the heads (attentions.py:50: einops raises otherwise)
         case.update(dim=dim, heads=heads)
         return case
 
