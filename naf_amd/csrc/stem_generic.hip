@@ -133,7 +133,9 @@ __global__ __launch_bounds__(NWG * 64) void stem_conv0_generic_kernel(const Stem
 }
 
 // ---- GroupNorm -> SiLU -> Conv2d(C -> C) --------------------------------------------------------------------------------
-template <int KS>
+// WIDE (C >= 128): weight fragments a tap ahead (below); a separate instantiation, so that the narrow layers keep their registers (with both
+// loops in one kernel the C = 48 layer went from 23 to 38 us: 179 registers instead of ~100).
+template <int KS, bool WIDE>
 __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParams p) {
     constexpr int PH = TH + KS - 1, PW = TW + KS - 1;     // input patch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -204,50 +206,108 @@ __global__ __launch_bounds__(NWG * 64) void stem_convg_kernel(const StemGenParam
     const int noc = C / 16;                                // 16-channel output tiles, dealt round-robin to the waves
     const bf16_t* wb = reinterpret_cast<const bf16_t*>(p.w);
     const int ksteps = (C + 31) / 32;
-    for (int ot = wave; ot < noc; ot += NWG) {
-        f32x4_t acc[TH];
+    // Round 6, wide layers (C >= 128).  The first version loaded each weight fragment right in front of the eight MFMAs that use it (an
+    // L2 round trip per 128 matrix cycles) and read a patch fragment from the LDS per MFMA: at C = 256 the 3x3 layer took 0.74 ms for
+    // 2 x 256^2 pixels (0.21 PFLOP/s; tools/denoise_train_time.py).  Weight fragments a tap ahead: 0.63 ms; two output tiles per wave
+    // pass (a patch fragment feeds two MFMAs) with the fragments of the next four k-steps in flight: 0.50 ms -- still five times its matrix
+    // time: one wave per SIMD (the 95 KB patch leaves one workgroup per CU).  No BASELINE shape runs this kernel.
+    // Narrow layers keep the simple loop in their own instantiation (at C = 48 the prefetching form is slower: 32 against 23 us).
+    // WIDE: a wave takes TWO output tiles at a time, so that a patch fragment read from the LDS feeds two MFMAs, and the weight fragments
+    // of the next four k-steps (2 x 4 x 4 registers) are on their way during the 64 MFMAs of the current four
+    constexpr int OTB = WIDE ? 2 : 1;
+    for (int og = wave; og * OTB < noc; og += NWG) {
+        const int ot0 = og * OTB;
+        f32x4_t acc[OTB][TH];
 #pragma unroll
-        for (int r = 0; r < TH; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const int ic = ks * 32 + grp * 8;
-                bf16x8_t a = {};
-                if (ic < C) a = *reinterpret_cast<const bf16x8_t*>(wb + ((int64_t)tap * C + ot * 16 + col) * C + ic);
+        for (int u = 0; u < OTB; ++u)
 #pragma unroll
-                for (int r = 0; r < TH; ++r) {
-                    bf16x8_t bv = {};
-                    if (ic < C) bv = *reinterpret_cast<const bf16x8_t*>(patch + ((r + ky) * PW + col + kx) * CP + ic);
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[r], 0, 0, 0);
+            for (int r = 0; r < TH; ++r) acc[u][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!WIDE) {       // narrow layers: fragment, then its eight MFMAs
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int ky = tap / KS, kx = tap - ky * KS;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const int ic = ks * 32 + grp * 8;
+                    bf16x8_t a = {};
+                    if (ic < C) a = *reinterpret_cast<const bf16x8_t*>(wb + ((int64_t)tap * C + ot0 * 16 + col) * C + ic);
+#pragma unroll
+                    for (int r = 0; r < TH; ++r) {
+                        bf16x8_t bv = {};
+                        if (ic < C) bv = *reinterpret_cast<const bf16x8_t*>(patch + ((r + ky) * PW + col + kx) * CP + ic);
+                        acc[0][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[0][r], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            const int nh = (ksteps + 3) / 4, nstep = KS * KS * nh;      // steps of (up to) four k-steps inside a tap
+            bf16x8_t wf[2][OTB][4];
+            auto load_step = [&](int st, bf16x8_t (&fr)[OTB][4]) __attribute__((always_inline)) {
+                const int tap = st / nh, h = st - tap * nh;
+#pragma unroll
+                for (int u = 0; u < OTB; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ks = h * 4 + k, ic = ks * 32 + grp * 8;
+                        fr[u][k] = bf16x8_t{};
+                        if (ks < ksteps && ic < C && ot0 + u < noc)
+                            fr[u][k] = *reinterpret_cast<const bf16x8_t*>(wb + ((int64_t)tap * C + (ot0 + u) * 16 + col) * C + ic);
+                    }
+            };
+            auto step_mfmas = [&](int st, const bf16x8_t (&fr)[OTB][4]) __attribute__((always_inline)) {
+                const int tap = st / nh, h = st - tap * nh;
+                const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ks = h * 4 + k, ic = ks * 32 + grp * 8;
+                    if (ks >= ksteps) break;
+#pragma unroll
+                    for (int r = 0; r < TH; ++r) {
+                        bf16x8_t bv = {};
+                        if (ic < C) bv = *reinterpret_cast<const bf16x8_t*>(patch + ((r + ky) * PW + col + kx) * CP + ic);
+#pragma unroll
+                        for (int u = 0; u < OTB; ++u) acc[u][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[u][k], bv, acc[u][r], 0, 0, 0);
+                    }
+                }
+            };
+            load_step(0, wf[0]);
+            for (int st = 0; st < nstep; st += 2) {                     // two steps per trip: the two fragment sets keep their names
+                if (st + 1 < nstep) load_step(st + 1, wf[1]);
+                step_mfmas(st, wf[0]);
+                if (st + 1 < nstep) {
+                    if (st + 2 < nstep) load_step(st + 2, wf[0]);
+                    step_mfmas(st + 1, wf[1]);
                 }
             }
         }
         // epilogue: lane (px = col, grp) holds channels ot*16 + grp*4 + {0..3} of pixel (row r, col)
-        const int c0 = ot * 16 + grp * 4;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < TH; ++r) {
-            const int yy = ty0 + r, xx = tx0 + col;
-            const bool inside = yy < p.H && xx < p.W;
-            bf16x4_t o;
+        for (int u = 0; u < OTB; ++u) {
+            if (ot0 + u >= noc) continue;
+            const int c0 = (ot0 + u) * 16 + grp * 4;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[r][e] + cvec[c0 + e];
-                o[e] = (bf16_t)v;
-                if (inside) { s1[e] += v; s2[e] += v * v; }
-            }
-            if (inside) *reinterpret_cast<bf16x4_t*>(p.y + (int64_t)b * p.ys[0] + (int64_t)yy * p.ys[1] + (int64_t)xx * p.ys[2] + c0) = o;
-        }
-        if (p.stats_out != nullptr) {
+            for (int r = 0; r < TH; ++r) {
+                const int yy = ty0 + r, xx = tx0 + col;
+                const bool inside = yy < p.H && xx < p.W;
+                bf16x4_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = s1[e], q = s2[e];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {      // over the 16 pixel lanes of the row group
-                    a += __shfl_xor(a, o);
-                    q += __shfl_xor(q, o);
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[u][r][e] + cvec[c0 + e];
+                    o[e] = (bf16_t)v;
+                    if (inside) { s1[e] += v; s2[e] += v * v; }
                 }
-                if (col == 0) { s1c[c0 + e] = a; s2c[c0 + e] = q; }     // (ot, grp, e) -> one channel: a single writer
+                if (inside) *reinterpret_cast<bf16x4_t*>(p.y + (int64_t)b * p.ys[0] + (int64_t)yy * p.ys[1] + (int64_t)xx * p.ys[2] + c0) = o;
+            }
+            if (p.stats_out != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = s1[e], q = s2[e];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {      // over the 16 pixel lanes of the row group
+                        a += __shfl_xor(a, o);
+                        q += __shfl_xor(q, o);
+                    }
+                    if (col == 0) { s1c[c0 + e] = a; s2c[c0 + e] = q; }     // (ot, grp, e) -> one channel: a single writer
+                }
             }
         }
     }
@@ -306,5 +366,6 @@ int naf_launch_stem_conv_generic(const naf_stem_conv_args* a, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, blk, lds, s, p);
         return naf_check_launch("stem_convg_kernel");
     };
-    return a->ksize == 1 ? launch(stem_convg_kernel<1>) : launch(stem_convg_kernel<3>);
+    if (C >= 128) return a->ksize == 1 ? launch(stem_convg_kernel<1, true>) : launch(stem_convg_kernel<3, true>);
+    return a->ksize == 1 ? launch(stem_convg_kernel<1, false>) : launch(stem_convg_kernel<3, false>);
 }

@@ -14,7 +14,8 @@
 // consecutive pixels of ITS channel, two reads are the 8 consecutive k of a v_mfma_f32_16x16x32_bf16 operand -- for dY (A operand,
 // lane = oc) and for a (B operand, lane = ic) alike, so both agree on the pixel order by construction.  A workgroup owns one tap,
 // a block of <= 128 output channels and a band of image rows; wave w owns the 16-channel oc tiles {w, w + 4} of the block times all
-// ic tiles (<= 2 x 16 accumulator tiles of 4 registers).  Per 32-pixel segment: stage dY and a, one MFMA per accumulator tile.
+// ic tiles (<= 2 x 16 accumulator tiles of 4 registers).  Per 32-pixel segment: one MFMA per accumulator tile, the next segment's dY and a
+// on their way into the other LDS buffer meanwhile.
 #include "naf_common.h"
 
 namespace {
@@ -44,9 +45,8 @@ template <int KS>
 __global__ __launch_bounds__(256) void stem_wgradg_kernel(const StemWgradGParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.C, PITCH = C + GPAD, nch = C / 8;
-    bf16_t* Dt = reinterpret_cast<bf16_t*>(smem);             // [32 px][PITCH]
-    bf16_t* At = Dt + GSEG * PITCH;                            // [32 px][PITCH]
-    float* cv = reinterpret_cast<float*>(At + GSEG * PITCH);   // [2][C] GroupNorm scale / shift
+    bf16_t* Dt = reinterpret_cast<bf16_t*>(smem);             // [2 buffers][dY: 32 px x PITCH | a: 32 px x PITCH]
+    float* cv = reinterpret_cast<float*>(Dt + 4 * GSEG * PITCH);   // [2][C] GroupNorm scale / shift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tap = blockIdx.y / p.nsplit, split = blockIdx.y - tap * p.nsplit;
@@ -93,47 +93,76 @@ __global__ __launch_bounds__(256) void stem_wgradg_kernel(const StemWgradGParams
     const int nit = (r1 - r0) * p.nseg;
     const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0];
     const bf16_t* xb = p.x + (int64_t)b * p.xs[0];
-    for (int s = 0; s < nit; ++s) {
+    // two LDS buffers: the next segment's global loads are in flight during this segment's MFMAs and land in the other buffer behind them
+    // (the first version staged and multiplied in turns, two barriers per segment; measured the same: 0.78 ms per 3x3 layer at C = 256 either way,
+    // tools/denoise_train_time.py -- the transposing LDS reads, 36 per 32 MFMAs and wave, are what bounds it, as in stem_wgrad.hip)
+    constexpr int NI = 4;                                       // 16-byte items per thread and segment: 32 px x C / 8 chunks / 256 threads <= 4
+    u32x4_t dreg[NI], areg[NI];
+    auto issue = [&](int s) __attribute__((always_inline)) {
         const int y = r0 + s / p.nseg, x0 = (s % p.nseg) * GSEG;
         const int ya = g_reflect(y + ty - KS / 2, p.H);
-        __syncthreads();                                        // the previous segment's fragments have been read
-        for (int i = tid; i < GSEG * nch; i += 256) {
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int i = n * 256 + tid;
+            if (i >= GSEG * nch) continue;
             const int px = i / nch, ch = i - px * nch;
-            u32x4_t d = {0u, 0u, 0u, 0u};
-            if (x0 + px < p.W) d = *reinterpret_cast<const u32x4_t*>(dyb + (int64_t)y * p.dys[1] + (int64_t)(x0 + px) * p.dys[2] + ch * 8);
-            *reinterpret_cast<u32x4_t*>(Dt + px * PITCH + ch * 8) = d;          // past the row: contributes nothing
+            dreg[n] = u32x4_t{0u, 0u, 0u, 0u};                  // past the row: contributes nothing
+            if (x0 + px < p.W) dreg[n] = *reinterpret_cast<const u32x4_t*>(dyb + (int64_t)y * p.dys[1] + (int64_t)(x0 + px) * p.dys[2] + ch * 8);
             const int xa = g_reflect(min(x0 + px, p.W - 1) + tx - KS / 2, p.W);
-            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)ya * p.xs[1] + (int64_t)xa * p.xs[2] + ch * 8);
+            areg[n] = *reinterpret_cast<const u32x4_t*>(xb + (int64_t)ya * p.xs[1] + (int64_t)xa * p.xs[2] + ch * 8);
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        bf16_t* Db = Dt + buf * 2 * GSEG * PITCH;
+        bf16_t* Ab = Db + GSEG * PITCH;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int i = n * 256 + tid;
+            if (i >= GSEG * nch) continue;
+            const int px = i / nch, ch = i - px * nch;
+            *reinterpret_cast<u32x4_t*>(Db + px * PITCH + ch * 8) = dreg[n];
             if (!act) {
-                *reinterpret_cast<u32x4_t*>(At + px * PITCH + ch * 8) = raw;
+                *reinterpret_cast<u32x4_t*>(Ab + px * PITCH + ch * 8) = areg[n];
             } else {
-                const bf16x8_t v = __builtin_bit_cast(bf16x8_t, raw);
+                const bf16x8_t v = __builtin_bit_cast(bf16x8_t, areg[n]);
                 bf16x8_t o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float z = fmaf((float)v[e], cv[ch * 8 + e], cv[C + ch * 8 + e]);
                     o[e] = (bf16_t)(z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)));
                 }
-                *reinterpret_cast<bf16x8_t*>(At + px * PITCH + ch * 8) = o;
+                *reinterpret_cast<bf16x8_t*>(Ab + px * PITCH + ch * 8) = o;
             }
         }
+    };
+    if (nit > 0) {
+        issue(0);
+        commit(0);
         __syncthreads();
+    }
+    for (int s = 0; s < nit; ++s) {
+        const int buf = s & 1;
+        const bf16_t* Db = Dt + buf * 2 * GSEG * PITCH;
+        const bf16_t* Ab = Db + GSEG * PITCH;
+        if (s + 1 < nit) issue(s + 1);
         if (want_db && tid < C) {
 #pragma unroll 8
-            for (int px = 0; px < GSEG; ++px) bsum += (float)Dt[px * PITCH + tid];
+            for (int px = 0; px < GSEG; ++px) bsum += (float)Db[px * PITCH + tid];
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int ot = wave + 4 * m;
             if (ot >= noc) continue;                            // wave-uniform
-            const bf16x8_t fa = frag(Dt, oc0 + ot * 16);
+            const bf16x8_t fa = frag(Db, oc0 + ot * 16);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
                 if (n >= nic) continue;
-                const bf16x8_t fb = frag(At, n * 16);
+                const bf16x8_t fb = frag(Ab, n * 16);
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[m][n], 0, 0, 0);
             }
         }
+        if (s + 1 < nit) commit(buf ^ 1);                       // the other buffer: its readers finished before the barrier of the step before
+        __syncthreads();
     }
     if (want_db && tid < C) atomicAdd(&p.db[tid], bsum);
     // D[oc = 4 (lane >> 4) + r][ic = lane & 15] -> dW[tap][oc][ic]
@@ -174,7 +203,12 @@ int naf_launch_stem_wgrad_generic(const naf_stem_wgrad_args* a, hipStream_t s) {
     if (rows < 1) rows = 1;
     p.rows_per_block = rows;
     const dim3 grid((uint32_t)((a->H + rows - 1) / rows), (uint32_t)(taps * p.nsplit), (uint32_t)a->B);
-    const size_t lds = (size_t)2 * GSEG * (C + GPAD) * 2 + (size_t)2 * C * sizeof(float);
+    const size_t lds = (size_t)4 * GSEG * (C + GPAD) * 2 + (size_t)2 * C * sizeof(float);      // <= 71.7 KB at C = 256
+    const void* fn = a->ksize == 3 ? reinterpret_cast<const void*>(stem_wgradg_kernel<3>) : reinterpret_cast<const void*>(stem_wgradg_kernel<1>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        naf_set_error("naf_stem_wgrad: cannot reserve %zu bytes of LDS", lds);
+        return NAF_ERR_LAUNCH;
+    }
     if (a->ksize == 3) hipLaunchKernelGGL(stem_wgradg_kernel<3>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(stem_wgradg_kernel<1>, grid, dim3(256), lds, s, p);
     return naf_check_launch("stem_wgradg_kernel");

@@ -41,6 +41,9 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
       tail -3 $out/forward.log | cut -c1-200 ;;
     denoise)     # the denoising training step at its model widths: HIP stem (auto) vs the torch arms, with a kernel table
       python tools/denoise_train_time.py --profile > $out/denoise_train.txt 2>&1; grep -E "^NAF|stem_|xna_|Self CUDA" $out/denoise_train.txt | cut -c1-260 ;;
+    gen)         # the general-width stem kernels after a change: their parity tests, then the denoising training step
+      timeout 900 python -m pytest tests -m gpu -q -x -k "any_width or plain_convolution or weight_gradient or act_backward or first_convolution or without_autocast or denoising or F2 or F6 or F7 or fuzz_train" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log | cut -c1-200
+      python tools/denoise_train_time.py --profile > $out/denoise_train.txt 2>&1; grep -E "^NAF|stem_|Self CUDA time" $out/denoise_train.txt | cut -c1-100,200-260 ;;
     *) echo "unknown step $step" ;;
   esac
 done
