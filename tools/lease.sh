@@ -44,6 +44,12 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
     gen)         # the general-width stem kernels after a change: their parity tests, then the denoising training step
       timeout 900 python -m pytest tests -m gpu -q -x -k "any_width or plain_convolution or weight_gradient or act_backward or first_convolution or without_autocast or denoising or F2 or F6 or F7 or fuzz_train" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log | cut -c1-200
       python tools/denoise_train_time.py --profile > $out/denoise_train.txt 2>&1; grep -E "^NAF|stem_|Self CUDA time" $out/denoise_train.txt | cut -c1-100,200-260 ;;
+    driver)      # what the driver does at round end: smoke(), the GPU suite, the default bench line
+      python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+      timeout 1400 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; tail -4 $out/tests.log | cut -c1-200
+      python bench.py --steps 20 > $out/bench20.json 2> $out/bench20.err; python3 -c "
+import json; j = json.load(open('$out/bench20.json')); r = j['roofline']
+print('bench --steps 20: %.2f Mpix/s  %.4f ms (from idle %.4f)  attention %.4f ms = %.4f of the roof; first steps settled %s | from idle %s' % (j['value'], j['ms_per_step'], j['ms_per_step_no_settle'], r['kernel_ms'], r['frac'], j['step_ms']['head'][:4], j['step_ms_no_settle']['head'][:6]))" ;;
     *) echo "unknown step $step" ;;
   esac
 done
