@@ -27,7 +27,9 @@ Parity status
   for it:  **parity unpinned at the NATTEN boundary**.  ``natten_window_start`` restates NATTEN
   <=0.17's published ``get_window_start``; it is pinned only by NATTEN-independent identities
   (tests/test_oracle.py: full-window == dense SDPA, constant-V, unfold interior, two independent
-  derivations -- dilated hi-res form vs low-res window form).
+  derivations -- dilated hi-res form vs low-res window form -- and, since round 6, the definition
+  of dilation itself: delta independent undilated neighbourhood attentions on the strided sub-grids,
+  for every axis length / window / dilation NATTEN accepts, remainder branch included).
 """
 from __future__ import annotations
 

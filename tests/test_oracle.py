@@ -165,6 +165,27 @@ def test_lowres_form_equals_dilated_form(L_in, d, k):
     assert np.array_equal(O.axis_index_table(L_in * d, L_in, k), O.lowres_window_table(L_in * d, L_in, k))
 
 
+def test_dilated_rule_equals_independent_strided_groups():
+    """Fifth NATTEN-independent identity (round 6).  Dilation in neighbourhood attention is DEFINED (DiNAT, Hassani & Shi 2022: dilated
+    neighbourhoods) as delta independent, undilated neighbourhood attentions on the strided sub-grids {m, m + delta, m + 2 delta, ...}: pixel
+    i = m + delta j attends to the clamped k-window around j inside its own sub-grid of length ceil((L - m) / delta).  The restated
+    ``get_window_start`` -- including its remainder branch for axis lengths that are not multiples of the dilation (the non-integer-ratio
+    calls of the notebooks, golden F4 / F9) -- must be exactly that, for every axis length, window and dilation NATTEN accepts (k delta <= L)."""
+    checked = 0
+    for L in range(3, 90):
+        for k in (3, 5, 7, 9, 11, 13, 15):
+            for dil in range(1, 17):
+                if k * dil > L:
+                    continue
+                for i in range(L):
+                    m, j = i % dil, i // dil
+                    n_group = (L - m + dil - 1) // dil                       # pixels of residue class m
+                    start = min(max(j - k // 2, 0), n_group - k)             # plain clamped window inside the sub-grid
+                    assert O.natten_window_start(i, L, k, dil) == m + dil * start, (L, k, dil, i)
+                    checked += 1
+    assert checked > 200000
+
+
 def test_nearest_exact_matches_torch_off_ties():
     for L_in, L_out in [(5, 23), (7, 30), (14, 224), (28, 64), (28, 128), (6, 13), (3, 10)]:
         x = torch.arange(L_in, dtype=torch.float32).view(1, 1, 1, L_in)
