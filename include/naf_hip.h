@@ -54,7 +54,9 @@ extern "C" {
  * 0.4.2 (binary compatible with 0.4.x): the training-side stem entries serve every width the forward serves (multiples of 16 up to
  * 256, the reference's denoising models): naf_stem_wgrad_args and naf_stem_conv0_wgrad_args gain `channels` in what was alignment
  * padding (a zero-initialised struct of an older host reads 0 = 128, struct sizes and all other offsets unchanged), the plain mode
- * of naf_stem_conv_fwd and naf_stem_act_fwd / _bwd lose their 128- / 64-multiple restrictions. */
+ * of naf_stem_conv_fwd and naf_stem_act_fwd / _bwd lose their 128- / 64-multiple restrictions; naf_forward_workspace_bytes_ex; the cell
+ * backward takes cells of 14 / 15 / 28 / 30 ... pixels per row at windows up to 9 x 9 (naf_xna_bwd_supported then says NAF_XNA_MFMA where
+ * 0.4.1 said NAF_XNA_ROWS: no tables / workspace needed any more). */
 /* The copy count is part of the ABI and the export names are DERIVED from it (round 6): a library built with another value
  * (-DNAF_STATS_SLOTS=8) exports naf_stem_conv0_fwd_s8, ..., so that a host holding [16][B][8][2] buffers cannot resolve them. */
 #ifndef NAF_STATS_SLOTS
@@ -453,7 +455,8 @@ int naf_xna_fwd(const naf_xna_args* a, naf_stream_t stream);
  *          ZEROES them on the same stream before the call; the kernel adds every cell's window sums (fp32 atomics).
  *   idx_y, idx_x   optional device int32 tables from naf_axis_index_table, required by the table-driven path.
  * Kernels, like the forward: the MFMA cell kernels (what the MFMA forward serves with ky = kx <= 15, Wo/w a
- * multiple of 16 and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 at every Dv and 11 x 11 up to Dv = 128 on
+ * multiple of 16 -- since 0.4.2, for windows up to 9 x 9, also the widths the forward's row tiles take with a partial last tile: 14
+ * (patch-14 backbones), 15, 28, 30 ... -- and Dv in {32, 64, 96, 128, 192, 256}: windows up to 9 x 9 at every Dv and 11 x 11 up to Dv = 128 on
  * the wave-specialised eight-wave kernel, wider heads at 11 x 11 and every head at 13 x 13 / 15 x 15 on the same kernel in
  * CHANNEL CHUNKS of at most 128 / 64 / 64 value channels per launch -- the softmax does not depend on V, dV splits by channel and dQ / dK are
  * sums over channels, so each launch is a complete backward for its slice and later launches add their dQ to the earlier ones'), the

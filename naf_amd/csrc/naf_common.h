@@ -165,3 +165,11 @@ __device__ __forceinline__ uint32_t naf_xcd_remap(uint32_t bid, uint32_t n) {
     const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return base + idx;
 }
+
+// Row tiles of the attention cell kernels: a 16-query tile is (up to) 16 consecutive pixels of one cell row.  Exact for Wo/w a multiple of 16;
+// for other widths the last tile of a row is partial (masked lanes), taken while at most 1/7 of the row's lanes idle (14-pixel cells of
+// patch-14 backbones, 15, 28, 30, 31 ...).  Forward: xna_mfma_kernel.h / xna_slide_kernel.h; backward: xna_bwd2_kernel.h (PT).
+__host__ __device__ inline bool xna_row_tiles_ok(int dx) {
+    const int pad = ((dx + 15) & ~15) - dx;
+    return pad * 6 <= dx;
+}

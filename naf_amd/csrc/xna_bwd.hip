@@ -33,7 +33,7 @@ static int bwd_next_chunk(int ks, int dv, int left) {
 }
 
 // 1 when the cell kernel serves the request: the forward's MFMA conditions (square odd window 3..15, Dq = 64, integer
-// ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0), Dv in {32, 64, 96, 128, 192, 256} and K/V windows + round buffers
+// ratio, h, w >= window) plus row tiles (Wo/w % 16 == 0; up to 9 x 9 also 14, 15, 28, 30 ...), Dv in {32, 64, 96, 128, 192, 256} and K/V windows + round buffers
 // within 160 KB of LDS (all Dv up to k = 9 in one launch; wider heads at k = 11, 13 and 15 in channel chunks, above).
 int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->ky != a->kx) return 0;
@@ -42,7 +42,10 @@ int naf_xna_bwd_eligible(const naf_xna_bwd_args* a) {
     if (a->Dq != 64) return 0;
     if (a->h < ks || a->w < ks) return 0;
     if (a->Ho % a->h != 0 || a->Wo % a->w != 0) return 0;
-    if ((a->Wo / a->w) % 16 != 0) return 0;
+    // cell rows of whole 16-query tiles -- or (round 6) rows whose last tile is partial, where the forward takes them too (xna_row_tiles_ok: the
+    // 14-pixel cells of patch-14 backbones, 15, 28, 30 ...): windows up to 9 x 9 (the reference's training windows), whole heads
+    const int dx = a->Wo / a->w;
+    if (dx % 16 != 0 && !(xna_row_tiles_ok(dx) && ks <= 9)) return 0;
     switch (a->Dv) {
         case 32: case 64: case 96: case 128: case 192: case 256: break;
         default: return 0;
@@ -69,7 +72,7 @@ int naf_xna_bwd_chunks(const naf_xna_bwd_args* a, int32_t* out, int cap) {
 int naf_launch_xna_bwd(const naf_xna_bwd_args* a, float scale, hipStream_t s) {
     if (!naf_xna_bwd_eligible(a)) {
         naf_set_error(
-            "naf_xna_bwd: needs square odd kernel 3..15, Dq=64, integer ratio with Wo/w %% 16 == 0, h,w >= kernel, "
+            "naf_xna_bwd: needs square odd kernel 3..15, Dq=64, integer ratio with row tiles (Wo/w %% 16 == 0, or 14 / 15 / 28 ... up to 9x9), h,w >= kernel, "
             "Dv in {32,64,96,128,192,256} and 16-byte aligned tensors (got k=%dx%d Dq=%d Dv=%d %dx%d -> %dx%d)",
             a->ky, a->kx, a->Dq, a->Dv, a->h, a->w, a->Ho, a->Wo);
         return NAF_ERR_UNSUPPORTED;

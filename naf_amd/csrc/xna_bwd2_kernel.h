@@ -70,8 +70,15 @@ struct XnaBwd2Geom {
 // CH: a CHANNEL CHUNK of a wider head (xna_bwd.hip: 11 x 11 beyond Dv = 128 runs as chunks of <= 128 on this kernel instead of whole on the four-wave
 // one): dV rows are p.dv_pitch channels apart instead of DV, and launches after the first add their dQ to what is there (p.dq_accum).  A
 // template parameter so that the whole-head instantiations keep their code (their query waves sit at 229-253 of 256 registers).
-template <int KS, int DV, bool CH = false>
+// PT (round 6): PARTIAL row tiles -- cells whose rows are not a multiple of 16 pixels wide (the 14-pixel cells of patch-14 backbones, DINOv2's;
+// 15, 28, 30 ...: xna_row_tiles_ok, as in the forward): the last tile of a row holds fewer than 16 queries.  Its idle lanes load the row's last
+// valid pixel (finite data), take part in every MFMA, and are taken out where a query's contribution leaves the lane: their P / dS rows and
+// their Q / dO row copies go to the LDS as zeros (so the key waves' contractions over queries see nothing of them) and their dQ is not stored.
+// Those shapes ran the row-streaming kernel until now (32^2 -> 448^2, C = 384, window 9: 1.54 ms against 0.13 ms for 28^2 -> 448^2 here).
+// A template parameter so that the whole-tile instantiations keep their code and registers; whole heads only (no channel chunks).
+template <int KS, int DV, bool CH = false, bool PT = false>
 __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) {
+    static_assert(!(CH && PT), "partial row tiles: whole heads only");
     using G = XnaBwdGeom<KS, DV>;
     using G2 = XnaBwd2Geom<KS, DV>;
     constexpr int NSLOT = G::NSLOT, MT = G::MT, KST = G::KST, KROW = G::KROW, VROW = G::VROW, NVT = G::NVT, NVW = G::NVW;
@@ -125,8 +132,9 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
     };
     auto x0_of = [&](int cx) __attribute__((always_inline)) { return min(max(cx - KS / 2, 0), p.w - KS); };
 
-    const int tpr = p.dx >> 4, ntile = p.dy * tpr;
+    const int tpr = PT ? (p.dx + 15) >> 4 : p.dx >> 4, ntile = p.dy * tpr;
     const int nround = (ntile + 3) >> 2;
+    auto cols_of = [&](int tx) __attribute__((always_inline)) { return min(16, p.dx - tx * 16); };   // valid queries of the tile at 16-column block tx
 
     // 16-byte chunk i of window column x (rows y0 .. y0 + KS - 1; per row 8 chunks of K, then Dv/8 of V) -> global address, LDS offset
     constexpr int VCH = DV / 8, RCH = 8 + VCH, CCH = KS * RCH;   // chunks per key, per column
@@ -192,10 +200,16 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
         auto request = [&](bf16x8_t (&qv)[2], bf16x8_t (&gv)[DKS]) __attribute__((always_inline)) {
             const char* qp = reinterpret_cast<const char*>(a_q + (int64_t)a_ty * p.qs[2] + (int64_t)(a_tx * 16) * p.qs[3]);
             const char* gp = reinterpret_cast<const char*>(a_g + (int64_t)a_ty * p.gs[2] + (int64_t)(a_tx * 16) * p.gs[3]);
-            qv[0] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q);
-            qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + lane_q + 64);
+            uint32_t lq = lane_q, lg = lane_g;
+            if constexpr (PT) {        // idle lanes of a row's last tile read the row's last valid pixel
+                const int over = max(col - (cols_of(a_tx) - 1), 0);
+                lq -= (uint32_t)(over * (int)p.qs[3]) * 2u;
+                lg -= (uint32_t)(over * (int)p.gs[3]) * 2u;
+            }
+            qv[0] = *reinterpret_cast<const bf16x8_t*>(qp + lq);
+            qv[1] = *reinterpret_cast<const bf16x8_t*>(qp + lq + 64);
 #pragma unroll
-            for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + lane_g + ks * 64);
+            for (int ks = 0; ks < DKS; ++ks) gv[ks] = *reinterpret_cast<const bf16x8_t*>(gp + lg + ks * 64);
             // one round on (past the last cell the walker stays on the last tile: harmless re-reads)
             if (a_r + 1 < nround) {
                 ++a_r;
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 const int t = 4 * r + wave;
                 const bool live = t < ntile;                       // dead tiles compute on the cell's last tile and contribute zeros
                 const int ty = ty_cur, tx0 = tx_cur * 16;
+                const bool lane_on = !PT || col < cols_of(tx_cur);   // this lane's query exists (PT: the row's last tile may hold fewer than 16)
 
                 if constexpr (!KRES && !KTILE) {
 #pragma unroll
@@ -286,10 +301,18 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                 // row-major LDS copies of the rows: the key waves' B operands
                 bf16_t* qrow = Qs + (wave * 16 + col) * KROW + grp * 8;
                 bf16_t* grow = Gs + (wave * 16 + col) * VROW + grp * 8;
-                *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
-                *reinterpret_cast<bf16x8_t*>(qrow + 32) = qf[1];
+                if constexpr (PT) {
+                    const bf16x8_t z = {};
+                    *reinterpret_cast<bf16x8_t*>(qrow) = lane_on ? qf[0] : z;
+                    *reinterpret_cast<bf16x8_t*>(qrow + 32) = lane_on ? qf[1] : z;
 #pragma unroll
-                for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
+                    for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = lane_on ? gf[ks] : z;
+                } else {
+                    *reinterpret_cast<bf16x8_t*>(qrow) = qf[0];
+                    *reinterpret_cast<bf16x8_t*>(qrow + 32) = qf[1];
+#pragma unroll
+                    for (int ks = 0; ks < DKS; ++ks) *reinterpret_cast<bf16x8_t*>(grow + ks * 32) = gf[ks];
+                }
 
                 // ---- S^T[key][q] = K . Q^T, dP^T[key][q] = V . dO^T: a lane owns one QUERY (softmax statistics, delta and dS^T as the B
                 // operand of dQ^T without any exchange) ----
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) pkv[mt][rr] = live ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
+                    for (int rr = 0; rr < 4; ++rr) pkv[mt][rr] = (live && lane_on) ? (bf16_t)sT[mt][rr] : (bf16_t)0.f;
                 auto write_ps = [&]() __attribute__((always_inline)) {
                     bf16_t* prow = Pq + (wave * 16 + col) * PROW + grp * 4;
                     bf16_t* srow = Sq + (wave * 16 + col) * PROW + grp * 4;
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                     for (int mt = 0; mt < MT; ++mt) {
                         bf16x4_t sk;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) sk[rr] = live ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
+                        for (int rr = 0; rr < 4; ++rr) sk[rr] = (live && lane_on) ? dsf[mt >> 1][(mt & 1) * 4 + rr] : (bf16_t)0.f;
                         if (mt * 16 + 16 <= PROW || mt * 16 + grp * 4 + 4 <= PROW) {     // (9 x 9: the last tile's columns past the row pitch are not stored)
                             *reinterpret_cast<bf16x4_t*>(prow + mt * 16) = pkv[mt];
                             *reinterpret_cast<bf16x4_t*>(srow + mt * 16) = sk;
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void xna_bwd2_kernel(const XnaBwdParams p) 
                         const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
                         const auto r0_ = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                         const auto r1_ = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                        *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0_[0], r1_[0], r0_[1], r1_[1]};
+                        if (lane_on) *reinterpret_cast<u32x4_t*>(dqp + (grp & 1) * 16 + (grp >> 1) * 8 + ct * 16) = u32x4_t{r0_[0], r1_[0], r0_[1], r1_[1]};
                     }
                 }
                 BWD2_STAMP(3);   // dQ
@@ -765,6 +788,15 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
     } else {
         constexpr size_t lds = XnaBwd2Geom<KS, DV>::lds_bytes();
         auto kern = xna_bwd2_kernel<KS, DV>;
+        if ((p.dx & 15) != 0) {      // partial row tiles (patch-14 cells ...): windows up to 9 x 9, whole heads (naf_xna_bwd_eligible)
+            if constexpr (KS <= 9) {
+                if (p.dv_pitch == DV) kern = xna_bwd2_kernel<KS, DV, false, true>;
+            }
+            if (KS > 9 || p.dv_pitch != DV) {
+                naf_set_error("xna_bwd2: cells of %d pixels per row (not a multiple of 16) need a window <= 9 x 9 and the whole head", p.dx);
+                return NAF_ERR_UNSUPPORTED;
+            }
+        } else
         if constexpr ((KS == 11 && DV <= 128) || (KS == 13 && DV <= 64) || (KS == 15 && DV <= 64)) {
             if (p.dv_pitch != DV) kern = xna_bwd2_kernel<KS, DV, true>;     // a channel chunk of a wider head
         } else if (p.dv_pitch != DV) {
@@ -801,7 +833,7 @@ static int xna_bwd2_launch_one(const XnaBwdParams& p, hipStream_t s) {
 template <int KS>
 static int xna_bwd2_launch_ks(const XnaBwdParams& p, int Dv, hipStream_t s) {
     static const bool v1 = [] { const char* e = naf_knob("NAF_BWD_V1"); return e != nullptr && atoi(e) != 0; }();
-    if (v1) return xna_bwd_launch_ks<KS>(p, Dv, s);
+    if (v1 && (p.dx & 15) == 0) return xna_bwd_launch_ks<KS>(p, Dv, s);      // (the four-wave kernel has whole row tiles only)
     switch (Dv) {
         case 32: return xna_bwd2_launch_one<KS, 32>(p, s);
         case 64: return xna_bwd2_launch_one<KS, 64>(p, s);

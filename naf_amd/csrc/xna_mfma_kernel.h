@@ -96,10 +96,7 @@ constexpr size_t xna_mfma_lds_bytes() {
 // rotate-on-load applies.  Exact for Wo/w a multiple of 16; for other widths the last tile of a row is partial (masked
 // lanes), taken while at most 1/7 of the lanes idle (14-pixel cells of patch-14 backbones, 15, 28, 30, 31 ...);
 // narrower cells pack their pixels across rows instead (generic tile loop).
-__host__ __device__ inline bool xna_row_tiles_ok(int dx) {
-    const int pad = ((dx + 15) & ~15) - dx;
-    return pad * 6 <= dx;
-}
+// (xna_row_tiles_ok itself lives in naf_common.h: the attention backward applies the same rule)
 
 // Logical workgroup id of hardware block `bid` (the hardware places block b on XCD b % 8).
 //   order 0: every XCD owns one contiguous band of logical ids (neighbouring K/V windows meet in one L2, but the chip

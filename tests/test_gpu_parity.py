@@ -778,6 +778,12 @@ def test_oracle_on_the_device_equals_the_oracle_on_the_host(dev):
     (1, 768, (13, 14), (26, 224), 13),     # 13x13, Dv = 192: channel chunks 64 x 3 on the eight-wave kernel (dQ of the later launches adds to the first's)
     (1, 512, (15, 16), (30, 256), 15),     # 15x15 (BASELINE configs[2]'s largest window), Dv = 128: chunks 64 + 64 on the eight-wave kernel (P / dS rows of 240 slots)
     (2, 384, (16, 15), (16, 240), 15),     # 15x15, Dv = 96: chunks 64 + 32, one-row cells (three dead waves per round), two images
+    # round 6: PARTIAL row tiles (xna_bwd2_kernel PT) -- cell rows that are not a multiple of 16 pixels, the patch-14 backbones' 14 first
+    (1, 384, (12, 10), (168, 140), 9),     # ratio 14 at the reference's default window, Dv = 96: 14 of a tile's 16 lanes hold a query (row-streaming kernel until round 5)
+    (1, 256, (8, 9), (120, 135), 7),       # ratio 15, Dv = 64
+    (2, 768, (9, 10), (126, 280), 9),      # cells of 14 x 28 pixels: two tiles per row, the second with 12 queries; Dv = 192, two images
+    (1, 1024, (8, 9), (32, 126), 7),       # ratio (4, 14) at Dv = 256: one V key tile from the LDS per round, dead query waves AND idle lanes
+    (1, 128, (5, 6), (150, 180), 5),       # cells of 30 x 30 pixels (16 + 14), Dv = 32
 ])
 def test_xna_backward_matches_oracle(dev, B, C, lr, out_sz, ksz):
     """naf_xna_bwd vs autograd through the oracle's forward, same bf16-rounded q, k, v and output gradient."""
@@ -856,11 +862,11 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
     from naf_amd import ops
     seed, want = int(os.environ.get("NAF_FUZZ_BWD_SEED", "9753")), int(os.environ.get("NAF_FUZZ_BWD_CASES", "70"))   # campaigns: profiles/r05_fuzz_backward.txt
     rng = np.random.RandomState(seed)
-    done = ragged = small = chunked = 0
+    done = ragged = small = chunked = partial = 0
     for _ in range(8 * want):
         ksz = int(rng.choice([3, 5, 7, 7, 7, 9, 11, 13, 15, 15]))
         h, w = int(rng.randint(ksz, ksz + 6)), int(rng.randint(ksz, ksz + 6))
-        dy, dx = int(rng.choice([1, 2, 3, 5, 6, 8, 16])), int(rng.choice([16, 16, 32, 48]))
+        dy, dx = int(rng.choice([1, 2, 3, 5, 6, 8, 16])), int(rng.choice([16, 16, 32, 48, 14, 15, 28, 30]))      # (14 ... 30: partial row tiles, windows <= 9)
         Ho, Wo = h * dy, w * dx
         if Ho * Wo > 160 * 400:
             continue
@@ -879,7 +885,8 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
             err = float((x.float() - y.float()).abs().max())
             assert bool(torch.isfinite(x.float()).all()) and err <= 2.5e-2 * scale + 1e-3, (name, B, heads, h, w, Ho, Wo, ksz, Dv, err, scale)
         done += 1
-        ragged += int((dy * (dx // 16)) % 4 != 0)
+        ragged += int((dy * ((dx + 15) // 16)) % 4 != 0)
+        partial += int(dx % 16 != 0)           # round 6: rows whose last tile holds fewer than 16 queries (windows <= 9)
         small += int(ksz <= 7)
         chunked += int((ksz == 11 and Dv > 128) or (ksz == 13 and Dv > 64) or (ksz == 15 and Dv > 64))
         if os.environ.get("NAF_FUZZ_BWD_CASES"):
@@ -887,7 +894,7 @@ def test_cell_backward_fuzz_against_table_driven_kernel(dev):
                 seed, ksz, h, w, Ho, Wo, B, heads, Dv, " ".join("%.2e" % (float((x.float() - y.float()).abs().max()) / (float(y.float().abs().max()) + 1e-30)) for x, y in zip(a, b))))
         if done >= want:
             break
-    assert done >= 40 and ragged >= 10 and small >= 20 and chunked >= 5, (done, ragged, small, chunked)
+    assert done >= 40 and ragged >= 10 and small >= 20 and chunked >= 3 and partial >= 8, (done, ragged, small, chunked, partial)
 
 
 @pytest.mark.parametrize("B,heads,lr,d,Dv,ksz", [
@@ -969,7 +976,8 @@ def _rows_backward_case(dev, B, Cq, C, heads, lr, out_sz, ksz):
 
 @pytest.mark.parametrize("B,Cq,C,heads,lr,out_sz,ksz", [
     (4, 256, 768, 4, (16, 16), (32, 32), 9),     # the reference's OWN training step (train.py:113-133, config/base.yaml): ratio 2, Dv = 192
-    (1, 256, 384, 4, (12, 10), (168, 140), 9),   # patch-14 backbone (ratio 14: no 16-pixel row tiles for the cell kernel), Dv = 96
+    (1, 256, 384, 4, (12, 12), (132, 132), 11),  # patch-11-like ratio 11 (no row tiles for the cell kernel: 5 of 16 lanes would idle), window 11, Dv = 96
+    (1, 256, 384, 4, (12, 12), (168, 168), 11),  # ratio 14 with an 11 x 11 window: the cell kernel's partial row tiles stop at 9 x 9 (round 6), so this stays here
     (2, 256, 128, 4, (9, 11), (27, 44), 7),      # ratio (3, 4), Dv = 32 through the fragment path, ragged key tiles
     (1, 256, 1024, 4, (15, 15), (60, 60), 15),   # 15 x 15 window as tall as the grid, ratio 4, Dv = 256
     (1, 128, 6, 2, (10, 20), (20, 40), 5),       # ratio 2 with three value channels per head (gather form)

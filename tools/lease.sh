@@ -50,6 +50,9 @@ print('$w steal=$st  step %.4f ms  attention %.4f ms  frac %.4f  mfma_frac %.4f'
       python bench.py --steps 20 > $out/bench20.json 2> $out/bench20.err; python3 -c "
 import json; j = json.load(open('$out/bench20.json')); r = j['roofline']
 print('bench --steps 20: %.2f Mpix/s  %.4f ms (from idle %.4f)  attention %.4f ms = %.4f of the roof; first steps settled %s | from idle %s' % (j['value'], j['ms_per_step'], j['ms_per_step_no_settle'], r['kernel_ms'], r['frac'], j['step_ms']['head'][:4], j['step_ms_no_settle']['head'][:6]))" ;;
+    bwdpt)       # round 6: partial row tiles in the cell backward (patch-14 cells) -- parity, then the patch-14 training point's backward
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz_train.py tests/test_gpu_fullsize.py -m gpu -q -x -s -k "backward or fuzz_train or denoising" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; grep -aE "passed|failed|rc=|Error" $out/tests.log | tail -5 | cut -c1-200
+      python tools/bwd_k15_time.py 2>/dev/null | grep -E "448|k  9" | tee $out/p14.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
