@@ -314,7 +314,9 @@ def test_xna_backward_policy_and_chunk_plan(built_lib):
     assert sel(64, 64, 1024, 1024, 768, 7) == _lib.XNA_MFMA                  # G1
     assert sel(32, 32, 512, 512, 1024, 15) == _lib.XNA_MFMA                  # G2's largest window (round 5: channel chunks)
     assert sel(16, 16, 32, 32, 768, 9) == _lib.XNA_ROWS                      # the reference's own training geometry (ratio 2)
-    assert sel(28, 28, 392, 392, 384, 9) == _lib.XNA_ROWS                    # patch-14 backbone: no 16-pixel row tiles
+    assert sel(28, 28, 392, 392, 384, 9) == _lib.XNA_MFMA                    # patch-14 backbone: 14 of a row tile's 16 lanes (0.4.2: partial row tiles, windows <= 9)
+    assert sel(28, 28, 392, 392, 384, 11) == _lib.XNA_ROWS                   # ... an 11 x 11 window at that ratio stays on the row-streaming kernel
+    assert sel(28, 28, 308, 308, 384, 9) == _lib.XNA_ROWS                    # ratio 11: 5 of 16 lanes would idle (xna_row_tiles_ok), no row tiles
     assert sel(24, 20, 24, 20, 3, 5, heads=1, Dq=80) == _lib.XNA_GENERIC     # head dim without a matrix-core instantiation
     assert sel(64, 64, 1024, 1024, 768, 7, path=_lib.XNA_GENERIC) == _lib.XNA_GENERIC   # the tests' independent reference, any shape
     assert sel(64, 64, 1024, 1024, 768, 7, path=_lib.XNA_ROWS) == _lib.XNA_ROWS
