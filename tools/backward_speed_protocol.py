@@ -11,7 +11,8 @@ import naf_amd
 
 dev = torch.device("cuda:0")
 NUM_RUNS = 10
-POINTS = {"REF448 (reference's point)": (384, 28, 448, 9)}
+POINTS = {"REF448 (reference's point)": (384, 28, 448, 9),
+          "P14 (448^2, patch-14 grid)": (384, 32, 448, 9)}      # a DINOv2-S/14 backbone's 32 x 32 tokens: 14-pixel cells (round 6: cell backward with partial row tiles)
 if "--all" in sys.argv:
     POINTS.update({"448^2 C768": (768, 28, 448, 9), "448^2 C1024 k7": (1024, 28, 448, 7), "G1 (1024^2, C768, k7)": (768, 64, 1024, 7)})
 for name, (C, lr, out, ks) in POINTS.items():
