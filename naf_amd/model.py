@@ -674,7 +674,7 @@ class NAF(nn.Module):
         """Capture this forward for the given shapes in a hipGraph; see ``GraphedForward``."""
         return GraphedForward(self, image, features, output_size, capture_error_mode=capture_error_mode)
 
-    def forward_train(self, image, features, output_size, amp="auto"):
+    def forward_train(self, image, features, output_size, amp="auto", return_weights=False):
         """Differentiable forward for training (train.py:127-137): gradients reach the encoder parameters, the image
         and the features.  The attention and its backward are the HIP kernels (naf_xna_fwd / naf_xna_bwd through
         ``ops.XnaFunction``); the conv stem, RoPE and key pooling run as torch ops so that autograd can
@@ -683,6 +683,8 @@ class NAF(nn.Module):
         has a backward kernel (``ops.xna_backward_select``): the MFMA cell kernel (integer ratio, Wo/w a multiple of 16, window <= 13
         with K/V windows inside the LDS), the row-streaming matrix-core kernel (every other integer ratio: the reference's own training
         geometry 16^2 -> 32^2, patch-14 backbones, the denoising call), the table-driven scalar kernel for the rest.
+        ``return_weights``: also returns the scaled pre-softmax scores [B, heads, Ho, Wo, k*k] of the q / k this step used, fp32, without a
+        gradient (the reference's ``return_weights`` under autograd, attentions.py:64-67; its callers only display them).
         ``amp="auto"`` (the default, and what ``model(image, feats, size)`` uses when a gradient is wanted; round 6) trains through the
         library's own differentiable stem ``_HipStem`` whenever ``image_encoder.stem_impl == "hip"`` and the width has HIP training
         kernels -- with or without ``torch.autocast``: its contract (bf16 activations between layers, fp32 accumulation, fp64 GroupNorm
@@ -734,10 +736,12 @@ class NAF(nn.Module):
             B, C = features.shape[:2]
             v5 = features.reshape(B, heads, C // heads, h, w).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
             out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
-            out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
+            res = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype, bool(return_weights))
+            out5, logits = res if return_weights else (res, None)
             # [B, heads, Ho, Wo, Dv] is a view of a [B, Ho, Wo, heads * Dv] buffer: hand it out as a logical NCHW view of that
             # (channels-last memory, no transpose copy of the largest tensor of the step)
-            return out5.permute(0, 2, 3, 1, 4).reshape(B, ho, wo, C).permute(0, 3, 1, 2)
+            out = out5.permute(0, 2, 3, 1, 4).reshape(B, ho, wo, C).permute(0, 3, 1, 2)
+            return (out, logits) if return_weights else out
         # RoPE (rope.py:15-34,139-153) from the cached tables: angle index t < D/4 -> row, else column
         # [Ho, 2, P], [Wo, 2, P]; in training mode with the reference's coordinate augmentation (rope.py:107-124)
         if enc.rope.training and enc.rope.cache_train_coords:
@@ -762,8 +766,10 @@ class NAF(nn.Module):
         to5 = lambda t, d: t.reshape(B, heads, d, *t.shape[-2:]).permute(0, 1, 3, 4, 2).to(torch.bfloat16).contiguous()
         q5, k5, v5 = to5(xr, Dq), to5(k, Dq), to5(features, C // heads)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
-        out5 = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype)
-        return out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
+        res = ops.XnaFunction.apply(q5, k5, v5, self.upsampler.kernel_size, self.upsampler.scale, out_dtype, bool(return_weights))
+        out5, logits = res if return_weights else (res, None)
+        out = out5.permute(0, 1, 4, 2, 3).reshape(B, C, ho, wo)
+        return (out, logits) if return_weights else out
 
     def forward(self, image, features, output_size, return_weights=False, *args, **kwargs):
         """``naf(image, lr_features, target_size)`` (naf.py:104-116).  The reference's forward is always differentiable;
@@ -774,12 +780,10 @@ class NAF(nn.Module):
         coordinates (the reference's train-mode coordinate jitter only exists on the differentiable path here)."""
         if torch.is_grad_enabled() and (image.requires_grad or features.requires_grad or
                                         (self.training and any(p.requires_grad for p in self.parameters()))):
-            if return_weights:
-                raise NotImplementedError("naf_amd: return_weights is an inference feature (notebooks/attention_maps.ipynb); "
-                                          "call under torch.no_grad() or after .eval()")
             # the library's own differentiable stem whenever it serves the width, with or without torch.autocast (round 6: the
-            # bf16-activation contract is what the inference path computes); else the torch stem in the ambient precision
-            return self.forward_train(image, features, output_size, amp="auto")
+            # bf16-activation contract is what the inference path computes); else the torch stem in the ambient precision.
+            # return_weights (attentions.py:64-67 under autograd): (out, scores) with the scores as a non-differentiable output
+            return self.forward_train(image, features, output_size, amp="auto", return_weights=return_weights)
         with torch.no_grad():
             return self._forward_inference(image, features, output_size, return_weights)
 

@@ -702,16 +702,25 @@ class XnaFunction(torch.autograd.Function):
     """Differentiable ``xna_forward``: forward = naf_xna_fwd, backward = naf_xna_bwd (MFMA or table-driven kernels)."""
 
     @staticmethod
-    def forward(ctx, q, k_lr, v_lr, kernel_size, scale, out_dtype):
+    def forward(ctx, q, k_lr, v_lr, kernel_size, scale, out_dtype, *rest):
+        return_logits = bool(rest[0]) if rest else False       # optional seventh argument
+        ctx.nrest = len(rest)
         ctx.save_for_backward(q, k_lr, v_lr)
         ctx.kernel_size, ctx.scale = kernel_size, scale
+        if return_logits:
+            # return_weights on a gradient-enabled call (attentions.py:64-67 works under autograd): the scaled pre-softmax scores of the
+            # very q / k this differentiable step uses, as a second output WITHOUT a gradient (nothing in the reference's callers
+            # differentiates through them: notebooks/attention_maps.ipynb reads them for display)
+            out, logits = xna_forward(q, k_lr, v_lr, kernel_size, out_dtype=out_dtype, path="auto", scale=scale, return_logits=True)
+            ctx.mark_non_differentiable(logits)
+            return out, logits
         return xna_forward(q, k_lr, v_lr, kernel_size, out_dtype=out_dtype, path="auto", scale=scale)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *unused):
         q, k_lr, v_lr = ctx.saved_tensors
         dq, dk, dv = xna_backward(q, k_lr, v_lr, dout, ctx.kernel_size, scale=ctx.scale)
-        return dq, dk.to(k_lr.dtype), dv.to(v_lr.dtype), None, None, None
+        return (dq, dk.to(k_lr.dtype), dv.to(v_lr.dtype), None, None, None) + (None,) * ctx.nrest
 
 
 def xna_rope_fusable(q: torch.Tensor, lr_size, Dv: int, kernel_size, rope_tables, out_dtype=torch.bfloat16,
