@@ -53,6 +53,9 @@ print('bench --steps 20: %.2f Mpix/s  %.4f ms (from idle %.4f)  attention %.4f m
     bwdpt)       # round 6: partial row tiles in the cell backward (patch-14 cells) -- parity, then the patch-14 training point's backward
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz_train.py tests/test_gpu_fullsize.py -m gpu -q -x -s -k "backward or fuzz_train or denoising" > $out/tests.log 2>&1; echo "rc=$?" >> $out/tests.log; grep -aE "passed|failed|rc=|Error" $out/tests.log | tail -5 | cut -c1-200
       python tools/bwd_k15_time.py 2>/dev/null | grep -E "448|k  9" | tee $out/p14.txt ;;
+    bwdfuzz)     # the cell-backward fuzz as a campaign (partial row tiles included)
+      NAF_FUZZ_BWD_SEED=${NAF_FUZZ_BWD_SEED:-6161} NAF_FUZZ_BWD_CASES=${NAF_FUZZ_BWD_CASES:-300} timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "test_cell_backward_fuzz" > $out/bwd.log 2>&1; echo "rc=$?" >> $out/bwd.log
+      grep -ac "^bwd fuzz" $out/bwd.log; grep -aE "passed|failed|rc=" $out/bwd.log | tail -3 ;;
     *) echo "unknown step $step" ;;
   esac
 done
