@@ -55,6 +55,10 @@ WORKLOADS = {
     # cells other than 16 x 16 pixels at the reference's timing size: a patch-14 backbone's grid (448 / 14 = 32) and a ratio-8 call
     "P14": (384, 32, 448, 9),
     "R8": (384, 56, 448, 9),
+    # the reference's DEFAULT window (NAF() / the released checkpoint: kernel_size 9) at the BASELINE sizes -- not BASELINE configurations
+    # (those say window 7), but what a user of hubconf.naf() runs
+    "G1-k9": (768, 64, 1024, 9),
+    "G3-k9": (1024, 64, 1024, 9),
 }
 PUBLISHED_MPIX = {"REF448": 3.57}   # BASELINE.md numbers for the exact configuration (other hardware)
 
