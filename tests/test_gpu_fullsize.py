@@ -359,7 +359,8 @@ def test_bench_multi_rank_path_dry_run(dev, launcher, world, total):
     assert j["weak_leg"]["images_per_gpu"] == min(8, total // world) and j["weak_leg"]["ms_all_ranks_busy"] > 0 and j["weak_leg"]["ms_rank0_alone"] > 0
     ph = j["phases_ms"]
     assert ph["stem"] > 0 and ph["rope_pool"] > 0 and ph["attention"] > 0 and ph["stem_conv3"] > 0
-    assert 0 < j["roofline"]["frac_with_prepass"] < j["roofline"]["frac"]
+    # (<=: with eight processes time-slicing one GPU the attention launch takes so long that the 5 us pre-pass vanishes in the fourth decimal)
+    assert 0 < j["roofline"]["frac_with_prepass"] <= j["roofline"]["frac"]
 
 
 @pytest.mark.parametrize("amp", ["auto", False])
