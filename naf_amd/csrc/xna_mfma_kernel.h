@@ -83,13 +83,17 @@ constexpr int XNA_ROPE_ROWS = 16;   // cell rows whose RoPE row tables ride in L
 // LDS bytes: K window [NSLOT][64+8] + V window [NSLOT][dvt+16] (pad key slots are NOT stored: their reads are
 // clamped to the last real row, P is exactly 0 there) + optional per-wave output staging tiles + (staged) the cell's
 // RoPE row tables [16][32] fp32 and, in 8-wave workgroups (two of which share a CU: LDS to spare), its column tables too.
-constexpr size_t xna_mfma_lds_for(int ks, int cb, int dvt, bool staged, int nw = 4) {
+// hs (round 6): HALF-row staging -- the per-wave store tile holds hs of the dvt channels at a time ([16 px][hs], flushed as runs of 2 hs
+// bytes per pixel: whole 128-byte lines for hs = 64 / 128) instead of the whole row.  What it buys is LDS: at Dv = 256 the whole-row tiles
+// of eight waves are 64 KB and ONE eight-wave workgroup (or two four-wave ones: eight waves in flight) fits a CU; with hs = 128 two
+// eight-wave workgroups do, the sixteen waves per CU G1's width has had since round 2.
+constexpr size_t xna_mfma_lds_for(int ks, int cb, int dvt, bool staged, int nw = 4, int hs = 0) {
     return (size_t)((ks + cb - 1) * (ks + cb - 1)) * (72 + dvt + 16) * 2 +
-           (staged ? (size_t)nw * 16 * xna_stage_row(dvt) * 2 + (size_t)(nw >= 8 ? 2 : 1) * XNA_ROPE_ROWS * 32 * 4 : 0);
+           (staged ? (size_t)nw * 16 * xna_stage_row(hs > 0 ? hs : dvt) * 2 + (size_t)(nw >= 8 ? 2 : 1) * XNA_ROPE_ROWS * 32 * 4 : 0);
 }
-template <int KS, int CB, int DVT, bool STG, int NW = 4>
+template <int KS, int CB, int DVT, bool STG, int NW = 4, int HS = 0>
 constexpr size_t xna_mfma_lds_bytes() {
-    return xna_mfma_lds_for(KS, CB, DVT, STG, NW);
+    return xna_mfma_lds_for(KS, CB, DVT, STG, NW, HS);
 }
 
 // Row tiles: a 16-query tile is (up to) 16 consecutive pixels of ONE cell row -- all tile bookkeeping is wave-uniform and
@@ -138,7 +142,7 @@ __device__ __forceinline__ void xna_store4(float* dst, f32x4_t v) { *reinterpret
         var = __builtin_readcyclecounter();               \
         __builtin_amdgcn_sched_barrier(0);                \
     }
-template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4, int TPW = 1>
+template <int KS, int DVT, typename OutT, bool STG = false, int CB = 1, int ABL = 0, int NW = 4, int TPW = 1, int HS = 0>
 __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p) {
     constexpr int NT = NW * 64;  // threads per workgroup
     using G = XnaGeom<KS, CB>;
@@ -146,7 +150,11 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     constexpr int VROW = XnaVRow<DVT>::VROW;
     constexpr int CT = DVT / 16;
     constexpr int VCH = DVT / 8;  // 16-byte chunks per V row
-    using ST = XnaStageTile<DVT>;
+    // the staged piece: the whole DVT-channel row of a pixel, or (HS) HS channels of it at a time
+    static_assert(HS == 0 || (STG && HS % 32 == 0 && DVT % HS == 0 && HS < DVT), "half-row staging: staged plans, a proper divisor of the Dv tile");
+    constexpr int SW = HS > 0 ? HS : DVT;          // channels per staged piece
+    constexpr int SCT = SW / 16, SVCH = SW / 8;    // ... channel tiles, 16-byte chunks per pixel
+    using ST = XnaStageTile<SW>;
     constexpr int OROW = ST::OROW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -394,14 +402,14 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     };
     // store pieces of the staged path: 16-byte chunk i = it*64 + lane of the wave's [16 px][DVT] tile; its LDS
     // offset and its byte offset from the tile's first pixel are per-lane constants of the whole kernel
-    constexpr int NCH = 16 * VCH;            // 16-byte chunks in a tile
+    constexpr int NCH = 16 * SVCH;           // 16-byte chunks in a staged piece of a tile
     constexpr int NIT = STG ? (NCH + 63) / 64 : 1;
     int st_lds[NIT], st_pp[NIT];
     uint32_t st_goff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = min(it * 64 + lane, NCH - 1);
-        const int pp = i / VCH, ch = i - pp * VCH;
+        const int pp = i / SVCH, ch = i - pp * SVCH;
         st_pp[it] = pp;
         st_lds[it] = ST::offset(pp, ch);
         st_goff[it] = (uint32_t)(pp * (int)p.os[3] + ch * 8) * (uint32_t)sizeof(OutT);
@@ -698,6 +706,37 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                         fa[ks][4] = hi[0]; fa[ks][5] = hi[1]; fa[ks][6] = hi[2]; fa[ks][7] = hi[3];
                     }
                 };
+                // the staged piece (channel tiles cbase .. cbase + SCT - 1 of the tile) -> memory
+                const int t0 = tv[0] * 16;
+                auto flush_piece = [&](int cbase) __attribute__((always_inline)) {
+                    char* obase = reinterpret_cast<char*>(obv[0]) + cbase * 16 * (int)sizeof(OutT);
+                    // Whole tiles (cell width a multiple of 16: every BASELINE shape): all LDS reads are issued, then all stores.
+                    // Behind a per-store predicate each store sits in its own exec-masked block -- ds_read, s_waitcnt lgkmcnt(0),
+                    // store, six times in a row (1.8 k of the 6 k cycles a tile takes, profiles/r02_xna_phase_timing.txt).
+                    if (FAST && (NCH % 64 == 0) && !(ABL & (1 | 8192)) && (p.dx & 15) == 0) {   // (ABL 8192: probe keeps the predicated form)
+                        u32x4_t wv[NIT];
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) wv[it] = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(obase + st_goff[it]) = wv[it];
+                    } else
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
+                            const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
+                            if (ABL & 1) {
+                                asm volatile("" ::"v"(wv));
+                            } else if constexpr (FAST) {
+                                if (tx0v[0] + st_pp[it] < p.dx) *reinterpret_cast<u32x4_t*>(obase + st_goff[it]) = wv;
+                            } else {
+                                const int pp = (it * 64 + lane) / SVCH, ch = (it * 64 + lane) - pp * SVCH;
+                                const int sp = min(t0 + pp, npix - 1);
+                                const int yy = sp / p.dx, xx = sp - yy * p.dx;
+                                if (t0 + pp < npix) *reinterpret_cast<u32x4_t*>(obv[0] + yy * p.os[2] + xx * p.os[3] + cbase * 16 + ch * 8) = wv;
+                            }
+                        }
+                    }
+                };
                 bf16x8_t vf[2][2][KST];
                 if (!(ABL & 2)) {
                     vt_frag(0, vf[0][0]);
@@ -732,36 +771,13 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
                     const u32x2_t ua = __builtin_bit_cast(u32x2_t, ab), ub = __builtin_bit_cast(u32x2_t, bb);
                     const auto r0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
-                    *reinterpret_cast<u32x4_t*>(ow + ST::offset(col, ct * 2 + ochunk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-                }
-                const int t0 = tv[0] * 16;
-                XNA_TSTAMP(t_c)
-                // Whole tiles (cell width a multiple of 16: every BASELINE shape): all LDS reads are issued, then all stores.
-                // Behind a per-store predicate each store sits in its own exec-masked block -- ds_read, s_waitcnt lgkmcnt(0),
-                // store, six times in a row (1.8 k of the 6 k cycles a tile takes, profiles/r02_xna_phase_timing.txt).
-                if (FAST && (NCH % 64 == 0) && !(ABL & (1 | 8192)) && (p.dx & 15) == 0) {   // (ABL 8192: probe keeps the predicated form)
-                    u32x4_t wv[NIT];
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) wv[it] = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv[it];
-                } else
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    if ((NCH % 64 == 0) || it * 64 + lane < NCH) {
-                        const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(ow + st_lds[it]);
-                        if (ABL & 1) {
-                            asm volatile("" ::"v"(wv));
-                        } else if constexpr (FAST) {
-                            if (tx0v[0] + st_pp[it] < p.dx) *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(obv[0]) + st_goff[it]) = wv;
-                        } else {
-                            const int pp = (it * 64 + lane) / VCH, ch = (it * 64 + lane) - pp * VCH;
-                            const int sp = min(t0 + pp, npix - 1);
-                            const int yy = sp / p.dx, xx = sp - yy * p.dx;
-                            if (t0 + pp < npix) *reinterpret_cast<u32x4_t*>(obv[0] + yy * p.os[2] + xx * p.os[3] + ch * 8) = wv;
-                        }
+                    *reinterpret_cast<u32x4_t*>(ow + ST::offset(col, (ct % SCT) * 2 + ochunk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    if constexpr (HS > 0) {
+                        if ((ct + 2) % SCT == 0) flush_piece(ct + 2 - SCT);     // HS channels of the tile are in the LDS: they leave as 2 HS bytes per pixel
                     }
                 }
+                XNA_TSTAMP(t_c)
+                if constexpr (HS == 0) flush_piece(0);
             } else {
                 constexpr bool kWide = (sizeof(OutT) == 2) && !(ABL & 64);
                 constexpr int CTP = kWide ? (CT & ~1) : 0;   // tiles stored as pairs (16 B per lane)
@@ -875,11 +891,11 @@ __global__ __launch_bounds__(NW * 64) void xna_mfma_kernel(const XnaMfmaParams p
     }
 }
 
-template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4>
+template <int KS, int DVT, typename OutT, bool STG, int CB, int TPW = 1, int NW = 4, int HS = 0>
 static int xna_mfma_launch_one(const XnaMfmaParams& p, hipStream_t s) {
-    constexpr size_t lds = xna_mfma_lds_bytes<KS, CB, DVT, STG, NW>();
+    constexpr size_t lds = xna_mfma_lds_bytes<KS, CB, DVT, STG, NW, HS>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = xna_mfma_kernel<KS, DVT, OutT, STG, CB, 0, NW, TPW>;
+    auto kern = xna_mfma_kernel<KS, DVT, OutT, STG, CB, 0, NW, TPW, HS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -907,6 +923,7 @@ struct XnaMfmaPlan {
     bool staged;  // whole-row stores through LDS (bf16 output)
     int tpw;      // 16-query tiles a wave processes together (2: K / V^T fragments feed two MFMAs each)
     size_t lds;
+    int hs;       // staged plans: 0 = whole rows, else channels per staged piece (half-row staging, eight-wave workgroups)
 };
 
 // Windows of 11x11 and up are LDS/MFMA-bound (G2, k = 11 / 15): pair the tiles.  Smaller windows are HBM-bound
@@ -919,6 +936,22 @@ constexpr int xna_mfma_nw(int ks, int cb, int dvt, bool staged) {
     if (!staged) return xna_mfma_lds_for(ks, cb, dvt, false) > 80 * 1024 ? 8 : 4;
     return ((160 * 1024) / xna_mfma_lds_for(ks, cb, dvt, true, 4) < 4 && xna_mfma_lds_for(ks, cb, dvt, true, 8) <= 80 * 1024) ? 8 : 4;
 }
+
+// Half-row staging (round 6): taken where the whole-row staged plan keeps fewer than sixteen waves per CU in flight and two EIGHT-wave
+// workgroups fit with store tiles of hs channels (128, else 64: runs of whole 128-byte lines).  Dv = 256 at 7 x 7 (BASELINE's G2 / G3
+// width) with hs = 128, the reference's default 9 x 9 window at Dv = 192 / 256 with hs = 64.  0: keep whole rows (G1: sixteen waves already).
+// NAF_XNA_HS=0 (with NAF_HIP_KNOBS=1): never (A/B).
+constexpr int xna_mfma_hs(int ks, int cb, int dvt) {
+    if (xna_mfma_tpw(ks) != 1 || dvt % 32 != 0) return 0;
+    const size_t whole4 = xna_mfma_lds_for(ks, cb, dvt, true, 4), whole8 = xna_mfma_lds_for(ks, cb, dvt, true, 8);
+    const int nw_whole = ((160 * 1024) / whole4 < 4 && whole8 <= 80 * 1024) ? 8 : 4;
+    const int waves_whole = (int)((160 * 1024) / (nw_whole == 8 ? whole8 : whole4)) * nw_whole;
+    if (waves_whole >= 16) return 0;
+    if (128 < dvt && dvt % 128 == 0 && xna_mfma_lds_for(ks, cb, dvt, true, 8, 128) <= 80 * 1024) return 128;
+    if (64 < dvt && dvt % 64 == 0 && xna_mfma_lds_for(ks, cb, dvt, true, 8, 64) <= 80 * 1024) return 64;
+    return 0;
+}
+
 
 // The largest Dv tile that divides Dv and fits 160 KiB; 2x2 cell blocks when free (KS = 7, 15) and they fit;
 // staged whole-row stores for bf16 output when the tile count is even and the staging tiles still fit.
@@ -939,9 +972,13 @@ inline bool xna_mfma_plan(int ks, int Dv, int out_dtype, XnaMfmaPlan* pl) {
                 // for 3: with the window staging batched and dispatch-order workgroups, two staged 4-wave workgroups beat
                 // the sliding kernel at k = 7, Dv = 256: G3 0.565 -> 0.530 ms, G2-k7 0.157 -> 0.139 ms, gpurun r2w.)
                 if (st && force == 0) continue;
-                if (st && force != 1 && (int)(160 * 1024 / lds) < 2) continue;
+                static const bool no_hs = [] { const char* e = naf_knob("NAF_XNA_HS"); return e && atoi(e) == 0; }();   // A/B knob
+                const int hs = (st != 0 && !no_hs) ? xna_mfma_hs(ks, cb, c) : 0;
+                if (st && force != 1 && (int)(160 * 1024 / lds) < 2 && hs == 0) continue;   // (half-row tiles may still fit two workgroups)
                 if (lds <= 160 * 1024) {
                     pl->dvt = c; pl->cb = cb; pl->staged = st != 0; pl->tpw = tpw; pl->lds = lds;
+                    pl->hs = hs;
+                    if (pl->hs) pl->lds = xna_mfma_lds_for(ks, cb, c, true, 8, pl->hs);
                     return true;
                 }
             }
@@ -955,8 +992,13 @@ static int xna_mfma_launch_ks(const XnaMfmaParams& p, const XnaMfmaPlan& pl, int
     constexpr int CBM = xna_mfma_cb(KS);
 #define NAF_TRY(D, ST, CBV, T)                                                              \
     if constexpr (xna_mfma_lds_for(KS, CBV, D, ST) <= 160 * 1024 && (!(ST) || ((D % 32 == 0) && xna_mfma_tpw(KS) == 1))) \
-        if (pl.dvt == D && pl.staged == ST && pl.cb == CBV)                                     \
-            return xna_mfma_launch_one<KS, D, T, ST, CBV, xna_mfma_tpw(KS), xna_mfma_nw(KS, CBV, D, ST)>(p, s);
+        if (pl.dvt == D && pl.staged == ST && pl.cb == CBV) {                                   \
+            if constexpr ((ST) && xna_mfma_hs(KS, CBV, D) > 0) {                                \
+                if (pl.hs == xna_mfma_hs(KS, CBV, D))                                           \
+                    return xna_mfma_launch_one<KS, D, T, ST, CBV, xna_mfma_tpw(KS), 8, xna_mfma_hs(KS, CBV, D)>(p, s); \
+            }                                                                                   \
+            return xna_mfma_launch_one<KS, D, T, ST, CBV, xna_mfma_tpw(KS), xna_mfma_nw(KS, CBV, D, ST)>(p, s); \
+        }
 #define NAF_CASE(D)                                   \
     if (out_dtype == NAF_BF16) {                      \
         NAF_TRY(D, true, CBM, bf16_t)                 \

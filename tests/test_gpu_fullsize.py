@@ -571,13 +571,9 @@ def test_edge_inputs_empty_batch_dtypes_and_strides(dev):
         m(img.to(dev), ft.to(dev), (2, 64))                            # output smaller than the feature grid (dilation 0)
 
 
-def test_tail_handover_arm_of_the_sliding_kernel_is_bit_identical(dev):
-    """VERDICT r05 item 2: the sliding-window kernel's tail hand-over (xna_slide_kernel.h, STEAL: the last cells of every segment claimed
-    cell by cell, finished workgroups take other runs' unclaimed tail cells) was built, measured slower and left OFF
-    (profiles/r06_other_workloads.txt); it stays as an A/B arm behind NAF_XNA_STEAL=1.  Which workgroup computes a cell must not change a
-    single bit of it: G2-k11, a 13 x 13 window and a non-square grid with uneven segments (12, 12, 12, 10 cells) through the whole forward, default vs the arm, in two
-    processes (the knob is read once per process)."""
-    import hashlib
+def _forward_hashes(cases, env_extra):
+    """SHA-256 of the bf16 output of ``naf(image, feats, size)`` for every (Ho, Wo, lh, lw, C, k) of ``cases``, in a fresh process with
+    ``env_extra`` set (the library reads its A/B knobs once per process)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -585,20 +581,38 @@ def test_tail_handover_arm_of_the_sliding_kernel_is_bit_identical(dev):
         "import sys, hashlib, torch; sys.path.insert(0, %r)\n"
         "from oracle import naf_oracle as O\n"
         "from naf_amd import NAF\n"
-        "for (Ho, Wo, lh, lw, C, k) in ((512, 512, 32, 32, 1024, 11), (512, 512, 32, 32, 768, 13), (256, 736, 16, 46, 1024, 11)):\n"
+        "for (Ho, Wo, lh, lw, C, k) in %r:\n"
         "    p = O.make_params(seed=61)\n"
         "    m = NAF(kernel_size=k).eval(); m.load_state_dict(p, strict=True); m = m.cuda()\n"
         "    img = O.hash_normal((1, 3, Ho, Wo), 6101).cuda(); ft = O.hash_normal((1, C, lh, lw), 6102).cuda().to(torch.bfloat16)\n"
         "    out = m(img, ft, (Ho, Wo)); torch.cuda.synchronize()\n"
-        "    print('SHA', Ho, Wo, k, hashlib.sha256(out.contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n" % root)
-    got = {}
-    for arm in ("0", "1"):
-        env = dict(os.environ, NAF_HIP_KNOBS="1", NAF_XNA_STEAL=arm)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got[arm] = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
-        assert len(got[arm]) == 3, r.stdout
-    assert got["0"] == got["1"], (got["0"], got["1"])
+        "    print('SHA', Ho, Wo, k, hashlib.sha256(out.contiguous().view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n" % (root, tuple(cases)))
+    env = dict(os.environ, NAF_HIP_KNOBS="1", **env_extra)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
+    assert len(got) == len(cases), r.stdout
+    return got
+
+
+def test_tail_handover_arm_of_the_sliding_kernel_is_bit_identical(dev):
+    """VERDICT r05 item 2: the sliding-window kernel's tail hand-over (xna_slide_kernel.h, STEAL: the last cells of every segment claimed
+    cell by cell, finished workgroups take other runs' unclaimed tail cells) was built, measured slower and left OFF
+    (profiles/r06_other_workloads.txt); it stays as an A/B arm behind NAF_XNA_STEAL=1.  Which workgroup computes a cell must not change a
+    single bit of it: G2-k11, a 13 x 13 window and a non-square grid with uneven segments (12, 12, 12, 10 cells) through the whole forward,
+    default vs the arm, in two processes."""
+    cases = ((512, 512, 32, 32, 1024, 11), (512, 512, 32, 32, 768, 13), (256, 736, 16, 46, 1024, 11))
+    assert _forward_hashes(cases, {"NAF_XNA_STEAL": "0"}) == _forward_hashes(cases, {"NAF_XNA_STEAL": "1"})
+
+
+def test_half_row_staging_of_the_cell_kernel_is_bit_identical(dev):
+    """Round 6: where the whole-row store tiles of the cell kernel leave fewer than sixteen waves per CU in flight -- Dv = 256 at 7 x 7
+    (BASELINE's G2 / G3 width), the reference's default 9 x 9 window at Dv = 192 / 256 -- the planner takes eight-wave workgroups with store
+    tiles of 128 / 64 channels (xna_mfma_kernel HS: G2-k7 0.62 -> 0.69, G3 0.64 -> 0.69 of the HBM roof, profiles/r06_other_workloads.txt).
+    Only the way a tile's result leaves the LDS changes: the output is bit-identical to the whole-row arm (NAF_XNA_HS=0)."""
+    cases = ((512, 512, 32, 32, 1024, 7), (448, 448, 28, 28, 768, 9), (256, 320, 16, 20, 1024, 9), (160, 176, 10, 11, 1024, 5),
+             (448, 448, 32, 32, 1024, 7))        # the last one: 14-pixel cells (partial row tiles: the predicated flush)
+    assert _forward_hashes(cases, {"NAF_XNA_HS": "1"}) == _forward_hashes(cases, {"NAF_XNA_HS": "0"})
 
 
 @pytest.mark.parametrize("mode", ["train", "eval_requires_grad"])
