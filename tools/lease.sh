@@ -4,7 +4,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/lease.sh wino tests'
 set -u
 export TMPDIR=/tmp
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/.."; R=$PWD
 for step in "$@"; do
   out=gpurun_out/$step; mkdir -p "$out"
   case $step in
@@ -56,6 +56,17 @@ print('bench --steps 20: %.2f Mpix/s  %.4f ms (from idle %.4f)  attention %.4f m
     bwdfuzz)     # the cell-backward fuzz as a campaign (partial row tiles included)
       NAF_FUZZ_BWD_SEED=${NAF_FUZZ_BWD_SEED:-6161} NAF_FUZZ_BWD_CASES=${NAF_FUZZ_BWD_CASES:-300} timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "test_cell_backward_fuzz" > $out/bwd.log 2>&1; echo "rc=$?" >> $out/bwd.log
       grep -ac "^bwd fuzz" $out/bwd.log; grep -aE "passed|failed|rc=" $out/bwd.log | tail -3 ;;
+    trainprof)   # which kernels a training step of the reference's backward protocol spends its time in (torch.profiler table, three steps)
+      python tools/backward_speed_protocol.py --profile > $out/profile.txt 2>&1; grep -aE "^REF448|^P14" $out/profile.txt | cut -c1-200
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/tools/backward_speed_protocol.py > $out/trace.log 2>&1)
+      python3 - "$(ls $out/trace/*/*kernel_stats.csv | head -1)" <<'PY' | tee $out/kernel_stats.csv | cut -c1-180 | head -50
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("Name,Calls,TotalDurationNs,AverageNs,Percentage")
+for r in rows[:60]:
+    print(",".join(['"%s"' % r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
+PY
+      rm -rf $out/trace ;;
     *) echo "unknown step $step" ;;
   esac
 done
