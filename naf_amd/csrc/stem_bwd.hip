@@ -320,6 +320,136 @@ __global__ __launch_bounds__(256) void stem_conv0_wgrad_kernel(const Conv0WgradP
     }
 }
 
+
+// Round 6: the same sums on the matrix pipe.  The kernel above issues 27 LDS broadcasts and 27 FMAs per pixel and thread, each thread fetching ONE
+// bf16 of dy per pixel: 0.114 / 0.080 ms at 448^2 (3 x 3 / 1 x 1) for 51 MB of dy -- instruction bound at an eighth of the HBM rate.  As a GEMM
+// contracted over pixels: D[oc][n] += sum_px dy[px][oc] * P[px][n], n = (c, ty, tx) < 27, n = 27 a column of ones (the bias gradient), the rest 0:
+// v_mfma_f32_32x32x16_bf16 with A = dy through the transposing LDS read (as stem_wgrad.hip) and B built by each lane (column n, 8 consecutive
+// pixels) from the staged fp32 image rows, split into bf16 high and low parts (two MFMAs: the image keeps 16 mantissa bits).  A workgroup streams
+// segments of 32 pixels (grid-stride over batch x rows x segments; the next segment's dy and image taps are in flight while this one is
+// computed), a wave owns 32-channel tiles; partial sums meet in LDS and leave as coalesced atomics.
+namespace {
+typedef float c0_f32x16_t __attribute__((ext_vector_type(16)));
+}
+template <int KS, typename T>
+__global__ __launch_bounds__(256, 3) void stem_conv0_wgrad_mfma_kernel(const Conv0WgradParams p) {
+    constexpr int HALO = KS / 2, NTAP = 3 * KS * KS, SEGP = 32, IW = SEGP + 2 * HALO + 2;     // image strip width (padded)
+    extern __shared__ __attribute__((aligned(16))) unsigned char c0_smem[];
+    const int CP = (p.C + 31) & ~31, PITCH = CP + 32;                  // dy tile [32 px][PITCH] bf16
+    bf16_t* const Dt = reinterpret_cast<bf16_t*>(c0_smem);            // [2][SEGP * PITCH]
+    float* const Im = reinterpret_cast<float*>(Dt + 2 * SEGP * PITCH);   // [2][KS][3][IW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = (p.W + SEGP - 1) / SEGP, total = p.B * p.H * nseg;
+    const int nchunk = CP / 8, ppp = 256 / nchunk;                     // 16-byte chunks per pixel, pixels per pass
+    const int chunk = tid % nchunk, pl = tid / nchunk;
+    const int npass = (SEGP + ppp - 1) / ppp;                          // <= 4 (C >= 32 -> nchunk >= 4 -> ppp <= 64)
+    const bool chunk_live = chunk * 8 < p.C;
+
+    u32x4_t dreg[4];
+    float ireg[2];
+    auto issue = [&](int g) __attribute__((always_inline)) {
+        const int b = g / (p.H * nseg), rem = g - b * p.H * nseg, y = rem / nseg, x0 = (rem - y * nseg) * SEGP;
+        const bf16_t* dyb = p.dy + (int64_t)b * p.dys[0] + (int64_t)y * p.dys[1] + chunk * 8;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int px = pl + ppp * n;
+            dreg[n] = u32x4_t{0u, 0u, 0u, 0u};
+            if (n < npass && px < SEGP && x0 + px < p.W && chunk_live) dreg[n] = *reinterpret_cast<const u32x4_t*>(dyb + (int64_t)(x0 + px) * p.dys[2]);
+        }
+        const T* ib = reinterpret_cast<const T*>(p.image) + (int64_t)b * p.is[0];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int i = tid + 256 * n;
+            ireg[n] = 0.f;
+            if (i < KS * 3 * IW) {
+                const int r = i / (3 * IW), rem2 = i - r * 3 * IW, c = rem2 / IW, j = rem2 - c * IW;
+                const int yy = reflect_idx(y + r - HALO, p.H), xx = reflect_idx(x0 + j - HALO, p.W);
+                ireg[n] = (float)ib[c * p.is[1] + (int64_t)yy * p.is[2] + (int64_t)xx * p.is[3]];
+            }
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int px = pl + ppp * n;
+            if (n < npass && px < SEGP) *reinterpret_cast<u32x4_t*>(&Dt[buf * SEGP * PITCH + px * PITCH + chunk * 8]) = dreg[n];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int i = tid + 256 * n;
+            if (i < KS * 3 * IW) Im[buf * KS * 3 * IW + i] = ireg[n];
+        }
+    };
+    // this lane's column of the patch matrix: n = (c * KS + ty) * KS + tx -> image strip row ty, channel c, shift tx
+    const int ncol = lane & 31, kgrp = lane >> 5;
+    const int cc = ncol / (KS * KS), tyy = (ncol / KS) % KS, txx = ncol % KS;
+    const int b_off = ncol < NTAP ? (tyy * 3 + cc) * IW + txx + kgrp * 8 : 0;
+    const float b_one = ncol == NTAP ? 1.f : 0.f, b_live = ncol < NTAP ? 1.f : 0.f;
+    const int gi = lane >> 4, li = lane & 15;
+    const int frag_off = ((gi >> 1) * 8 + (li >> 2)) * PITCH + (gi & 1) * 16 + (li & 3) * 4;
+    const int ntile = CP / 32;                                         // 32-channel tiles: wave w owns tiles w, w + 4
+    c0_f32x16_t acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    int g = blockIdx.x;
+    if (g < total) {
+        issue(g);
+        commit(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; g < total; g += gridDim.x, buf ^= 1) {
+        const int gn = g + gridDim.x;
+        if (gn < total) issue(gn);
+        const bf16_t* dt = Dt + buf * SEGP * PITCH;
+        const float* im = Im + buf * KS * 3 * IW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(im[b_off + ks * 16 + e], b_live, b_one);
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (bf16_t)v[e];
+                lo[e] = (bf16_t)(v[e] - (float)hi[e]);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = wave + 4 * m;
+                if (t < ntile) {
+                    const bf16_t* a0 = dt + (ks * 16) * PITCH + t * 32 + frag_off;
+                    const bf16x4_t l4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)a0);
+                    const bf16x4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((NAF_LDS bf16x4_t*)(a0 + 4 * PITCH));
+                    const bf16x8_t fa = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, hi, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lo, acc[m], 0, 0, 0);
+                }
+            }
+        }
+        if (gn < total) commit(buf ^ 1);      // the other buffer: its readers finished before the barrier of the step before
+        __syncthreads();
+    }
+    // D[oc = 32 t + 8 (r >> 2) + 4 half + (r & 3)][n = lane & 31] -> LDS [n][oc] -> atomics with lanes along oc
+    float* red = reinterpret_cast<float*>(c0_smem);     // [NTAP + 1][CP]
+    const int half = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int t = wave + 4 * m;
+        if (t < ntile && ncol <= NTAP)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[ncol * CP + t * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] = acc[m][r];
+    }
+    __syncthreads();
+    for (int i = tid; i < (NTAP + 1) * CP; i += 256) {
+        const int n = i / CP, oc = i - n * CP;
+        if (oc < p.C) atomicAdd(n < NTAP ? &p.dw[n * p.C + oc] : &p.db[oc], red[i]);
+    }
+}
+
 int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t s) {
     Conv0WgradParams p;
     p.dy = static_cast<const bf16_t*>(a->dy); p.image = a->image; p.dw = a->dw; p.db = a->db;
@@ -328,6 +458,21 @@ int naf_launch_stem_conv0_wgrad(const naf_stem_conv0_wgrad_args* a, hipStream_t 
     p.cw_log2 = p.C <= 64 ? 6 : (p.C <= 128 ? 7 : 8);
     for (int i = 0; i < 3; ++i) p.dys[i] = a->dy_stride[i];
     for (int i = 0; i < 4; ++i) p.is[i] = a->image_stride[i];
+    static const bool v1 = [] { const char* e = naf_knob("NAF_CONV0_WGRAD_V1"); return e && atoi(e) != 0; }();   // A/B knob: the scalar kernel
+    if (!v1 && p.C >= 32) {
+        const int CP = (p.C + 31) & ~31, IW = 32 + 2 * (a->ksize / 2) + 2;
+        size_t lds = (size_t)2 * 32 * (CP + 32) * 2 + (size_t)2 * a->ksize * 3 * IW * 4;
+        const size_t redb = (size_t)(3 * a->ksize * a->ksize + 1) * CP * 4;
+        if (lds < redb) lds = redb;
+        const int nseg = (a->W + 31) / 32, total = a->B * a->H * nseg;
+        int blocks = naf_cu_count() * 3;        // three workgroups per CU (160 registers)
+        if (blocks > total) blocks = total;
+#define NAF_C0M(KS, T) hipLaunchKernelGGL((stem_conv0_wgrad_mfma_kernel<KS, T>), dim3(blocks), dim3(256), lds, s, p)
+        if (a->ksize == 3) { if (a->image_dtype == NAF_BF16) NAF_C0M(3, bf16_t); else NAF_C0M(3, float); }
+        else { if (a->image_dtype == NAF_BF16) NAF_C0M(1, bf16_t); else NAF_C0M(1, float); }
+#undef NAF_C0M
+        return naf_check_launch("stem_conv0_wgrad_mfma_kernel");
+    }
     const int target = naf_cu_count() * 2;
     int rows = (a->H * a->B + target - 1) / target;
     if (rows < 1) rows = 1;

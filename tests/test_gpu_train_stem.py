@@ -96,7 +96,11 @@ def test_act_backward(dev, fold, H, W, C):
 
 
 @pytest.mark.parametrize("k,B,H,W,C", [(3, 1, 20, 64, 128), (1, 2, 9, 32, 128), (3, 2, 13, 45, 128), (1, 1, 7, 19, 128), (3, 1, 2, 2, 128),
-                                       (3, 2, 13, 45, 48), (1, 1, 9, 33, 96), (3, 1, 17, 40, 256), (3, 1, 6, 70, 144), (1, 2, 5, 5, 16)])
+                                       (3, 2, 13, 45, 48), (1, 1, 9, 33, 96), (3, 1, 17, 40, 256), (3, 1, 6, 70, 144), (1, 2, 5, 5, 16),
+                                       # the pipelined kernel (round 6): ranges cut inside image rows (commit-only extension segments at either end), last
+                                       # segments of 22 / 4 / 13 pixels, odd and even segment counts per workgroup, one-segment workgroups, batch 2
+                                       (3, 1, 200, 96, 128), (3, 2, 100, 150, 128), (3, 1, 40, 36, 128), (1, 1, 300, 160, 128), (3, 1, 64, 448, 128),
+                                       (1, 2, 64, 100, 128), (3, 1, 173, 77, 128), (3, 1, 33, 35, 128), (3, 3, 31, 64, 128)])
 def test_weight_gradient(dev, k, B, H, W, C):
     """naf_stem_wgrad vs autograd of conv(reflect_pad(SiLU(GroupNorm(x)))) w.r.t. the weight, on the same bf16 tensors; the widths
     other than 128 run stem_generic_bwd.hip (round 6: 144 and 256 split their output channels over two workgroups)."""
@@ -121,7 +125,10 @@ def test_weight_gradient(dev, k, B, H, W, C):
         assert rel(dw[:, :, t // k, t % k], w.grad[:, :, t // k, t % k]) < 5e-3, t
 
 
-@pytest.mark.parametrize("k,B,H,W,C", [(3, 2, 12, 20, 128), (1, 1, 9, 33, 128), (3, 1, 2, 2, 128), (3, 2, 11, 19, 48), (1, 1, 8, 8, 256), (3, 1, 5, 6, 16)])
+@pytest.mark.parametrize("k,B,H,W,C", [(3, 2, 12, 20, 128), (1, 1, 9, 33, 128), (3, 1, 2, 2, 128), (3, 2, 11, 19, 48), (1, 1, 8, 8, 256), (3, 1, 5, 6, 16),
+                                       # round 6, the matrix-pipe kernel: several segments per workgroup, a last segment of 4 / 13 pixels, every channel-tile count
+                                       (3, 1, 70, 100, 128), (1, 2, 64, 96, 128), (3, 1, 40, 45, 160), (3, 2, 150, 77, 128), (1, 1, 90, 64, 96), (3, 1, 33, 200, 256),
+                                       (3, 1, 24, 36, 32)])
 def test_first_convolution_gradients(dev, k, B, H, W, C):
     """naf_stem_conv0_wgrad (weight, bias) and naf_stem_conv0_dgrad (image; round 6) vs autograd of Conv2d(3 -> C, reflect)."""
     from naf_amd import ops

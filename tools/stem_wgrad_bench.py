@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from naf_amd import ops
 dev = torch.device("cuda:0")
-for H in (448, 1024):
+for H in ([int(os.environ['WGRAD_H'])] if os.environ.get('WGRAD_H') else (448, 1024)):
     x = torch.randn(1, H, H, 128, device=dev).to(torch.bfloat16)
     dy = torch.randn(1, H, H, 128, device=dev).to(torch.bfloat16)
     xd = x.double().reshape(1, -1, 8, 16)
