@@ -15,6 +15,7 @@
 // Two phases over (da, x): sums, then apply; both recompute z and silu'(z) (the passes are HBM-bound).
 // Layout as in the forward stem: channels-last bf16, thread -> (pixel lane, 16-byte chunk of 8 channels).
 #include "naf_common.h"
+#include <type_traits>
 
 namespace {
 struct StemActParams {
@@ -132,49 +133,139 @@ __global__ __launch_bounds__(256) void stem_act_bwd_kernel(const StemActParams p
     const bf16_t* xb = p.x + (int64_t)b * p.xs[0] + chunk * 8;
     const bf16_t* db = p.da + (int64_t)b * p.das[0] + chunk * 8;   // fold: points at padded (0, 0); interior (y, x) is (y + 1, x + 1)
     bf16_t* ob = PHASE == 2 ? p.dx + (int64_t)b * p.dxs[0] + chunk * 8 : nullptr;
+    // one pixel's arithmetic: dz = da * silu'(z), then the sums (phase 1) or dx (phase 2)
+    auto pixel = [&](const bf16x8_t xv, const float (&da)[8], int y, int x) __attribute__((always_inline)) {
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = (float)xv[e];
+            const float z = fmaf(xf, sc[e], sh[e]);
+            const float s = sigmoidf_fast(z);
+            const float dz = da[e] * (s * fmaf(z, 1.0f - s, 1.0f));
+            const float xh = fmaf(xf, rs[e], rm[e]);
+            if (PHASE == 1) {
+                s1[e] += dz;
+                s2[e] = fmaf(dz, xh, s2[e]);
+            } else {
+                o[e] = (bf16_t)(rs[e] * (gam[e] * dz - m1[e] - xh * m2[e]));
+            }
+        }
+        if (PHASE == 2) *reinterpret_cast<bf16x8_t*>(ob + (int64_t)y * p.dxs[1] + (int64_t)x * p.dxs[2]) = o;
+    };
+    // any pixel: with `fold`, the adjoint of reflect padding (pad 1) on load -- padded row -1 mirrors row 1, padded row H mirrors row H - 2
+    auto general = [&](int y, int x) __attribute__((always_inline)) {
+        const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xb + (int64_t)y * p.xs[1] + (int64_t)x * p.xs[2]);
+        float da[8];
+        if (!p.fold) {
+            const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)y * p.das[1] + (int64_t)x * p.das[2]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) da[e] = (float)dv[e];
+        } else {
+            const int ry[3] = {y, (y == 1) ? -1 : -2, (y == p.H - 2) ? p.H : -2};
+            const int rx[3] = {x, (x == 1) ? -1 : -2, (x == p.W - 2) ? p.W : -2};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) da[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (ry[i] == -2) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (rx[j] == -2) continue;
+                    const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)(ry[i] + 1) * p.das[1] + (int64_t)(rx[j] + 1) * p.das[2]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) da[e] += (float)dv[e];
+                }
+            }
+        }
+        pixel(xv, da, y, x);
+    };
     if (active) {
-        for (int y = r0; y < r1; ++y) {
-            for (int x = plane; x < p.W; x += nplanes) {
-                const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xb + (int64_t)y * p.xs[1] + (int64_t)x * p.xs[2]);
+        // Round 6: pixels that take ONE da load (every pixel without `fold`; with it, rows other than 1 / H - 2 and columns 2 .. W - 3) go four at a
+        // time with their eight loads issued together -- a workgroup is one image row and a thread's pixels came one dependent pair of
+        // loads after the other (2.3 TB/s in the sums pass at 448^2)
+        const int fo = p.fold ? 1 : 0;
+        const bf16x8_t zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        // pixels [x, x_hi) of this thread's sequence whose da is ONE load (MIR: plus the mirrored padded row), four at a time
+        auto run = [&](auto mir, int y, int& x, int x_hi, const bf16_t* xr, const bf16_t* dr, const bf16_t* dm) __attribute__((always_inline)) {
+            constexpr bool MIR = decltype(mir)::value;
+            for (; x + 3 * nplanes < x_hi; x += 4 * nplanes) {
+                bf16x8_t xv[4], dv[4], mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const bf16x8_t*>(xr + (int64_t)(x + u * nplanes) * p.xs[2]);
+                    dv[u] = *reinterpret_cast<const bf16x8_t*>(dr + (int64_t)(x + u * nplanes) * p.das[2]);
+                    if (MIR) mv[u] = *reinterpret_cast<const bf16x8_t*>(dm + (int64_t)(x + u * nplanes) * p.das[2]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float da[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) da[e] = MIR ? (float)dv[u][e] + (float)mv[u][e] : (float)dv[u][e];
+                    pixel(xv[u], da, y, x + u * nplanes);
+                }
+            }
+            for (; x < x_hi; x += nplanes) {
+                const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(xr + (int64_t)x * p.xs[2]);
+                const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(dr + (int64_t)x * p.das[2]);
                 float da[8];
-                if (!p.fold) {
-                    const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)y * p.das[1] + (int64_t)x * p.das[2]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) da[e] = (float)dv[e];
-                } else {
-                    // adjoint of reflect padding (pad 1): padded row -1 mirrors row 1, padded row H mirrors row H - 2
-                    const int ry[3] = {y, (y == 1) ? -1 : -2, (y == p.H - 2) ? p.H : -2};
-                    const int rx[3] = {x, (x == 1) ? -1 : -2, (x == p.W - 2) ? p.W : -2};
+                for (int e = 0; e < 8; ++e) da[e] = (float)dv[e];
+                if (MIR) {
+                    const bf16x8_t mv = *reinterpret_cast<const bf16x8_t*>(dm + (int64_t)x * p.das[2]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) da[e] = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (ry[i] == -2) continue;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (rx[j] == -2) continue;
-                            const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(db + (int64_t)(ry[i] + 1) * p.das[1] + (int64_t)(rx[j] + 1) * p.das[2]);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) da[e] += (float)dv[e];
-                        }
-                    }
+                    for (int e = 0; e < 8; ++e) da[e] += (float)mv[e];
                 }
-                bf16x8_t o;
+                pixel(xv, da, y, x);
+            }
+        };
+        for (int y = r0; y < r1; ++y) {
+            int x = plane;
+            const bool top = p.fold && y == 1, bot = p.fold && y == p.H - 2;
+            if (p.fold && (p.W < 4 || (top && bot))) {
+                for (; x < p.W; x += nplanes) general(y, x);
+                continue;
+            }
+            const bf16_t* xr = xb + (int64_t)y * p.xs[1];
+            const bf16_t* dr = db + (int64_t)(y + fo) * p.das[1] + (int64_t)fo * p.das[2];   // da of pixel (y, x) at dr + x * das[2]
+            const int xlast = plane + ((p.W - 1 - plane) / nplanes) * nplanes;
+            const bool hasL = p.fold && plane < 2, hasR = p.fold && plane < p.W && xlast >= p.W - 2 && xlast >= 2;
+            const int x_hi = p.fold ? p.W - 2 : p.W;
+            if (top || bot) {
+                // rows 1 / H - 2 also take the padded rows -1 / H.  (Round 6: through the same batched loads -- as dependent load-then-use per
+                // pixel these two rows' workgroups ran three to four times as long as every other one and set the kernel's duration: the
+                // folded call took 45 % longer than the plain one on the same bytes)
+                const bf16_t* dm = db + (int64_t)(top ? 0 : p.H + 1) * p.das[1] + (int64_t)fo * p.das[2];
+                if (hasL) { general(y, plane); x += nplanes; }
+                run(std::true_type{}, y, x, x_hi, xr, dr, dm);
+                if (hasR) general(y, xlast);
+                continue;
+            }
+            // `fold`: the row's first two and last two pixels (columns 1 and W - 2 also take the padded columns -1 / W): their loads are
+            // issued here and used behind the row's other pixels
+            bf16x8_t exv[2] = {zero8, zero8}, edv[2] = {zero8, zero8}, emv[2] = {zero8, zero8};
+            if (hasL) {
+                exv[0] = *reinterpret_cast<const bf16x8_t*>(xr + (int64_t)plane * p.xs[2]);
+                edv[0] = *reinterpret_cast<const bf16x8_t*>(dr + (int64_t)plane * p.das[2]);
+                if (plane == 1) emv[0] = *reinterpret_cast<const bf16x8_t*>(dr - 1 * p.das[2]);            // padded column -1
+                x += nplanes;
+            }
+            if (hasR) {
+                exv[1] = *reinterpret_cast<const bf16x8_t*>(xr + (int64_t)xlast * p.xs[2]);
+                edv[1] = *reinterpret_cast<const bf16x8_t*>(dr + (int64_t)xlast * p.das[2]);
+                if (xlast == p.W - 2) emv[1] = *reinterpret_cast<const bf16x8_t*>(dr + (int64_t)p.W * p.das[2]);   // padded column W
+            }
+            run(std::false_type{}, y, x, x_hi, xr, dr, nullptr);
+            if (hasL) {
+                float da[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xf = (float)xv[e];
-                    const float z = fmaf(xf, sc[e], sh[e]);
-                    const float s = sigmoidf_fast(z);
-                    const float dz = da[e] * (s * fmaf(z, 1.0f - s, 1.0f));
-                    const float xh = fmaf(xf, rs[e], rm[e]);
-                    if (PHASE == 1) {
-                        s1[e] += dz;
-                        s2[e] = fmaf(dz, xh, s2[e]);
-                    } else {
-                        o[e] = (bf16_t)(rs[e] * (gam[e] * dz - m1[e] - xh * m2[e]));
-                    }
-                }
-                if (PHASE == 2) *reinterpret_cast<bf16x8_t*>(ob + (int64_t)y * p.dxs[1] + (int64_t)x * p.dxs[2]) = o;
+                for (int e = 0; e < 8; ++e) da[e] = (float)edv[0][e] + (float)emv[0][e];
+                pixel(exv[0], da, y, plane);
+            }
+            if (hasR) {
+                float da[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) da[e] = (float)edv[1][e] + (float)emv[1][e];
+                pixel(exv[1], da, y, xlast);
             }
         }
     }
@@ -206,7 +297,10 @@ static int act_common(StemActParams& p, int C, int H, const char* who) {
     p.tpp = tpp;
     p.C = C;
     // ~8 blocks per CU and sample: enough to fill the chip at batch 1, few enough that the sums' atomics stay cheap
-    const int target = naf_cu_count() * 8;
+#ifndef NAF_ACT_BLOCKS_PER_CU
+#define NAF_ACT_BLOCKS_PER_CU 8
+#endif
+    const int target = naf_cu_count() * NAF_ACT_BLOCKS_PER_CU;
     int rows = (H + target - 1) / target;
     if (rows < 1) rows = 1;
     p.rows_per_block = rows;

@@ -58,7 +58,7 @@ print('bench --steps 20: %.2f Mpix/s  %.4f ms (from idle %.4f)  attention %.4f m
       grep -ac "^bwd fuzz" $out/bwd.log; grep -aE "passed|failed|rc=" $out/bwd.log | tail -3 ;;
     trainprof)   # which kernels a training step of the reference's backward protocol spends its time in (torch.profiler table, three steps)
       python tools/backward_speed_protocol.py --profile > $out/profile.txt 2>&1; grep -aE "^REF448|^P14" $out/profile.txt | cut -c1-200
-      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/tools/backward_speed_protocol.py > $out/trace.log 2>&1)
+      (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -- python $R/tools/backward_speed_protocol.py > $R/$out/trace.log 2>&1)
       python3 - "$(ls $out/trace/*/*kernel_stats.csv | head -1)" <<'PY' | tee $out/kernel_stats.csv | cut -c1-180 | head -50
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
