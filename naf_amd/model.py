@@ -247,10 +247,28 @@ class _HipStem(torch.autograd.Function):
         grads = []
         dimage = None
         need_img = ctx.needs_input_grad[1]
-        for br, seq in enumerate((enc.encoder, enc.sem_encoder)):
+        # every accumulator of the step -- weight / bias gradients (fp32 atomics) and the norm layers' sums (fp64 atomics) -- lives in ONE zeroed
+        # buffer per dtype, and the sums are reduced over the batch once at the end (a memset, a reduction and two casts per LAYER before)
+        branches = (enc.encoder, enc.sem_encoder)
+        sizes = []
+        for seq in branches:
+            lay = _stem_layers(seq)
+            kk, k0 = (lay[0][1].kernel_size[0] if lay else 1), seq[0].kernel_size[0]
+            sizes.append([(3 * k0 * k0 + 1) * hid] + [kk * kk * hid * hid + hid] * len(lay))
+        acc32 = torch.zeros((sum(sum(z) for z in sizes),), dtype=torch.float32, device=dev)
+        nl_max = max(len(z) - 1 for z in sizes)
+        acc64 = torch.zeros((2, max(nl_max, 1), B, hid, 2), dtype=torch.float64, device=dev)
+        pos32 = 0
+        for br, seq in enumerate(branches):
             ys = saved[br]
             layers = _stem_layers(seq)
             k = layers[0][1].kernel_size[0] if layers else 1
+            out0 = acc32[pos32:pos32 + sizes[br][0]]
+            pos32 += sizes[br][0]
+            outs = []
+            for z in sizes[br][1:]:
+                outs.append(acc32[pos32:pos32 + z])
+                pos32 += z
             # 3x3 branch: a layer's output gradient lives in the interior of a buffer with a 2-pixel ZERO border (what the
             # data-gradient convolution of the padded domain reads); naf_stem_act_bwd writes the next one straight into
             # the other buffer's interior, so only the branch's incoming gradient is ever copied
@@ -266,7 +284,7 @@ class _HipStem(torch.autograd.Function):
                 w = conv.weight.detach()
                 gw, gb = norm.weight.detach().float(), norm.bias.detach().float()
                 # weight / bias gradient: naf_stem_wgrad (pixel-contraction GEMM; a = SiLU(GroupNorm(x)) recomputed in its loader)
-                dw, db = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k, with_bias=True)
+                dw, db = ops.stem_wgrad(gl, ys[li], stats[br, li], gw, gb, norm.eps, k, with_bias=True, out=outs[li])
                 # data gradient: the same conv kernel, plain, on the flipped / transposed weights
                 wt = ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1))
                 if k == 3:
@@ -274,31 +292,34 @@ class _HipStem(torch.autograd.Function):
                     full = torch.empty_like(ext[cur])
                     ops.stem_conv_plain(ext[cur], wt, full)
                     dx = ext[cur ^ 1][:, 2:H + 2, 2:W + 2]
-                    sums = ops.stem_act_bwd(full[:, 1:H + 3, 1:W + 3], ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=True)
+                    ops.stem_act_bwd(full[:, 1:H + 3, 1:W + 3], ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=True, sums=acc64[br, li])
                     del full
                 else:
                     da = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
                     ops.stem_conv_plain(gl, wt, da)
                     dx = torch.empty((B, H, W, hid), dtype=torch.bfloat16, device=dev)
-                    sums = ops.stem_act_bwd(da, ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=False)
+                    ops.stem_act_bwd(da, ys[li], stats[br, li], gw, gb, norm.eps, dx, fold=False, sums=acc64[br, li])
                     del da
-                s32 = sums.sum(0).float()
-                bgrads.append((s32[:, 1].to(norm.weight.dtype), s32[:, 0].to(norm.bias.dtype),
-                               dw.to(conv.weight.dtype), db.to(conv.bias.dtype)))
+                bgrads.append((li, norm, dw.to(conv.weight.dtype), db.to(conv.bias.dtype)))
                 gl = dx
             # first convolution (3 -> hid on the image): naf_stem_conv0_wgrad for the parameters and, when the image wants a
             # gradient, naf_stem_conv0_dgrad (round 6: no ATen / MIOpen convolution is left on the training path)
             conv0 = seq[0]
-            dw0, db0 = ops.stem_conv0_wgrad(gl, image.detach(), conv0.kernel_size[0])
-            grads += [dw0.to(conv0.weight.dtype), db0.to(conv0.bias.dtype)]
+            dw0, db0 = ops.stem_conv0_wgrad(gl, image.detach(), conv0.kernel_size[0], out=out0)
+            grads.append((br, dw0.to(conv0.weight.dtype), db0.to(conv0.bias.dtype), bgrads[::-1]))
             if need_img:
                 if dimage is None:
                     dimage = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
                     ops.stem_conv0_dgrad(gl, conv0.weight.detach().float().contiguous(), dimage, accumulate=False)
                 else:
                     ops.stem_conv0_dgrad(gl, conv0.weight.detach().float().contiguous(), dimage, accumulate=True)
-            for t in reversed(bgrads):
-                grads += list(t)
+        s32 = acc64.sum(2).float()      # [branch, layer, hid, {d bias, d weight}]: one reduction over the batch for every norm layer
+        flat = []
+        for br, dw0, db0, per_layer in grads:          # the order of _hip_stem_params
+            flat += [dw0, db0]
+            for li, norm, dw, db in per_layer:
+                flat += [s32[br, li, :, 1].to(norm.weight.dtype), s32[br, li, :, 0].to(norm.bias.dtype), dw, db]
+        grads = flat
         assert len(grads) == ctx.nparams
         return (None, dimage.to(image.dtype) if dimage is not None else None, *grads)
 

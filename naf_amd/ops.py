@@ -279,18 +279,25 @@ def stem_act(x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, g
 
 
 def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tensor], gn_weight: Optional[torch.Tensor],
-               gn_bias: Optional[torch.Tensor], eps: float, ksize: int, with_bias: bool = False):
+               gn_bias: Optional[torch.Tensor], eps: float, ksize: int, with_bias: bool = False, out: Optional[torch.Tensor] = None):
     """Weight gradient [C, C, k, k] (fp32) of y = conv_k(SiLU(GroupNorm(x))) + b: ``naf_stem_wgrad``; dy, x bf16 [B,H,W,C]
     (C = 128: the hand-scheduled kernel of stem_wgrad.hip; other multiples of 16 up to 256: stem_generic_bwd.hip).
     ``stats_in=None``: x already is the activation SiLU(GroupNorm(.)) (``stem_act(..., pad=0)``).  ``with_bias``: also returns
-    the bias gradient [128] (sum of dy over pixels, accumulated by the same kernel)."""
+    the bias gradient [128] (sum of dy over pixels, accumulated by the same kernel).  ``out``: a ZEROED fp32 buffer of
+    ``k*k*C*C + C`` elements to accumulate into (a training step zeroes one buffer for all its layers) instead of a new one."""
     lib = _lib.load()
     _gpu(x, "x")
     B, H, W, Cc = x.shape
     if (Cc % 16 or not (16 <= Cc <= 256) or tuple(dy.shape) != (B, H, W, Cc) or dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16
             or dy.stride(3) != 1 or x.stride(3) != 1):
         raise ValueError("stem_wgrad: bf16 [B,H,W,C] tensors with channels contiguous, C a multiple of 16 up to 256")
-    buf = torch.zeros((ksize * ksize * Cc * Cc + Cc,), dtype=torch.float32, device=x.device)   # one memset for both
+    n_out = ksize * ksize * Cc * Cc + Cc
+    if out is not None:
+        if out.dtype != torch.float32 or out.numel() != n_out or not out.is_contiguous() or out.device != x.device:
+            raise ValueError(f"stem_wgrad: out must be a contiguous zeroed f32 buffer of {n_out} elements")
+        buf = out.view(-1)
+    else:
+        buf = torch.zeros((n_out,), dtype=torch.float32, device=x.device)   # one memset for both
     dw = buf[: ksize * ksize * Cc * Cc].view(ksize, ksize, Cc, Cc)                       # taps outermost: coalesced atomics
     db = buf[ksize * ksize * Cc * Cc:]
     a = _lib.StemWgradArgs()
@@ -309,7 +316,7 @@ def stem_wgrad(dy: torch.Tensor, x: torch.Tensor, stats_in: Optional[torch.Tenso
     return (dw.permute(2, 3, 0, 1), db) if with_bias else dw.permute(2, 3, 0, 1)
 
 
-def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int, out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dW [C, 3, k, k], db [C]) of the first convolution (``naf_stem_conv0_wgrad``): dy bf16 [B,H,W,C], image [B,3,H,W]."""
     lib = _lib.load()
     _gpu(dy, "dy")
@@ -319,7 +326,12 @@ def stem_conv0_wgrad(dy: torch.Tensor, image: torch.Tensor, ksize: int) -> Tuple
     if image.dtype not in _DT:
         image = image.float()
     nt = 3 * ksize * ksize
-    buf = torch.zeros(((nt + 1) * Cc,), dtype=torch.float32, device=dy.device)
+    if out is not None:      # a ZEROED contiguous f32 buffer of (3 k k + 1) C elements (see stem_wgrad)
+        if out.dtype != torch.float32 or out.numel() != (nt + 1) * Cc or not out.is_contiguous() or out.device != dy.device:
+            raise ValueError(f"stem_conv0_wgrad: out must be a contiguous zeroed f32 buffer of {(nt + 1) * Cc} elements")
+        buf = out.view(-1)
+    else:
+        buf = torch.zeros(((nt + 1) * Cc,), dtype=torch.float32, device=dy.device)
     a = _lib.StemConv0WgradArgs()
     a.dy, a.image, a.dw, a.db = dy.data_ptr(), image.data_ptr(), buf.data_ptr(), buf[nt * Cc:].data_ptr()
     a.image_dtype, a.ksize, a.B, a.H, a.W, a.channels = _DT[image.dtype], int(ksize), B, H, W, Cc
@@ -352,7 +364,7 @@ def stem_conv0_dgrad(dy: torch.Tensor, weight: torch.Tensor, dimage: torch.Tenso
 
 
 def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_weight: torch.Tensor, gn_bias: torch.Tensor,
-                 eps: float, dx: torch.Tensor, fold: bool = False) -> torch.Tensor:
+                 eps: float, dx: torch.Tensor, fold: bool = False, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Backward of SiLU(GroupNorm(x)) (``naf_stem_act_bwd``): writes dx (bf16 [B,H,W,C] view) and returns the fp64 sums
     [B, C, 2] = per sample {d gn_bias, d gn_weight}.  ``fold``: da is [B, H+2, W+2, C], the gradient on the reflect-padded
     domain."""
@@ -362,7 +374,11 @@ def stem_act_bwd(da: torch.Tensor, x: torch.Tensor, stats_in: torch.Tensor, gn_w
     want = (B, H + 2, W + 2, Cc) if fold else (B, H, W, Cc)
     if tuple(da.shape) != want or da.dtype != torch.bfloat16 or da.stride(3) != 1 or dx.stride(3) != 1 or tuple(dx.shape) != (B, H, W, Cc):
         raise ValueError(f"stem_act_bwd: da {tuple(da.shape)} (want {want}) / dx {tuple(dx.shape)}")
-    sums = torch.zeros((B, Cc, 2), dtype=torch.float64, device=x.device)
+    if sums is not None:     # a ZEROED contiguous fp64 [B, C, 2] to accumulate into
+        if sums.dtype != torch.float64 or tuple(sums.shape) != (B, Cc, 2) or not sums.is_contiguous() or sums.device != x.device:
+            raise ValueError(f"stem_act_bwd: sums must be a contiguous zeroed f64 [{B}, {Cc}, 2]")
+    else:
+        sums = torch.zeros((B, Cc, 2), dtype=torch.float64, device=x.device)
     a = _lib.StemActBwdArgs()
     a.da, a.x, a.dx = da.data_ptr(), x.data_ptr(), dx.data_ptr()
     a.gn_weight, a.gn_bias, a.stats_in, a.sums = gn_weight.data_ptr(), gn_bias.data_ptr(), _stats_ptr(stats_in, B, "stem_act_bwd"), sums.data_ptr()
